@@ -1,0 +1,226 @@
+/*
+ * strugatzki_amd.h -- C ABI of the MI355X (gfx950) implementation of
+ * Strugatzki's similarity hot path.
+ *
+ * This is the surface a JNI shim (or any other FFI) binds.  The reference has
+ * no native boundary of its own: each entry point below names the lines of the
+ * reference's Scala implementation whose work it takes over.  Paths are
+ * relative to src/main/scala/de/sciss/strugatzki/ of the reference.
+ *
+ * Conventions
+ *   - every function returns SGZ_OK (0) or a negative SGZ_E_* code; the text of
+ *     the last failure of a context is available from sgz_last_error();
+ *   - feature frames are "interleaved": frame-major float32 [numFrames][numCh]
+ *     with numCh = numCoeffs + 1 and channel 0 = loudness, exactly the sample
+ *     order of a feature AIFF (impl/NonRealtimeProcessor.scala:164-165,
+ *     impl/FeatureExtractionImpl.scala:52-53);
+ *   - the caller owns every host buffer passed in or out; the library owns all
+ *     device memory behind the opaque context; a context is bound to one GPU
+ *     and one HIP stream and must not be used from two threads at once;
+ *   - nothing here falls back to the CPU: without a usable GPU every compute
+ *     entry point fails with SGZ_E_HIP.
+ */
+#ifndef STRUGATZKI_AMD_H
+#define STRUGATZKI_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGZ_API __attribute__((visibility("default")))
+
+#define SGZ_OK 0
+#define SGZ_E_ARG (-1)      /* illegal argument (IllegalArgumentException on the JVM side) */
+#define SGZ_E_HIP (-2)      /* HIP runtime failure / no device */
+#define SGZ_E_STATE (-3)    /* call order violated (e.g. correlate before set_target) */
+#define SGZ_E_OVERFLOW (-4) /* an output buffer was too small; counts are still reported */
+#define SGZ_E_IO (-5)       /* file could not be read / written / parsed (IOException) */
+
+#define SGZ_MAX_CHANNELS 64
+
+typedef struct sgz_context sgz_context;
+
+/* One database window that passed the compaction threshold. */
+typedef struct sgz_candidate {
+    int32_t file;    /* index of the database file (order of sgz_db_add_*) */
+    int32_t offset;  /* window start in feature frames = logicalOff of the reference loop */
+    float sim;
+    float boost;
+} sgz_candidate;
+
+/* Mirrors FeatureCorrelation.Match (FeatureCorrelation.scala:54) with the file
+ * given as database index. */
+typedef struct sgz_match {
+    float sim;
+    float boost_in;
+    float boost_out;
+    int32_t file;
+    int64_t start; /* punch.start, sample frames */
+    int64_t stop;  /* punch.stop */
+} sgz_match;
+
+/* Mirrors FeatureSegmentation.Break (FeatureSegmentation.scala:47). */
+typedef struct sgz_break {
+    float sim;
+    int32_t pad_;
+    int64_t pos; /* sample frames */
+} sgz_break;
+
+/* Region of a synthetic database file that is a noisy copy of another file. */
+typedef struct sgz_plant {
+    int64_t file;
+    int64_t offset;
+    int64_t src_file;
+    int64_t src_offset;
+    int64_t length;
+    float amp;
+    float gain;
+} sgz_plant;
+
+/* ---- life cycle --------------------------------------------------------- */
+
+/* Creates a context on GPU `device`.  `hip_stream` is a hipStream_t to run on
+ * (NULL: the context creates its own).  No counterpart in the reference; it
+ * stands for the per-processor state a `new impl.FeatureCorrelationImpl(config)`
+ * holds (FeatureCorrelation.scala:81). */
+SGZ_API int sgz_create(int device, void *hip_stream, sgz_context **out);
+SGZ_API void sgz_destroy(sgz_context *ctx);
+SGZ_API const char *sgz_last_error(const sgz_context *ctx);
+SGZ_API const char *sgz_version(void);
+/* Blocks until everything queued on the context's stream has finished. */
+SGZ_API int sgz_synchronize(sgz_context *ctx);
+
+/* ---- database ----------------------------------------------------------- */
+
+/* Drops all database files; the next files must have num_channels channels.
+ * Replaces the per-query opening of every feature file,
+ * impl/FeatureCorrelationImpl.scala:161-169. */
+SGZ_API int sgz_db_reset(sgz_context *ctx, int num_channels);
+/* Copies one feature file (raw, un-normalised) to the GPU and appends it.
+ * Replaces AudioFile.openRead + afExtr.read, impl/FeatureCorrelationImpl.scala:169,195. */
+SGZ_API int sgz_db_add_file(sgz_context *ctx, const float *frames, int64_t num_frames);
+/* Appends a feature file that already sits in device memory (not copied, not
+ * freed; must stay valid until the next sgz_db_reset). */
+SGZ_API int sgz_db_add_file_device(sgz_context *ctx, const float *device_frames, int64_t num_frames);
+/* Appends a synthetic feature file generated on the GPU: moving-average
+ * filtered counter-based noise, optionally overlaid with noisy copies
+ * (`plants`, those whose .file == file_id apply).  Benchmark / test input only;
+ * no counterpart in the reference. */
+SGZ_API int sgz_db_add_synthetic(sgz_context *ctx, uint64_t seed, int64_t file_id, int64_t num_frames,
+                         const sgz_plant *plants, int num_plants);
+SGZ_API int sgz_db_num_files(const sgz_context *ctx);
+SGZ_API int64_t sgz_db_file_frames(const sgz_context *ctx, int file);
+/* Copies the raw frames of a database file back to the host. */
+SGZ_API int sgz_db_read_file(sgz_context *ctx, int file, float *frames_out);
+
+/* Per-channel (min, max) pairs, norms[2*ch], norms[2*ch+1]; NULL switches
+ * normalisation off.  Replaces the feat_norms.aif read of
+ * impl/FeatureCorrelationImpl.scala:61-71 and MathUtil.normalize
+ * (impl/MathUtil.scala:132-152), which the kernels apply on the fly. */
+SGZ_API int sgz_set_norms(sgz_context *ctx, const float *norms);
+
+/* ---- FeatureCorrelation ------------------------------------------------- */
+
+/* Sets the punch-in target: `frames` are the raw interleaved feature frames of
+ * the target span (L = num_frames >= 1).  Normalises them, computes the
+ * temporal / spectral mean and std-dev and ln(avg loudness)
+ * (readInBuffer, impl/FeatureCorrelationImpl.scala:83-98). */
+SGZ_API int sgz_corr_set_target(sgz_context *ctx, const float *frames, int num_frames,
+                        float temporal_weight, float max_boost);
+
+/* Number of sliding windows the reference loop visits for database file `file`
+ * with the current target (impl/FeatureCorrelationImpl.scala:182-190,242-246):
+ * frames - L + 1.  Files shorter than the target have 0 windows here; the
+ * reference's single stale-ring window for such files is not reproduced. */
+SGZ_API int64_t sgz_corr_num_windows(const sgz_context *ctx, int file);
+
+/* Computes boost and similarity of every window of files [file_begin, file_end)
+ * on the GPU and keeps them in device memory.  Asynchronous on the context's
+ * stream.  Replaces the sliding loop of impl/FeatureCorrelationImpl.scala:190-210
+ * (calcBoost :75-78, correlate :414-421, MathUtil.stat/correlate/avg). */
+SGZ_API int sgz_corr_run(sgz_context *ctx, int file_begin, int file_end);
+
+/* Copies sim / boost of all windows of one file to the host (either pointer
+ * may be NULL).  Synchronises the stream. */
+SGZ_API int sgz_corr_read_dense(sgz_context *ctx, int file, float *sim_out, float *boost_out);
+
+/* Collects the windows of files [file_begin, file_end) whose sim is > threshold
+ * (the strict comparison of impl/FeatureCorrelationImpl.scala:234) into `out`
+ * (host memory, `capacity` records), sorted by (file, offset).  *count receives
+ * the number found even when it exceeds capacity (then SGZ_E_OVERFLOW). */
+SGZ_API int sgz_corr_compact(sgz_context *ctx, int file_begin, int file_end, float threshold,
+                     sgz_candidate *out, int64_t capacity, int64_t *count);
+/* Same, but writes unsorted records and the 64-bit count into caller-provided
+ * device memory and does not synchronise; for callers that exchange the
+ * candidates between GPUs (RCCL all-gather) before reading them. */
+SGZ_API int sgz_corr_compact_device(sgz_context *ctx, int file_begin, int file_end, float threshold,
+                            sgz_candidate *device_out, int64_t capacity,
+                            unsigned long long *device_count);
+
+/* Milliseconds the GPU spent in the last sgz_corr_run's correlation kernel
+ * (HIP events on the context's stream); < 0 if none has completed. */
+SGZ_API float sgz_corr_last_kernel_ms(sgz_context *ctx);
+/* Algorithmic work of the last sgz_corr_run: windows and floating point
+ * operations (2 * numCh * L per window for the cross term). */
+SGZ_API int sgz_corr_last_work(const sgz_context *ctx, int64_t *windows, double *flops);
+
+/* ---- match selection (host) --------------------------------------------- */
+
+/* The order-dependent match bookkeeping of impl/FeatureCorrelationImpl.scala:
+ * allPrio / entryPrio / lastEntryMatch (:113-150), the offer gate (:234), the
+ * per-file merge (:166-167, :399-400).  Pure host code. */
+typedef struct sgz_selector sgz_selector;
+SGZ_API sgz_selector *sgz_sel_create(int num_matches, int num_per_file, int64_t min_spacing,
+                             int step_size, int target_frames);
+SGZ_API void sgz_sel_destroy(sgz_selector *sel);
+/* Feeds the windows of the next database file in iteration order.  `offsets`
+ * may be NULL, meaning 0..n-1 (dense).  Windows must be in ascending offset
+ * order.  Leaving out windows is legal iff they could not pass the gate. */
+SGZ_API int sgz_sel_feed_file(sgz_selector *sel, int file, int64_t n, const int32_t *offsets,
+                      const float *sims, const float *boosts);
+/* 1 once allPrio holds num_matches entries: from then on only windows with
+ * sim > sgz_sel_threshold() can still be offered. */
+SGZ_API int sgz_sel_is_full(const sgz_selector *sel);
+SGZ_API float sgz_sel_threshold(const sgz_selector *sel);
+/* Writes the matches in descending sim order; returns their number. */
+SGZ_API int sgz_sel_result(const sgz_selector *sel, sgz_match *out, int capacity);
+
+/* ---- FeatureSegmentation ------------------------------------------------ */
+
+/* Novelty curve of one feature file: for every window start o in
+ * [af_start, af_stop - 2*half_win] the correlateHalf similarity of
+ * impl/FeatureSegmentationImpl.scala:107-120 (MathUtil.correlateHalf,
+ * impl/MathUtil.scala:80-99).  `frames` is host memory (raw interleaved,
+ * num_frames x num_channels as set by sgz_db_reset / sgz_set_norms);
+ * sim_out receives max(0, af_stop - af_start - 2*half_win + 1) values. */
+SGZ_API int sgz_segm_curve(sgz_context *ctx, const float *frames, int64_t num_frames, int num_channels,
+                   int af_start, int af_stop, int half_win, float temporal_weight,
+                   float *sim_out, int64_t *num_out);
+
+/* Break bookkeeping of impl/FeatureSegmentationImpl.scala:55-83,121-125 over a
+ * dense novelty curve.  Host code.  Returns the number of breaks written
+ * (ascending sim). */
+SGZ_API int sgz_segm_select(const float *sims, int64_t n, int af_start, int half_win, int step_size,
+                    int num_breaks, int64_t min_spacing, sgz_break *out, int capacity);
+
+/* ---- SelfSimilarity ----------------------------------------------------- */
+
+/* The decimated similarity matrix of impl/SelfSimilarityImpl.scala:123-165:
+ * entry (x, y) compares the half window of file 1 at frame af_start + x*decim
+ * with that of file 2 at af_start + y*decim; img_ext = numCorrs / decim
+ * (:81-91).  frames2 may equal frames1.  sim_out (nullable) receives
+ * img_ext*img_ext floats, [x][y] with x = left; img_out (nullable) receives
+ * the TYPE_INT_RGB raster of :150-155 (gray colour scheme only: colors must be
+ * 0).  Both triangles are filled from the upper one, as the reference does. */
+SGZ_API int sgz_selfsim_run(sgz_context *ctx, const float *frames1, int64_t num_frames1,
+                    const float *frames2, int64_t num_frames2, int num_channels,
+                    int af_start, int half_win, int decim, int img_ext,
+                    float temporal_weight, int colors, float color_warp, float color_ceil,
+                    int color_inv, float *sim_out, int32_t *img_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STRUGATZKI_AMD_H */

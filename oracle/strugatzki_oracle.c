@@ -1,0 +1,755 @@
+/*
+ * strugatzki_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Single-threaded CPU restatement of the arithmetic of Strugatzki's
+ * similarity hot path (sliding normalised cross-correlation, novelty
+ * segmentation, self-similarity) in plain C.  It exists only as the parity
+ * checker for the HIP kernels and as the timed CPU baseline; nothing in the
+ * shipped library links, loads or calls it.
+ *
+ * PARITY UNPINNED: the reference (Scala/JVM) cannot be built or run in this
+ * environment and its own test-suite holds no numeric vectors (it checks XML
+ * round trips only, src/test/scala/de/sciss/strugatzki/StrugatzkiSuite.scala:12-92).
+ * What pins this file are the invariants the reference states itself:
+ * correlate(a, a) == 1.0 (impl/MathUtil.scala:98,195), the boost law of
+ * notes/BoostFactor.txt:34-39, and the result orderings
+ * (FeatureCorrelation.scala:30-33, FeatureSegmentation.scala:32-35).
+ *
+ * Every function cites the reference lines it follows; paths are relative to
+ * src/main/scala/de/sciss/strugatzki/ of the reference.  Loop order, operand
+ * types (fp32 data, fp64 accumulators, fp32 results) and the modulo ring
+ * indexing are kept as in the reference on purpose: this is also the
+ * "single-threaded port" whose speed is reported as the CPU baseline.
+ *
+ * Build: gcc -O2 -ffp-contract=off (no FMA contraction: the JVM does not fuse).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define SGZO_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------- */
+/* Matrices are channel-major like the reference's Array[Array[Float]]:      */
+/* mat[ch * stride + frame].                                                 */
+/* ------------------------------------------------------------------------- */
+
+/* impl/MathUtil.scala:29-62 -- one mean and one population std-dev over the
+ * whole chanLen x frameLen sub-matrix, two passes, fp64 accumulators. */
+SGZO_API void sgzo_stat(const float *mat, int stride, int frameOff, int frameLen,
+                        int chanOff, int chanLen, double *meanOut, double *stdOut)
+{
+    const int chanStop = chanOff + chanLen;
+    const int frameStop = frameOff + frameLen;
+    double sum = 0.0;
+    for (int ch = chanOff; ch < chanStop; ch++) {
+        const float *cb = mat + (size_t)ch * stride;
+        for (int i = frameOff; i < frameStop; i++) sum += cb[i];
+    }
+    const int matSize = frameLen * chanLen;
+    const double mean = sum / matSize;
+    sum = 0.0;
+    for (int ch = chanOff; ch < chanStop; ch++) {
+        const float *cb = mat + (size_t)ch * stride;
+        for (int i = frameOff; i < frameStop; i++) {
+            const double d = cb[i] - mean;
+            sum += d * d;
+        }
+    }
+    *meanOut = mean;
+    *stdOut = sqrt(sum / matSize);
+}
+
+/* impl/MathUtil.scala:177-196 -- Pearson cross term of a static matrix `a`
+ * (numChannels x numFrames, stride aStride) against the ring buffer `b`
+ * (ring length bLen frames == cb.length in the reference). */
+SGZO_API float sgzo_correlate(const float *a, int aStride, double aMean, double aStdDev,
+                              int numFrames, int numChannels,
+                              const float *b, int bLen, double bMean, double bStdDev,
+                              int bFrameOff, int bChanOff)
+{
+    const double aAdd = -aMean;
+    const double bAdd = -bMean;
+    const int aMatSize = numChannels * numFrames;
+    double sum = 0.0;
+    for (int ch = 0; ch < numChannels; ch++) {
+        const float *ca = a + (size_t)ch * aStride;
+        const float *cb = b + (size_t)(ch + bChanOff) * bLen;
+        for (int i = 0; i < numFrames; i++) {
+            sum += (ca[i] + aAdd) * (cb[(i + bFrameOff) % bLen] + bAdd);
+        }
+    }
+    return (float)(sum / (aStdDev * bStdDev * aMatSize));
+}
+
+/* impl/MathUtil.scala:80-99 -- correlation between the two halves of a ring of
+ * exactly 2*halfWinSize frames, joint mean / std-dev over the whole ring. */
+SGZO_API float sgzo_correlate_half(int numChannels, int halfWinSize, const float *a,
+                                   int frameOff, int chanOff)
+{
+    const int numFrames = halfWinSize << 1;
+    double mean, stdDev;
+    sgzo_stat(a, numFrames, 0, numFrames, chanOff, numChannels, &mean, &stdDev);
+    const double add = -mean;
+    const int matSize = numChannels * halfWinSize;
+    double sum = 0.0;
+    for (int ch = 0; ch < numChannels; ch++) {
+        const float *ca = a + (size_t)(ch + chanOff) * numFrames;
+        const int j = frameOff + halfWinSize;
+        for (int i = frameOff; i < j; i++) {
+            sum += (ca[i % numFrames] + add) * (ca[(i + halfWinSize) % numFrames] + add);
+        }
+    }
+    return (float)(sum / (stdDev * stdDev * matSize));
+}
+
+/* impl/MathUtil.scala:109-118 */
+SGZO_API float sgzo_avg(const float *b, int off, int len)
+{
+    double sum = 0.0;
+    const int stop = off + len;
+    for (int i = off; i < stop; i++) sum += b[i];
+    return (float)(sum / len);
+}
+
+/* impl/MathUtil.scala:132-152 -- pure fp32, in place, no clipping; norm is
+ * [numCh][2] = (min, max) per channel; NULL means "leave untouched". */
+SGZO_API void sgzo_normalize(const float *norm, float *b, int numCh, int stride,
+                             int bOff, int bLen)
+{
+    if (norm == NULL) return;
+    for (int ch = 0; ch < numCh; ch++) {
+        float *cb = b + (size_t)ch * stride;
+        const float min = norm[2 * ch];
+        const float max = norm[2 * ch + 1];
+        const float d = max - min;
+        const int iStop = bOff + bLen;
+        for (int i = bOff; i < iStop; i++) {
+            const float f = cb[i];
+            cb[i] = (f - min) / d;
+        }
+    }
+}
+
+/* impl/FeatureCorrelationImpl.scala:38-39 (same in FeatureSegmentationImpl:37-38,
+ * SelfSimilarityImpl:40) */
+SGZO_API int32_t sgzo_full_to_feat(int64_t n, int32_t stepSize)
+{
+    return (int32_t)((n + (stepSize >> 1)) / stepSize);
+}
+SGZO_API int64_t sgzo_feat_to_full(int32_t i, int32_t stepSize)
+{
+    return (int64_t)i * stepSize;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Ordered set keyed on sim only (FeatureCorrelation.scala:75-77,            */
+/* FeatureSegmentation.scala:60-62).                                         */
+/* ------------------------------------------------------------------------- */
+
+/* java.lang.Float.compare: a total order with -0.0 < 0.0 and NaN above all
+ * (scala's `a.sim compare b.sim` on Float resolves to it). */
+static int java_float_compare(float a, float b)
+{
+    if (a < b) return -1;
+    if (a > b) return 1;
+    uint32_t ia, ib;
+    memcpy(&ia, &a, 4);
+    memcpy(&ib, &b, 4);
+    if (a != a) ia = 0x7fc00000u; /* floatToIntBits canonicalises NaN */
+    if (b != b) ib = 0x7fc00000u;
+    const int32_t sa = (int32_t)ia, sb = (int32_t)ib;
+    return sa == sb ? 0 : (sa < sb ? -1 : 1);
+}
+
+typedef struct {
+    float sim;
+    float boost_in;
+    float boost_out;
+    int32_t file;
+    int64_t start;
+    int64_t stop;
+} sgzo_match;
+
+typedef struct {
+    sgzo_match *e;
+    int size;
+    int cap;
+    int descending; /* 1: MatchMinOrd (head = highest sim); 0: BreakMaxOrd */
+} oset;
+
+static void oset_init(oset *s, int cap, int descending)
+{
+    s->e = (sgzo_match *)malloc(sizeof(sgzo_match) * (size_t)(cap > 0 ? cap : 1));
+    s->size = 0;
+    s->cap = cap > 0 ? cap : 1;
+    s->descending = descending;
+}
+static void oset_free(oset *s) { free(s->e); s->e = NULL; }
+static int oset_cmp(const oset *s, const sgzo_match *a, const sgzo_match *b)
+{
+    /* MatchMinOrd.compare(a, b) = b.sim compare a.sim */
+    return s->descending ? java_float_compare(b->sim, a->sim) : java_float_compare(a->sim, b->sim);
+}
+/* immutable.TreeSet `+`: an element that compares equal to one already in the
+ * set leaves the set unchanged [external library behaviour, Scala 2.11
+ * RedBlackTree.update(overwrite = false); not verifiable here]. */
+static void oset_add(oset *s, const sgzo_match *m)
+{
+    int pos = 0;
+    while (pos < s->size) {
+        const int c = oset_cmp(s, &s->e[pos], m);
+        if (c == 0) return;
+        if (c > 0) break;
+        pos++;
+    }
+    if (s->size == s->cap) {
+        s->cap *= 2;
+        s->e = (sgzo_match *)realloc(s->e, sizeof(sgzo_match) * (size_t)s->cap);
+    }
+    memmove(&s->e[pos + 1], &s->e[pos], sizeof(sgzo_match) * (size_t)(s->size - pos));
+    s->e[pos] = *m;
+    s->size++;
+}
+/* `-`: removes whatever element compares equal (same sim). */
+static void oset_remove(oset *s, const sgzo_match *m)
+{
+    for (int pos = 0; pos < s->size; pos++) {
+        if (oset_cmp(s, &s->e[pos], m) == 0) {
+            memmove(&s->e[pos], &s->e[pos + 1], sizeof(sgzo_match) * (size_t)(s->size - pos - 1));
+            s->size--;
+            return;
+        }
+    }
+}
+
+/* impl/SpanUtil.scala:38-43 */
+static int64_t span_spacing(int64_t aStart, int64_t aStop, int64_t bStart, int64_t bStop)
+{
+    if (aStart < bStart) return bStart - aStop;
+    return aStart - bStop;
+}
+
+/* ------------------------------------------------------------------------- */
+/* FeatureCorrelation (no punch-out): impl/FeatureCorrelationImpl.scala       */
+/* ------------------------------------------------------------------------- */
+
+typedef struct {
+    int64_t punch_in_start;  /* Punch.span, sample frames */
+    int64_t punch_in_stop;
+    float temporal_weight;
+    int32_t normalize;
+    float max_boost;
+    int32_t num_matches;
+    int32_t num_per_file;
+    int64_t min_spacing;
+    int32_t step_size;  /* fftSize / fftOverlap */
+    int32_t num_coeffs;
+} sgzo_corr_config;
+
+typedef struct {
+    oset allPrio, entryPrio;
+    int hasLast;
+    sgzo_match last;
+    const sgzo_corr_config *cfg;
+} corr_sel;
+
+/* impl/FeatureCorrelationImpl.scala:120-123 */
+static int corr_entry_has_space(const corr_sel *s)
+{
+    int maxEntrySz = s->cfg->num_matches - s->allPrio.size;
+    if (s->cfg->num_per_file < maxEntrySz) maxEntrySz = s->cfg->num_per_file;
+    return s->entryPrio.size < maxEntrySz;
+}
+/* :125-129 */
+static float corr_lowest_sim(const corr_sel *s)
+{
+    if (s->entryPrio.size > 0) return s->entryPrio.e[s->entryPrio.size - 1].sim;
+    if (s->allPrio.size > 0) return s->allPrio.e[s->allPrio.size - 1].sim;
+    return 0.0f;
+}
+/* :135-150 */
+static void corr_add_match(corr_sel *s, const sgzo_match *m)
+{
+    if (s->hasLast &&
+        span_spacing(m->start, m->stop, s->last.start, s->last.stop) < s->cfg->min_spacing) {
+        if (s->last.sim < m->sim) {
+            oset_remove(&s->entryPrio, &s->last);
+            oset_add(&s->entryPrio, m);
+            s->last = *m;
+        }
+    } else {
+        oset_add(&s->entryPrio, m);
+        if (s->entryPrio.size > s->cfg->num_per_file) {
+            sgzo_match lastE = s->entryPrio.e[s->entryPrio.size - 1];
+            oset_remove(&s->entryPrio, &lastE);
+        }
+        s->last = *m;
+        s->hasLast = 1;
+    }
+}
+
+/*
+ * Whole FeatureCorrelationImpl.body() without punch-out (:32-246, :399-411).
+ *
+ * target      : raw feature frames of the input file, interleaved
+ *               [targetFrames][numCh] as they sit in the feature AIFF
+ * norms       : [numCh][2] (min, max) or NULL when cfg->normalize == 0
+ * dbFrames[f] : raw interleaved frames of database file f, in iteration order
+ * dbNumFrames : frames per file
+ * denseSim / denseBoost : optional (may be NULL) arrays of per-file pointers
+ *               receiving sim / boost of every loop iteration (window)
+ * matches     : room for cfg->num_matches records; returns the count, sorted
+ *               by descending sim (:410-411); -1 on a bad argument.
+ *
+ * Quirk kept from the reference: the ring `eInBuf` is allocated once
+ * (:154) and a file with fewer than L frames yields exactly one window
+ * computed over its frames followed by whatever earlier files left in the
+ * ring (:194-195).
+ */
+SGZO_API int sgzo_correlation_run(const sgzo_corr_config *cfg,
+                                  const float *target, int64_t targetFrames,
+                                  const float *norms,
+                                  const float *const *dbFrames, const int64_t *dbNumFrames,
+                                  int numFiles,
+                                  float *const *denseSim, float *const *denseBoost,
+                                  sgzo_match *matches)
+{
+    const int numCh = cfg->num_coeffs + 1;
+    const int step = cfg->step_size;
+    const float *normBuf = cfg->normalize ? norms : NULL;
+    if (cfg->normalize && norms == NULL) return -1;
+
+    /* readInBuffer, :83-98 */
+    const int start = sgzo_full_to_feat(cfg->punch_in_start, step);
+    const int stop = sgzo_full_to_feat(cfg->punch_in_stop, step);
+    const int L = stop - start;
+    if (L <= 0 || start < 0 || (int64_t)start + L > targetFrames) return -1;
+    float *tb = (float *)malloc(sizeof(float) * (size_t)numCh * L);
+    for (int ch = 0; ch < numCh; ch++)
+        for (int i = 0; i < L; i++) tb[(size_t)ch * L + i] = target[(size_t)(start + i) * numCh + ch];
+    sgzo_normalize(normBuf, tb, numCh, L, 0, L);
+    double tMean, tStd, sMean, sStd;
+    sgzo_stat(tb, L, 0, L, 0, 1, &tMean, &tStd);                 /* feat(b.take(1)) */
+    sgzo_stat(tb + L, L, 0, L, 0, numCh - 1, &sMean, &sStd);     /* feat(b.drop(1)) */
+    const double lnAvgLoudness = log((double)sgzo_avg(tb, 0, L)); /* :73, :97 */
+
+    const float w = cfg->temporal_weight;
+
+    corr_sel sel;
+    oset_init(&sel.allPrio, cfg->num_matches + cfg->num_per_file + 2, 1);
+    oset_init(&sel.entryPrio, cfg->num_per_file + 2, 1);
+    sel.hasLast = 0;
+    sel.cfg = cfg;
+
+    float *eInBuf = (float *)calloc((size_t)numCh * L, sizeof(float)); /* :154 */
+
+    for (int f = 0; f < numFiles; f++) {
+        sel.entryPrio.size = 0;  /* :166 */
+        sel.hasLast = 0;         /* :167 */
+        const float *src = dbFrames[f];
+        int64_t filePos = 0;
+        int64_t left = dbNumFrames[f]; /* :182 */
+        int readSz = L;
+        int readOff = 0;
+        int logicalOff = 0;
+        while (left > 0) { /* :190 */
+            const int chunkLen = (int)(left < readSz ? left : readSz);
+            /* afExtr.read(eInBuf, readOff, chunkLen): de-interleave next frames */
+            for (int i = 0; i < chunkLen; i++)
+                for (int ch = 0; ch < numCh; ch++)
+                    eInBuf[(size_t)ch * L + readOff + i] = src[(size_t)(filePos + i) * numCh + ch];
+            filePos += chunkLen;
+            const int eInBufOff = logicalOff % L;
+            sgzo_normalize(normBuf, eInBuf, numCh, L, readOff, chunkLen);
+            /* calcBoost, :75-78 */
+            const double lnAvgB = log((double)sgzo_avg(eInBuf, 0, L));
+            const float boost = (float)exp((lnAvgLoudness - lnAvgB) / 0.6);
+            float sim;
+            if (boost <= cfg->max_boost) { /* :199 */
+                float temporal = 0.0f, spectral = 0.0f;
+                if (w > 0.0f) { /* :414-421 with bChanOff = 0 */
+                    double bMean, bStd;
+                    sgzo_stat(eInBuf, L, 0, L, 0, 1, &bMean, &bStd);
+                    temporal = sgzo_correlate(tb, L, tMean, tStd, L, 1, eInBuf, L, bMean, bStd, eInBufOff, 0);
+                }
+                if (w < 1.0f) {
+                    double bMean, bStd;
+                    sgzo_stat(eInBuf, L, 0, L, 1, numCh - 1, &bMean, &bStd);
+                    spectral = sgzo_correlate(tb + L, L, sMean, sStd, L, numCh - 1, eInBuf, L, bMean, bStd, eInBufOff, 1);
+                }
+                sim = temporal * w + spectral * (1.0f - w); /* :207, fp32 */
+            } else {
+                sim = 0.0f; /* :209 */
+            }
+            if (denseSim && denseSim[f]) denseSim[f][logicalOff] = sim;
+            if (denseBoost && denseBoost[f]) denseBoost[f][logicalOff] = boost;
+
+            if (corr_entry_has_space(&sel) || sim > corr_lowest_sim(&sel)) { /* :234 */
+                sgzo_match m;
+                m.sim = sim;
+                m.file = f;
+                m.start = sgzo_feat_to_full(logicalOff, step);
+                m.stop = sgzo_feat_to_full(logicalOff + L, step);
+                m.boost_in = boost;
+                m.boost_out = 1.0f;
+                corr_add_match(&sel, &m);
+            }
+            left -= chunkLen;
+            readOff = (readOff + chunkLen) % L;
+            logicalOff += 1;
+            readSz = 1;
+        }
+        /* :399-400 */
+        for (int i = 0; i < sel.entryPrio.size; i++) oset_add(&sel.allPrio, &sel.entryPrio.e[i]);
+        if (sel.allPrio.size > cfg->num_matches) sel.allPrio.size = cfg->num_matches;
+    }
+
+    const int n = sel.allPrio.size;
+    for (int i = 0; i < n; i++) matches[i] = sel.allPrio.e[i];
+    free(eInBuf);
+    free(tb);
+    oset_free(&sel.allPrio);
+    oset_free(&sel.entryPrio);
+    return n;
+}
+
+/* Number of loop iterations (windows) impl/FeatureCorrelationImpl.scala:190-246
+ * runs for a file of n frames and a target of L frames. */
+SGZO_API int64_t sgzo_correlation_num_windows(int64_t n, int32_t L)
+{
+    if (n <= 0) return 0;
+    return n >= L ? n - L + 1 : 1;
+}
+
+/* ------------------------------------------------------------------------- */
+/* FeatureSegmentation: impl/FeatureSegmentationImpl.scala:31-142            */
+/* ------------------------------------------------------------------------- */
+
+typedef struct {
+    int32_t has_start, has_stop; /* config.span: Span.HasStart / HasStop */
+    int64_t span_start, span_stop;
+    int64_t corr_len;
+    float temporal_weight;
+    int32_t normalize;
+    int32_t num_breaks;
+    int64_t min_spacing;
+    int32_t step_size;
+    int32_t num_coeffs;
+} sgzo_segm_config;
+
+typedef struct {
+    float sim;
+    int32_t pad_;
+    int64_t pos;
+} sgzo_break;
+
+/* Returns the number of breaks (ascending sim, FeatureSegmentation.scala:32-35);
+ * denseSim (optional) receives one value per loop iteration, *numDense their count. */
+SGZO_API int sgzo_segmentation_run(const sgzo_segm_config *cfg,
+                                   const float *frames, int64_t numFrames,
+                                   const float *norms,
+                                   float *denseSim, int64_t *numDense,
+                                   sgzo_break *breaks)
+{
+    const int numCh = cfg->num_coeffs + 1;
+    const int step = cfg->step_size;
+    const float *normBuf = cfg->normalize ? norms : NULL;
+    if (cfg->normalize && norms == NULL) return -1;
+    const int halfWinLen = sgzo_full_to_feat(cfg->corr_len, step); /* :52 */
+    const float tempWeight = cfg->temporal_weight;
+    const int winLen = halfWinLen * 2; /* :85 */
+    if (winLen <= 0) return -1;
+
+    oset prio;
+    oset_init(&prio, cfg->num_breaks + 2, 0);
+    int hasLast = 0;
+    sgzo_match lastBreak;
+    memset(&lastBreak, 0, sizeof lastBreak);
+
+    float *eInBuf = (float *)calloc((size_t)numCh * winLen, sizeof(float)); /* :86 */
+
+    /* :90-98 */
+    int afStart = 0;
+    if (cfg->has_start) {
+        afStart = sgzo_full_to_feat(cfg->span_start, step);
+        if (afStart < 0) afStart = 0;
+    }
+    int afStop = (int)numFrames;
+    if (cfg->has_stop) {
+        const int s = sgzo_full_to_feat(cfg->span_stop, step);
+        if (s < afStop) afStop = s;
+    }
+    const int afLen = afStop - afStart;
+
+    int64_t filePos = afStart; /* :100 */
+    int left = afLen;
+    int readSz = winLen;
+    int readOff = 0;
+    int logicalOff = 0;
+    while (left > 0) { /* :107 */
+        const int chunkLen = left < readSz ? left : readSz;
+        for (int i = 0; i < chunkLen; i++)
+            for (int ch = 0; ch < numCh; ch++)
+                eInBuf[(size_t)ch * winLen + readOff + i] = frames[(size_t)(filePos + i) * numCh + ch];
+        filePos += chunkLen;
+        const int eInBufOff = logicalOff % winLen;
+        sgzo_normalize(normBuf, eInBuf, numCh, winLen, readOff, chunkLen);
+        const float temporal = tempWeight > 0.0f ? sgzo_correlate_half(1, halfWinLen, eInBuf, eInBufOff, 0) : 0.0f;
+        const float spectral = tempWeight < 1.0f ? sgzo_correlate_half(numCh - 1, halfWinLen, eInBuf, eInBufOff, 1) : 0.0f;
+        const float sim = temporal * tempWeight + spectral * (1.0f - tempWeight); /* :120 */
+        if (denseSim) denseSim[logicalOff] = sim;
+        /* :58-62, :121 */
+        const int entryHasSpace = prio.size < cfg->num_breaks;
+        const float highestSim = prio.size > 0 ? prio.e[prio.size - 1].sim : 0.0f;
+        if (entryHasSpace || sim < highestSim) {
+            sgzo_match b;
+            memset(&b, 0, sizeof b);
+            b.sim = sim;
+            b.start = sgzo_feat_to_full(afStart + logicalOff + halfWinLen, step); /* pos, :122 */
+            /* addBreak, :68-83 */
+            if (hasLast && (b.start - lastBreak.start) < cfg->min_spacing) {
+                if (lastBreak.sim > b.sim) {
+                    oset_remove(&prio, &lastBreak);
+                    oset_add(&prio, &b);
+                    lastBreak = b;
+                }
+            } else {
+                oset_add(&prio, &b);
+                if (prio.size > cfg->num_breaks) {
+                    sgzo_match lastE = prio.e[prio.size - 1];
+                    oset_remove(&prio, &lastE);
+                }
+                lastBreak = b;
+                hasLast = 1;
+            }
+        }
+        left -= chunkLen;
+        readOff = (readOff + chunkLen) % winLen;
+        logicalOff += 1;
+        readSz = 1;
+    }
+    if (numDense) *numDense = logicalOff;
+    const int n = prio.size;
+    for (int i = 0; i < n; i++) {
+        breaks[i].sim = prio.e[i].sim;
+        breaks[i].pad_ = 0;
+        breaks[i].pos = prio.e[i].start;
+    }
+    free(eInBuf);
+    oset_free(&prio);
+    return n;
+}
+
+/* ------------------------------------------------------------------------- */
+/* SelfSimilarity: impl/SelfSimilarityImpl.scala:31-180                      */
+/* ------------------------------------------------------------------------- */
+
+typedef struct {
+    int32_t has_start, has_stop;
+    int64_t span_start, span_stop;
+    int64_t corr_len;
+    int32_t decimation;
+    float temporal_weight;
+    int32_t colors;   /* 0 = gray, 1 = psycho (SelfSimilarity.scala:30-56) */
+    float color_warp;
+    float color_ceil;
+    int32_t color_inv;
+    int32_t normalize;
+    int32_t step_size;
+    int32_t num_coeffs;
+} sgzo_selfsim_config;
+
+/* Geometry of impl/SelfSimilarityImpl.scala:64-91: returns imgExt, writes the
+ * effective decimation, afStart and numCorrs. -1 on an illegal setting. */
+SGZO_API int sgzo_selfsim_geometry(const sgzo_selfsim_config *cfg, int64_t numFrames1,
+                                   int64_t numFrames2, int32_t *decimOut,
+                                   int32_t *afStartOut, int32_t *numCorrsOut)
+{
+    const int step = cfg->step_size;
+    const int halfWinLen = sgzo_full_to_feat(cfg->corr_len, step);
+    const int winLen = halfWinLen * 2;
+    const int64_t afNumFrames = numFrames1 < numFrames2 ? numFrames1 : numFrames2;
+    int afStart = 0;
+    if (cfg->has_start) {
+        afStart = sgzo_full_to_feat(cfg->span_start, step);
+        if (afStart < 0) afStart = 0;
+    }
+    int afStop = (int)afNumFrames;
+    if (cfg->has_stop) {
+        const int s = sgzo_full_to_feat(cfg->span_stop, step);
+        if (s < afStop) afStop = s;
+    }
+    const int afLen = afStop - afStart;
+    int64_t n = (int64_t)afLen - winLen + 1;
+    if (n < 0) n = 0;
+    const int numCorrs = (int)n;
+    const int d = cfg->decimation;
+    if (d < 1) return -1;
+    int decim, imgExt;
+    const int i = numCorrs / d;
+    if (i <= 0xB504) {
+        decim = d;
+        imgExt = i;
+    } else {
+        decim = (numCorrs + 0xB503) / 0xB504;
+        imgExt = numCorrs / decim;
+    }
+    if (decimOut) *decimOut = decim;
+    if (afStartOut) *afStartOut = afStart;
+    if (numCorrsOut) *numCorrsOut = numCorrs;
+    return imgExt;
+}
+
+/* Gray colour functions of impl/SelfSimilarityImpl.scala:99-107. */
+static int32_t gray_color(float v, int inv)
+{
+    const float s = inv ? (1.0f - v) : v;
+    /* (sim * 255 + 0.5).toInt: Float*Int -> Float, then + Double; the JVM's
+     * d2i maps NaN to 0 and saturates. */
+    const double d = (double)(s * 255) + 0.5;
+    int i;
+    if (d != d) i = 0;
+    else if (d >= 255.0) i = 255;
+    else if (d <= 0.0) i = 0;
+    else i = (int)d;
+    return (i << 16) | (i << 8) | i;
+}
+
+/*
+ * The double loop of impl/SelfSimilarityImpl.scala:123-165.  frames1/frames2
+ * are the raw interleaved feature frames of the two inputs (the same pointer
+ * for a plain self-similarity).  simOut (optional) is imgExt*imgExt floats
+ * indexed [left/decim][right/decim], both triangles filled; imgOut (optional)
+ * is the imgExt*imgExt TYPE_INT_RGB raster, row-major with y = imgExt-1-right
+ * (:152-155).  Only the gray colour scheme is restated: the psycho-optical one
+ * lives in a third-party library (de.sciss:intensitypalette 1.0.0) that is
+ * not part of the reference tree.
+ */
+SGZO_API int sgzo_selfsim_run(const sgzo_selfsim_config *cfg,
+                              const float *frames1, int64_t numFrames1,
+                              const float *frames2, int64_t numFrames2,
+                              const float *norms, float *simOut, int32_t *imgOut)
+{
+    const int numCh = cfg->num_coeffs + 1;
+    const float *normBuf = cfg->normalize ? norms : NULL;
+    if (cfg->normalize && norms == NULL) return -1;
+    if (!(cfg->color_warp > 0) || !(cfg->color_ceil > 0)) return -1; /* :112-113 */
+    if (imgOut && cfg->colors != 0) return -1;
+    int decim, afStart, numCorrs;
+    const int imgExt = sgzo_selfsim_geometry(cfg, numFrames1, numFrames2, &decim, &afStart, &numCorrs);
+    if (imgExt < 0) return -1;
+    const int halfWinLen = sgzo_full_to_feat(cfg->corr_len, cfg->step_size);
+    const int winLen = halfWinLen * 2;
+    const float tempWeight = cfg->temporal_weight;
+    const double colorWarp = cfg->color_warp;
+    const float colorScale = 1.0f / cfg->color_ceil;
+    const int imgExtM1 = imgExt - 1;
+    float *eInBuf = (float *)calloc((size_t)numCh * (winLen > 0 ? winLen : 1), sizeof(float));
+    const int stop = numCorrs / decim * decim;
+
+    for (int leftOff = 0; leftOff < stop; leftOff += decim) {
+        for (int i = 0; i < halfWinLen; i++)
+            for (int ch = 0; ch < numCh; ch++)
+                eInBuf[(size_t)ch * winLen + i] = frames1[(size_t)(leftOff + afStart + i) * numCh + ch];
+        sgzo_normalize(normBuf, eInBuf, numCh, winLen, 0, halfWinLen);
+        for (int rightOff = leftOff; rightOff < stop; rightOff += decim) {
+            for (int i = 0; i < halfWinLen; i++)
+                for (int ch = 0; ch < numCh; ch++)
+                    eInBuf[(size_t)ch * winLen + halfWinLen + i] = frames2[(size_t)(rightOff + afStart + i) * numCh + ch];
+            sgzo_normalize(normBuf, eInBuf, numCh, winLen, halfWinLen, halfWinLen);
+            const float temporal = tempWeight > 0.0f ? sgzo_correlate_half(1, halfWinLen, eInBuf, 0, 0) : 0.0f;
+            const float spectral = tempWeight < 1.0f ? sgzo_correlate_half(numCh - 1, halfWinLen, eInBuf, 0, 1) : 0.0f;
+            const float sim = temporal * tempWeight + spectral * (1.0f - tempWeight);
+            const int x = leftOff / decim, y = rightOff / decim;
+            if (x < imgExt && y < imgExt) {
+                if (simOut) {
+                    simOut[(size_t)x * imgExt + y] = sim;
+                    simOut[(size_t)y * imgExt + x] = sim;
+                }
+                if (imgOut) {
+                    /* math.max(0f, sim): NaN stays NaN */
+                    const float m0 = (sim != sim) ? sim : (sim > 0.0f ? sim : 0.0f);
+                    const float v = (float)pow((double)m0, colorWarp) * colorScale; /* :150 */
+                    const int32_t colr = gray_color(v, cfg->color_inv);
+                    imgOut[(size_t)(imgExtM1 - y) * imgExt + x] = colr; /* off1 */
+                    imgOut[(size_t)(imgExtM1 - x) * imgExt + y] = colr; /* off2 */
+                }
+            }
+        }
+    }
+    free(eInBuf);
+    return imgExt;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Synthetic feature data (benchmark / test inputs, not part of the          */
+/* reference): counter-based so that C, numpy and the on-device generator    */
+/* produce identical bits.                                                   */
+/* ------------------------------------------------------------------------- */
+
+static uint64_t mix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+static float synth_u(uint64_t seed, int64_t file, int64_t frame, int ch, uint64_t stream)
+{
+    const uint64_t k = mix64(seed + (uint64_t)file * 0xD1342543DE82EF95ull + stream * 0xA0761D6478BD642Full);
+    const uint64_t h = mix64(k ^ ((uint64_t)frame * 16ull + (uint64_t)ch));
+    return (float)(h >> 40) * (1.0f / 16777216.0f);
+}
+/* Moving average of 8 uniforms, summed in index order in fp32. */
+static float synth_smooth(uint64_t seed, int64_t file, int64_t frame, int ch)
+{
+    float s = 0.0f;
+    for (int j = 0; j < 8; j++) s = s + synth_u(seed, file, frame + j, ch, 0);
+    return s * 0.125f;
+}
+SGZO_API float sgzo_synth_base(uint64_t seed, int64_t file, int64_t frame, int ch)
+{
+    const float s = synth_smooth(seed, file, frame, ch);
+    if (ch == 0) return 0.05f + 1.45f * s; /* strictly positive loudness */
+    return s;
+}
+
+typedef struct {
+    int64_t file;        /* database file receiving the copy */
+    int64_t offset;      /* first frame of the copy in that file */
+    int64_t src_file;    /* file the copy is taken from */
+    int64_t src_offset;  /* first source frame */
+    int64_t length;      /* frames */
+    float amp;           /* uniform noise amplitude added to the copy */
+    float gain;          /* loudness channel of the copy is multiplied by this */
+} sgzo_plant;
+
+/* Fills interleaved frames [frame0, frame0+n) x numCh of `file`. */
+SGZO_API void sgzo_synth_fill(uint64_t seed, int64_t file, int64_t frame0, int64_t n, int numCh,
+                              const sgzo_plant *plants, int numPlants, float *out)
+{
+    for (int64_t i = 0; i < n; i++) {
+        const int64_t fr = frame0 + i;
+        const sgzo_plant *p = NULL;
+        for (int k = 0; k < numPlants; k++) {
+            if (plants[k].file == file && fr >= plants[k].offset && fr < plants[k].offset + plants[k].length) {
+                p = &plants[k];
+                break;
+            }
+        }
+        for (int ch = 0; ch < numCh; ch++) {
+            float v;
+            if (p) {
+                const float b = sgzo_synth_base(seed, p->src_file, p->src_offset + (fr - p->offset), ch);
+                const float nz = synth_u(seed, file, fr, ch, 1) - 0.5f;
+                v = b + p->amp * nz;
+                if (ch == 0) v = v * p->gain;
+            } else {
+                v = sgzo_synth_base(seed, file, fr, ch);
+            }
+            out[(size_t)i * numCh + ch] = v;
+        }
+    }
+}

@@ -1,0 +1,61 @@
+// Context life cycle of libstrugatzki_amd.
+#include <hip/hip_runtime.h>
+
+#include "sgz_internal.hpp"
+
+extern "C" {
+
+const char *sgz_version(void) { return "strugatzki_amd 0.1 (gfx950)"; }
+
+int sgz_create(int device, void *hip_stream, sgz_context **out)
+{
+    if (!out) return SGZ_E_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return SGZ_E_HIP;
+    if (device < 0 || device >= count) return SGZ_E_ARG;
+    if (hipSetDevice(device) != hipSuccess) return SGZ_E_HIP;
+    sgz_context *ctx = new sgz_context();
+    ctx->device = device;
+    if (hip_stream) {
+        ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+        ctx->own_stream = false;
+    } else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete ctx;
+            return SGZ_E_HIP;
+        }
+        ctx->own_stream = true;
+    }
+    *out = ctx;
+    return SGZ_OK;
+}
+
+void sgz_destroy(sgz_context *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &f : ctx->files)
+        if (f.owned && f.d_raw) (void)hipFree(f.d_raw);
+    void *bufs[] = {ctx->d_aprime, ctx->d_files, ctx->d_tiles, ctx->d_ptiles, ctx->d_planar, ctx->d_prefix,
+                    ctx->d_sim,    ctx->d_boost, ctx->d_count, ctx->d_cand};
+    for (void *b : bufs)
+        if (b) (void)hipFree(b);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *sgz_last_error(const sgz_context *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int sgz_synchronize(sgz_context *ctx)
+{
+    if (!ctx) return SGZ_E_ARG;
+    SGZ_HIP(ctx, hipSetDevice(ctx->device));
+    SGZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SGZ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,147 @@
+// Internal declarations shared by the translation units of libstrugatzki_amd.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "strugatzki_amd.h"
+
+namespace sgz {
+
+// ---- geometry of the correlation kernel ------------------------------------
+constexpr int kR = 16;             // windows per lane == lags per step == frames per chunk
+constexpr int kTileW = 64 * kR;    // windows per workgroup tile
+constexpr int kWaves = 4;          // waves per workgroup; they split the lag range
+constexpr int kMT = 256;           // LDS row stride (chunks) of one staged channel block
+constexpr int kSBMax = kMT - 64;   // most lag steps one staged block can serve
+
+// One database file as the kernels see it.
+struct FileDesc {
+    const float *raw;        // interleaved raw frames [frames][numCh]
+    long long frames;
+    long long M;             // chunks per planar row (padded)
+    long long planar_off;    // offset in doubles into the planar buffer, layout [numCh][kR][M]
+    long long prefix_off;    // offset in doubles into the prefix buffer, 4 arrays of frames+1
+    long long win_off;       // offset of this file's windows in the dense sim / boost arrays
+    long long num_windows;
+};
+
+struct TileDesc {
+    int file;
+    int o0;  // first window of the tile
+};
+
+struct PrepTile {
+    int file;
+    int chunk0;  // first chunk of the tile
+};
+
+struct NormParams {
+    int enabled;
+    float mn[SGZ_MAX_CHANNELS];
+    float d[SGZ_MAX_CHANNELS];  // max - min, fp32 as MathUtil.normalize computes it
+};
+
+struct CorrParams {
+    int numCh;
+    int L;        // target frames
+    int S;        // lag steps (even), S * kR >= L
+    int nb;       // staged blocks per channel
+    int SB;       // steps per staged block (even, <= kSBMax)
+    double kT, kS;            // centring constants of the planar data
+    double aStdT, aStdS;      // target std-devs
+    double sumAT, sumAS;      // sum of the centred target (rounding residue)
+    double lnAvgIn;           // ln(avg loudness of the target)
+    float w;                  // temporal weight
+    float maxBoost;
+};
+
+struct DbFile {
+    float *d_raw = nullptr;
+    long long frames = 0;
+    bool owned = false;
+};
+
+}  // namespace sgz
+
+struct sgz_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    mutable std::string err;
+
+    int numCh = 0;
+    std::vector<sgz::DbFile> files;
+    sgz::NormParams norm{};
+
+    // target
+    bool have_target = false;
+    sgz::CorrParams cp{};
+    double *d_aprime = nullptr;  // [numCh][S * kR] centred target, fp64
+    size_t aprime_cap = 0;
+
+    // layout (depends on db + target length)
+    bool layout_dirty = true;
+    std::vector<sgz::FileDesc> h_files;
+    std::vector<sgz::TileDesc> h_tiles;      // correlation tiles, grouped by file
+    std::vector<int> tile_begin;             // first tile of each file (+ sentinel)
+    std::vector<sgz::PrepTile> h_ptiles;
+    std::vector<int> ptile_begin;
+    int prep_cb = 64;                        // chunks per prep tile
+    sgz::FileDesc *d_files = nullptr;
+    sgz::TileDesc *d_tiles = nullptr;
+    sgz::PrepTile *d_ptiles = nullptr;
+    size_t d_files_cap = 0, d_tiles_cap = 0, d_ptiles_cap = 0;
+    long long total_windows = 0;
+
+    double *d_planar = nullptr;
+    size_t planar_cap = 0;
+    double *d_prefix = nullptr;
+    size_t prefix_cap = 0;
+    float *d_sim = nullptr;
+    float *d_boost = nullptr;
+    size_t dense_cap = 0, boost_cap = 0;
+
+    unsigned long long *d_count = nullptr;   // compaction counter
+    sgz_candidate *d_cand = nullptr;
+    size_t cand_cap = 0;
+
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool ev_valid = false;
+    long long last_windows = 0;
+    double last_flops = 0.0;
+
+    int fail(int code, const std::string &msg) const
+    {
+        err = msg;
+        return code;
+    }
+};
+
+#define SGZ_HIP(ctx, call)                                                                  \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return (ctx)->fail(SGZ_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+namespace sgz {
+// Grows a device buffer to at least `count` elements (contents are not kept).
+template <typename T>
+int ensure(const sgz_context *ctx, T *&ptr, size_t &cap, size_t count)
+{
+    if (count <= cap && ptr) return SGZ_OK;
+    if (ptr) {
+        SGZ_HIP(ctx, hipFree(ptr));
+        ptr = nullptr;
+        cap = 0;
+    }
+    const size_t n = count ? count : 1;
+    SGZ_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ptr), n * sizeof(T)));
+    cap = n;
+    return SGZ_OK;
+}
+}  // namespace sgz

@@ -1,0 +1,256 @@
+// Host-side result bookkeeping: the order-dependent match / break selection of
+// the reference, replayed over similarities computed on the GPU.
+//
+//   matches: impl/FeatureCorrelationImpl.scala:113-150 (allPrio, entryPrio,
+//            lastEntryMatch, entryHasSpace, lowestSim, addMatch), :234-239 (offer
+//            gate), :166-167 and :399-400 (per-file reset and merge)
+//   breaks:  impl/FeatureSegmentationImpl.scala:55-83, :121-125
+//
+// Both priority sets of the reference are immutable.SortedSet instances whose
+// ordering looks at `sim` only (FeatureCorrelation.scala:75-77,
+// FeatureSegmentation.scala:60-62): two entries with the same sim are the same
+// element.  Adding an element that compares equal to a present one leaves the
+// set as it is; removing removes whichever entry has that sim.
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "strugatzki_amd.h"
+
+namespace {
+
+// Total order of java.lang.Float.compare: -0.0 < +0.0, NaN == NaN > +inf.
+int float_total_compare(float a, float b)
+{
+    if (a < b) return -1;
+    if (a > b) return 1;
+    uint32_t ia, ib;
+    std::memcpy(&ia, &a, 4);
+    std::memcpy(&ib, &b, 4);
+    if (a != a) ia = 0x7fc00000u;
+    if (b != b) ib = 0x7fc00000u;
+    const int32_t sa = (int32_t)ia, sb = (int32_t)ib;
+    return sa == sb ? 0 : (sa < sb ? -1 : 1);
+}
+
+struct Entry {
+    float sim;
+    float boost_in;
+    float boost_out;
+    int32_t file;
+    int64_t start;
+    int64_t stop;
+};
+
+// Sorted vector standing in for the reference's TreeSet.  `best_high` selects
+// the direction: true keeps the highest sims first (matches), false the lowest
+// first (breaks).
+class SimSet {
+public:
+    explicit SimSet(bool best_high) : best_high_(best_high) {}
+    size_t size() const { return v_.size(); }
+    bool empty() const { return v_.empty(); }
+    const Entry &last() const { return v_.back(); }
+    const std::vector<Entry> &items() const { return v_; }
+    void clear() { v_.clear(); }
+    void truncate(size_t n)
+    {
+        if (v_.size() > n) v_.resize(n);
+    }
+    void add(const Entry &e)
+    {
+        size_t pos = 0;
+        for (; pos < v_.size(); pos++) {
+            const int c = cmp(v_[pos], e);
+            if (c == 0) return;  // an equal-sim entry is already there: set unchanged
+            if (c > 0) break;
+        }
+        v_.insert(v_.begin() + (std::ptrdiff_t)pos, e);
+    }
+    void remove(const Entry &e)
+    {
+        for (size_t pos = 0; pos < v_.size(); pos++) {
+            if (cmp(v_[pos], e) == 0) {
+                v_.erase(v_.begin() + (std::ptrdiff_t)pos);
+                return;
+            }
+        }
+    }
+
+private:
+    int cmp(const Entry &a, const Entry &b) const
+    {
+        return best_high_ ? float_total_compare(b.sim, a.sim) : float_total_compare(a.sim, b.sim);
+    }
+    bool best_high_;
+    std::vector<Entry> v_;
+};
+
+// SpanUtil.spacing, impl/SpanUtil.scala:38-43
+int64_t spacing(const Entry &a, const Entry &b)
+{
+    if (a.start < b.start) return b.start - a.stop;
+    return a.start - b.stop;
+}
+
+}  // namespace
+
+struct sgz_selector {
+    int num_matches;
+    int num_per_file;
+    int64_t min_spacing;
+    int step_size;
+    int target_frames;
+    SimSet all{true};
+    SimSet entry{true};
+    bool has_last = false;
+    Entry last{};
+
+    bool entry_has_space() const
+    {
+        const int room = num_matches - (int)all.size();
+        const int max_entry = std::min(room, num_per_file);
+        return (int)entry.size() < max_entry;
+    }
+    float lowest_sim() const
+    {
+        if (!entry.empty()) return entry.last().sim;
+        if (!all.empty()) return all.last().sim;
+        return 0.0f;
+    }
+    void add_match(const Entry &m)
+    {
+        if (has_last && spacing(m, last) < min_spacing) {
+            if (last.sim < m.sim) {
+                entry.remove(last);
+                entry.add(m);
+                last = m;
+            }
+        } else {
+            entry.add(m);
+            if ((int)entry.size() > num_per_file) {
+                const Entry worst = entry.last();
+                entry.remove(worst);
+            }
+            last = m;
+            has_last = true;
+        }
+    }
+};
+
+extern "C" {
+
+sgz_selector *sgz_sel_create(int num_matches, int num_per_file, int64_t min_spacing, int step_size,
+                             int target_frames)
+{
+    if (num_matches < 0 || num_per_file < 0 || step_size < 1 || target_frames < 1) return nullptr;
+    sgz_selector *s = new sgz_selector();
+    s->num_matches = num_matches;
+    s->num_per_file = num_per_file;
+    s->min_spacing = min_spacing;
+    s->step_size = step_size;
+    s->target_frames = target_frames;
+    return s;
+}
+
+void sgz_sel_destroy(sgz_selector *sel) { delete sel; }
+
+int sgz_sel_feed_file(sgz_selector *sel, int file, int64_t n, const int32_t *offsets, const float *sims,
+                      const float *boosts)
+{
+    if (!sel || n < 0 || (n > 0 && (!sims || !boosts))) return SGZ_E_ARG;
+    sel->entry.clear();
+    sel->has_last = false;
+    for (int64_t i = 0; i < n; i++) {
+        const float sim = sims[i];
+        if (sel->entry_has_space() || sim > sel->lowest_sim()) {
+            const int64_t off = offsets ? offsets[i] : i;
+            Entry m;
+            m.sim = sim;
+            m.file = file;
+            m.start = off * sel->step_size;
+            m.stop = (off + sel->target_frames) * sel->step_size;
+            m.boost_in = boosts[i];
+            m.boost_out = 1.0f;
+            sel->add_match(m);
+        }
+    }
+    for (const Entry &e : sel->entry.items()) sel->all.add(e);
+    sel->all.truncate((size_t)sel->num_matches);
+    return SGZ_OK;
+}
+
+int sgz_sel_is_full(const sgz_selector *sel)
+{
+    return sel && (int)sel->all.size() >= sel->num_matches ? 1 : 0;
+}
+
+float sgz_sel_threshold(const sgz_selector *sel)
+{
+    if (!sel || sel->all.empty()) return 0.0f;
+    return sel->all.last().sim;
+}
+
+int sgz_sel_result(const sgz_selector *sel, sgz_match *out, int capacity)
+{
+    if (!sel || capacity < 0 || (capacity > 0 && !out)) return SGZ_E_ARG;
+    int n = 0;
+    for (const Entry &e : sel->all.items()) {
+        if (n >= capacity) break;
+        out[n].sim = e.sim;
+        out[n].boost_in = e.boost_in;
+        out[n].boost_out = e.boost_out;
+        out[n].file = e.file;
+        out[n].start = e.start;
+        out[n].stop = e.stop;
+        n++;
+    }
+    return n;
+}
+
+int sgz_segm_select(const float *sims, int64_t n, int af_start, int half_win, int step_size, int num_breaks,
+                    int64_t min_spacing, sgz_break *out, int capacity)
+{
+    if (n < 0 || (n > 0 && !sims) || step_size < 1 || num_breaks < 0 || capacity < 0 || (capacity > 0 && !out))
+        return SGZ_E_ARG;
+    SimSet prio(false);
+    bool has_last = false;
+    Entry last{};
+    for (int64_t i = 0; i < n; i++) {
+        const float sim = sims[i];
+        const bool has_space = (int)prio.size() < num_breaks;
+        const float highest = prio.empty() ? 0.0f : prio.last().sim;
+        if (has_space || sim < highest) {
+            Entry b{};
+            b.sim = sim;
+            b.start = ((int64_t)af_start + i + half_win) * step_size;  // pos
+            if (has_last && (b.start - last.start) < min_spacing) {
+                if (last.sim > b.sim) {
+                    prio.remove(last);
+                    prio.add(b);
+                    last = b;
+                }
+            } else {
+                prio.add(b);
+                if ((int)prio.size() > num_breaks) {
+                    const Entry worst = prio.last();
+                    prio.remove(worst);
+                }
+                last = b;
+                has_last = true;
+            }
+        }
+    }
+    int k = 0;
+    for (const Entry &e : prio.items()) {
+        if (k >= capacity) break;
+        out[k].sim = e.sim;
+        out[k].pad_ = 0;
+        out[k].pos = e.start;
+        k++;
+    }
+    return k;
+}
+
+}  // extern "C"

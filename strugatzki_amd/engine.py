@@ -1,0 +1,242 @@
+"""Thin object wrapper over the C ABI: one `Context` per GPU / processor.
+
+Everything numeric happens inside libstrugatzki_amd.so; this module only moves
+pointers and raises on error codes.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Iterable, Sequence
+
+import numpy as np
+
+from . import _native as N
+
+lib = N.lib
+
+
+def _as_frames(a: np.ndarray, num_ch: int | None = None) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if a.ndim != 2:
+        raise ValueError("frames must be a [numFrames][numCh] array")
+    if num_ch is not None and a.shape[1] != num_ch:
+        raise ValueError(f"expected {num_ch} channels, got {a.shape[1]}")
+    return a
+
+
+class Context:
+    """Owns one sgz_context (GPU `device`, optional existing HIP stream handle)."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        h = C.c_void_p()
+        rc = lib.sgz_create(device, C.c_void_p(stream) if stream else None, C.byref(h))
+        if rc != N.SGZ_OK:
+            raise N.NativeError(rc, "sgz_create failed (no usable GPU?)")
+        self._h = h
+        self.num_channels = 0
+
+    def close(self) -> None:
+        if self._h:
+            lib.sgz_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int) -> None:
+        if rc != N.SGZ_OK:
+            raise N.NativeError(rc, lib.sgz_last_error(self._h).decode())
+
+    # ---- database --------------------------------------------------------
+    def db_reset(self, num_channels: int) -> None:
+        self._check(lib.sgz_db_reset(self._h, num_channels))
+        self.num_channels = num_channels
+
+    def db_add_file(self, frames: np.ndarray) -> None:
+        a = _as_frames(frames, self.num_channels)
+        self._check(lib.sgz_db_add_file(self._h, N.ptr(a), a.shape[0]))
+
+    def db_add_file_device(self, device_ptr: int, num_frames: int) -> None:
+        self._check(lib.sgz_db_add_file_device(self._h, C.c_void_p(device_ptr), num_frames))
+
+    def db_add_synthetic(self, seed: int, file_id: int, num_frames: int, plants: Sequence[N.Plant] = ()) -> None:
+        arr = (N.Plant * len(plants))(*plants) if plants else None
+        self._check(lib.sgz_db_add_synthetic(self._h, seed, file_id, num_frames, arr, len(plants)))
+
+    @property
+    def num_files(self) -> int:
+        return lib.sgz_db_num_files(self._h)
+
+    def file_frames(self, file: int) -> int:
+        return lib.sgz_db_file_frames(self._h, file)
+
+    def db_read_file(self, file: int) -> np.ndarray:
+        n = self.file_frames(file)
+        out = np.empty((n, self.num_channels), dtype=np.float32)
+        self._check(lib.sgz_db_read_file(self._h, file, N.ptr(out)))
+        return out
+
+    def set_norms(self, norms: np.ndarray | None) -> None:
+        """norms: [numCh][2] (min, max) or None."""
+        if norms is None:
+            self._check(lib.sgz_set_norms(self._h, None))
+            return
+        a = np.ascontiguousarray(norms, dtype=np.float32)
+        if a.shape != (self.num_channels, 2):
+            raise ValueError("norms must be [numCh][2]")
+        self._check(lib.sgz_set_norms(self._h, N.ptr(a)))
+
+    # ---- correlation -----------------------------------------------------
+    def corr_set_target(self, frames: np.ndarray, temporal_weight: float, max_boost: float) -> None:
+        a = _as_frames(frames, self.num_channels)
+        self._check(lib.sgz_corr_set_target(self._h, N.ptr(a), a.shape[0], temporal_weight, max_boost))
+        self.target_frames = a.shape[0]
+
+    def corr_num_windows(self, file: int) -> int:
+        return lib.sgz_corr_num_windows(self._h, file)
+
+    def corr_run(self, file_begin: int = 0, file_end: int | None = None) -> None:
+        if file_end is None:
+            file_end = self.num_files
+        self._check(lib.sgz_corr_run(self._h, file_begin, file_end))
+
+    def corr_read_dense(self, file: int) -> tuple[np.ndarray, np.ndarray]:
+        n = max(0, self.corr_num_windows(file))
+        sim = np.empty(n, dtype=np.float32)
+        boost = np.empty(n, dtype=np.float32)
+        self._check(lib.sgz_corr_read_dense(self._h, file, N.ptr(sim), N.ptr(boost)))
+        return sim, boost
+
+    def corr_compact(self, file_begin: int, file_end: int, threshold: float, capacity: int) -> np.ndarray:
+        """Candidates with sim > threshold, sorted by (file, offset); raises on overflow."""
+        out = np.empty(max(capacity, 1), dtype=N.CANDIDATE_DTYPE)
+        cnt = C.c_int64(0)
+        rc = lib.sgz_corr_compact(self._h, file_begin, file_end, threshold, N.ptr(out), capacity, C.byref(cnt))
+        self._check(rc)
+        return out[: cnt.value]
+
+    def corr_compact_device(self, file_begin: int, file_end: int, threshold: float, out_ptr: int,
+                            capacity: int, count_ptr: int) -> None:
+        self._check(lib.sgz_corr_compact_device(self._h, file_begin, file_end, threshold,
+                                                C.c_void_p(out_ptr), capacity, C.c_void_p(count_ptr)))
+
+    def corr_last_kernel_ms(self) -> float:
+        return float(lib.sgz_corr_last_kernel_ms(self._h))
+
+    def corr_last_work(self) -> tuple[int, float]:
+        w = C.c_int64(0)
+        f = C.c_double(0.0)
+        self._check(lib.sgz_corr_last_work(self._h, C.byref(w), C.byref(f)))
+        return w.value, f.value
+
+    def synchronize(self) -> None:
+        self._check(lib.sgz_synchronize(self._h))
+
+    # ---- segmentation / self-similarity ----------------------------------
+    def segm_curve(self, frames: np.ndarray, af_start: int, af_stop: int, half_win: int,
+                   temporal_weight: float) -> np.ndarray:
+        a = _as_frames(frames)
+        n = max(0, (af_stop - af_start) - 2 * half_win + 1)
+        out = np.empty(max(n, 1), dtype=np.float32)
+        cnt = C.c_int64(0)
+        self._check(lib.sgz_segm_curve(self._h, N.ptr(a), a.shape[0], a.shape[1], af_start, af_stop, half_win,
+                                       temporal_weight, N.ptr(out), C.byref(cnt)))
+        return out[: cnt.value]
+
+    def selfsim(self, frames1: np.ndarray, frames2: np.ndarray | None, af_start: int, half_win: int, decim: int,
+                img_ext: int, temporal_weight: float, colors: int = 0, color_warp: float = 1.0,
+                color_ceil: float = 1.0, color_inv: bool = False, want_sim: bool = True,
+                want_img: bool = True) -> tuple[np.ndarray | None, np.ndarray | None]:
+        a1 = _as_frames(frames1)
+        a2 = a1 if frames2 is None else _as_frames(frames2, a1.shape[1])
+        sim = np.zeros((img_ext, img_ext), dtype=np.float32) if want_sim else None
+        img = np.zeros((img_ext, img_ext), dtype=np.int32) if want_img else None
+        self._check(lib.sgz_selfsim_run(self._h, N.ptr(a1), a1.shape[0], N.ptr(a2), a2.shape[0], a1.shape[1],
+                                        af_start, half_win, decim, img_ext, temporal_weight, colors, color_warp,
+                                        color_ceil, int(color_inv), N.ptr(sim), N.ptr(img)))
+        return sim, img
+
+
+class Selector:
+    """Match bookkeeping of FeatureCorrelationImpl (host side, sgz_sel_*)."""
+
+    def __init__(self, num_matches: int, num_per_file: int, min_spacing: int, step_size: int, target_frames: int):
+        self._h = lib.sgz_sel_create(num_matches, num_per_file, min_spacing, step_size, target_frames)
+        if not self._h:
+            raise ValueError("illegal selector parameters")
+        self.num_matches = num_matches
+
+    def close(self) -> None:
+        if self._h:
+            lib.sgz_sel_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def feed_dense(self, file: int, sims: np.ndarray, boosts: np.ndarray) -> None:
+        s = np.ascontiguousarray(sims, dtype=np.float32)
+        b = np.ascontiguousarray(boosts, dtype=np.float32)
+        rc = lib.sgz_sel_feed_file(self._h, file, s.shape[0], None, N.ptr(s), N.ptr(b))
+        if rc != N.SGZ_OK:
+            raise N.NativeError(rc, "sgz_sel_feed_file")
+
+    def feed_candidates(self, file: int, offsets: np.ndarray, sims: np.ndarray, boosts: np.ndarray) -> None:
+        o = np.ascontiguousarray(offsets, dtype=np.int32)
+        s = np.ascontiguousarray(sims, dtype=np.float32)
+        b = np.ascontiguousarray(boosts, dtype=np.float32)
+        rc = lib.sgz_sel_feed_file(self._h, file, s.shape[0], N.ptr(o), N.ptr(s), N.ptr(b))
+        if rc != N.SGZ_OK:
+            raise N.NativeError(rc, "sgz_sel_feed_file")
+
+    @property
+    def is_full(self) -> bool:
+        return bool(lib.sgz_sel_is_full(self._h))
+
+    @property
+    def threshold(self) -> float:
+        return float(lib.sgz_sel_threshold(self._h))
+
+    def result(self) -> list[N.Match]:
+        arr = (N.Match * max(self.num_matches, 1))()
+        n = lib.sgz_sel_result(self._h, arr, self.num_matches)
+        return [arr[i] for i in range(n)]
+
+
+def segm_select(sims: np.ndarray, af_start: int, half_win: int, step_size: int, num_breaks: int,
+                min_spacing: int) -> list[N.Break]:
+    s = np.ascontiguousarray(sims, dtype=np.float32)
+    arr = (N.Break * max(num_breaks, 1))()
+    n = lib.sgz_segm_select(N.ptr(s), s.shape[0], af_start, half_win, step_size, num_breaks, min_spacing, arr,
+                            num_breaks)
+    if n < 0:
+        raise N.NativeError(n, "sgz_segm_select")
+    return [arr[i] for i in range(n)]
+
+
+def match_tuple(m: N.Match) -> tuple:
+    return (m.sim, m.file, m.start, m.stop, m.boost_in, m.boost_out)
+
+
+def iter_files(cands: np.ndarray) -> Iterable[tuple[int, np.ndarray]]:
+    """Splits a (file, offset)-sorted candidate array into per-file slices."""
+    if len(cands) == 0:
+        return
+    files = cands["file"]
+    cuts = np.flatnonzero(np.diff(files)) + 1
+    start = 0
+    for c in list(cuts) + [len(cands)]:
+        yield int(files[start]), cands[start:c]
+        start = c

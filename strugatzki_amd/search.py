@@ -1,0 +1,152 @@
+"""Database search = GPU similarity + exact replay of the reference's match selection.
+
+The reference walks the database files one after another and keeps two
+priority sets whose gate depends on what earlier files produced
+(impl/FeatureCorrelationImpl.scala:113-150, :234, :399-400).  The GPU computes
+the similarity of every window of every file at once; the selection is then
+replayed on the host in file order:
+
+  1. "head": files are fed densely until the global set holds num_matches
+     entries.  From then on a window can only be offered if its sim exceeds
+     the sim of the worst global entry, and that bound never falls.
+  2. "tail": for all remaining files only windows above that bound are fetched
+     from the GPU (stream compaction) and fed in file / offset order.
+
+Sharded over several GPUs (one process each), every rank holds the head files
+plus its own slice of the tail; the ranks exchange their tail candidates with
+one all-gather and then run the same replay, so every rank ends with the same
+list as a single-GPU run.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Sequence
+
+import numpy as np
+
+from . import _native as N
+from .engine import Context, Selector, iter_files
+
+
+@dataclass
+class SearchParams:
+    num_matches: int = 1
+    num_per_file: int = 1
+    min_spacing: int = 0      # sample frames
+    step_size: int = 512      # fftSize / fftOverlap
+    capacity: int = 1 << 16   # candidate records fetched per rank
+
+
+def _feed_dense_head(ctx: Context, sel: Selector, files: Sequence[int], global_ids: Sequence[int]) -> int:
+    """Feeds files densely, in order, until the selector is full. Returns how many were fed."""
+    fed = 0
+    for local, gid in zip(files, global_ids):
+        if sel.is_full:
+            break
+        sim, boost = ctx.corr_read_dense(local)
+        sel.feed_dense(gid, sim, boost)
+        fed += 1
+    return fed
+
+
+def search(ctx: Context, p: SearchParams) -> list[N.Match]:
+    """Single-GPU search over all files of the context, in their index order."""
+    nf = ctx.num_files
+    sel = Selector(p.num_matches, p.num_per_file, p.min_spacing, p.step_size, ctx.target_frames)
+    head = min(nf, max(p.num_matches, 1))
+    ctx.corr_run(0, head)
+    if head < nf:
+        ctx.corr_run(head, nf)
+    f = _feed_dense_head(ctx, sel, range(head), range(head))
+    # rare: equal sims collapsed entries, the set is not full yet -> keep feeding densely
+    while f < nf and not sel.is_full:
+        sim, boost = ctx.corr_read_dense(f)
+        sel.feed_dense(f, sim, boost)
+        f += 1
+    if f < nf:
+        try:
+            cands = ctx.corr_compact(f, nf, sel.threshold, p.capacity)
+        except N.NativeError as e:
+            if e.code != N.SGZ_E_OVERFLOW:
+                raise
+            cands = None
+        if cands is None:  # more candidates than the buffer holds: dense replay of the tail
+            for g in range(f, nf):
+                sim, boost = ctx.corr_read_dense(g)
+                sel.feed_dense(g, sim, boost)
+        else:
+            for g, part in iter_files(cands):
+                sel.feed_candidates(g, part["offset"], part["sim"], part["boost"])
+    out = sel.result()
+    sel.close()
+    return out
+
+
+def shard_files(num_files: int, head: int, rank: int, world: int) -> list[int]:
+    """Global ids of the tail files rank `rank` owns (round robin keeps equal-length files balanced)."""
+    return [g for g in range(head, num_files) if (g - head) % world == rank]
+
+
+def exchange_candidates(rec, cnt, capacity: int, group=None) -> np.ndarray:
+    """The one collective of the search: all-gather of fixed-size candidate
+    buffers and their fill counts.  `rec` is an int32 [capacity][4] tensor whose
+    rows are sgz_candidate records (file already translated to the global id),
+    `cnt` a 1-element int64 tensor; both live on the GPU for the nccl (RCCL)
+    backend and on the host for gloo.  Returns all ranks' candidates sorted by
+    (file, offset)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    n_local = int(cnt.item())
+    if n_local > capacity:
+        raise RuntimeError(f"candidate buffer overflow ({n_local} > {capacity}); raise SearchParams.capacity")
+    recs = [torch.empty_like(rec) for _ in range(world)]
+    cnts = [torch.empty_like(cnt) for _ in range(world)]
+    dist.all_gather(cnts, cnt, group=group)
+    dist.all_gather(recs, rec, group=group)
+    parts = [recs[r][: int(cnts[r].item())].cpu().numpy() for r in range(world)]
+    allc = np.concatenate(parts, axis=0) if parts else np.zeros((0, 4), np.int32)
+    cands = np.ascontiguousarray(allc, dtype=np.int32).view(N.CANDIDATE_DTYPE).reshape(-1)
+    order = np.lexsort((cands["offset"], cands["file"]))
+    return cands[order]
+
+
+def finish_selection(sel: Selector, cands: np.ndarray) -> list[N.Match]:
+    """Tail replay over (file, offset)-sorted candidates, then the result list."""
+    for g, part in iter_files(cands):
+        sel.feed_candidates(g, part["offset"], part["sim"], part["boost"])
+    return sel.result()
+
+
+def search_sharded(ctx: Context, p: SearchParams, head_global: Sequence[int], tail_global: Sequence[int],
+                   group=None) -> list[N.Match]:
+    """Multi-process search, one process per GPU.  The context holds the head
+    files first (global ids `head_global`, identical on every rank) and then this
+    rank's tail files (`tail_global`, ascending)."""
+    import torch
+
+    nh, nt = len(head_global), len(tail_global)
+    assert ctx.num_files == nh + nt
+    sel = Selector(p.num_matches, p.num_per_file, p.min_spacing, p.step_size, ctx.target_frames)
+    ctx.corr_run(0, nh)
+    if nt:
+        ctx.corr_run(nh, nh + nt)
+    _feed_dense_head(ctx, sel, range(nh), head_global)
+    if not sel.is_full:  # every rank replayed the same head, so all ranks agree on this
+        raise RuntimeError("head files did not fill the match set; enlarge the head (degenerate equal sims)")
+    cap = p.capacity
+    dev = torch.device("cuda", torch.cuda.current_device())
+    rec = torch.zeros((cap, 4), dtype=torch.int32, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    torch.cuda.current_stream().synchronize()  # buffers are zeroed before the library's stream writes them
+    ctx.corr_compact_device(nh, nh + nt, sel.threshold, rec.data_ptr(), cap, cnt.data_ptr())
+    ctx.synchronize()
+    n_local = min(int(cnt.item()), cap)
+    if n_local:  # local file index -> global id
+        lut = torch.tensor(list(head_global) + list(tail_global), dtype=torch.int32, device=dev)
+        rec[:n_local, 0] = lut[rec[:n_local, 0].long()]
+    cands = exchange_candidates(rec, cnt, cap, group)
+    out = finish_selection(sel, cands)
+    sel.close()
+    return out

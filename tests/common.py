@@ -1,0 +1,71 @@
+"""Shared builders for the tests: synthetic feature databases and configs."""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import oracle_lib as O  # noqa: E402
+
+SEED = 0x5354525547  # "STRUG"
+NUM_CH = 14
+STEP = 512
+TARGET_FILE = -1
+
+
+def norms_default(num_ch: int = NUM_CH) -> np.ndarray:
+    """[numCh][2] (min, max): loudness 0..1.5, MFCC channels slightly different ranges each."""
+    n = np.zeros((num_ch, 2), dtype=np.float32)
+    n[0] = (0.0, 1.5)
+    for c in range(1, num_ch):
+        n[c] = (np.float32(0.01) * c, np.float32(1.0) + np.float32(0.02) * c)
+    return n
+
+
+def make_plants(num: int, L: int, num_files: int, frames_per_file: int, target_start: int, amp_step: float = 0.02,
+                first_file: int = 0):
+    """`num` noisy copies of the target, copy j in file first_file + j*stride at a distinct offset."""
+    plants = []
+    stride = max(1, (num_files - first_file) // max(num, 1))
+    for j in range(num):
+        f = first_file + j * stride
+        room = frames_per_file - L
+        off = (37 + 101 * j) % max(room, 1) if room > 0 else 0
+        plants.append(dict(file=f, offset=off, src_file=TARGET_FILE, src_offset=target_start, length=L,
+                           amp=float(np.float32(amp_step) * (j + 1)), gain=1.0))
+    return plants
+
+
+def oracle_plants(plants):
+    return [O.Plant(p["file"], p["offset"], p["src_file"], p["src_offset"], p["length"], p["amp"], p["gain"])
+            for p in plants]
+
+
+def native_plants(plants):
+    from strugatzki_amd import _native as N
+    return [N.Plant(p["file"], p["offset"], p["src_file"], p["src_offset"], p["length"], p["amp"], p["gain"])
+            for p in plants]
+
+
+def synth_db(num_files: int, frames, plants=(), seed: int = SEED, num_ch: int = NUM_CH):
+    """Host copy of the synthetic database (list of [frames][numCh] arrays)."""
+    if np.isscalar(frames):
+        frames = [int(frames)] * num_files
+    op = oracle_plants(plants)
+    return [O.synth_file(seed, f, int(frames[f]), num_ch, op) for f in range(num_files)]
+
+
+def synth_target(target_start: int, L: int, seed: int = SEED, num_ch: int = NUM_CH) -> np.ndarray:
+    """Frames [0, target_start + L + 16) of the dedicated target file."""
+    return O.synth_file(seed, TARGET_FILE, target_start + L + 16, num_ch)
+
+
+def corr_config(target_start: int, L: int, *, weight=0.5, normalize=True, max_boost=8.0, num_matches=10,
+                num_per_file=1, min_spacing=0, num_ch: int = NUM_CH) -> O.CorrConfig:
+    return O.CorrConfig(target_start * STEP, (target_start + L) * STEP, weight, int(normalize), max_boost,
+                        num_matches, num_per_file, min_spacing, STEP, num_ch - 1)

@@ -1,0 +1,163 @@
+"""GPU parity of the FeatureCorrelation path against the CPU oracle.
+
+Bar: similarities and boosts within 1e-5 absolute of the oracle, match offsets
+(punch spans, file indices) bit-exact.  The oracle itself is parity-unpinned
+against the Scala reference (see oracle/strugatzki_oracle.c).
+"""
+import numpy as np
+import pytest
+
+from common import (NUM_CH, SEED, STEP, O, corr_config, make_plants, native_plants, norms_default, synth_db,
+                    synth_target)
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5  # absolute, on sim; stated by the north star
+
+
+def _load(ctx, db, norms):
+    ctx.db_reset(db[0].shape[1] if db else NUM_CH)
+    for f in db:
+        ctx.db_add_file(f)
+    ctx.set_norms(norms)
+
+
+def _gpu_dense(ctx, nfiles):
+    ctx.corr_run(0, nfiles)
+    return [ctx.corr_read_dense(f) for f in range(nfiles)]
+
+
+def _check_dense(ctx, db, tgt, ts, L, norms, weight=0.5, max_boost=8.0):
+    import strugatzki_amd as S
+    cfg = corr_config(ts, L, weight=weight, normalize=norms is not None, max_boost=max_boost, num_matches=5)
+    _, sims, boosts = O.correlation_run(cfg, tgt, norms, db)
+    _load(ctx, db, norms)
+    ctx.corr_set_target(tgt[ts:ts + L], weight, max_boost)
+    got = _gpu_dense(ctx, len(db))
+    worst = 0.0
+    for f, (gs, gb) in enumerate(got):
+        n = ctx.corr_num_windows(f)
+        if db[f].shape[0] < L:
+            assert n == 0  # the stale-ring window of the reference is not produced
+            continue
+        assert n == sims[f].shape[0] == gs.shape[0]
+        np.testing.assert_allclose(gs, sims[f], rtol=0, atol=TOL)
+        np.testing.assert_allclose(gb, boosts[f], rtol=2e-6, atol=0)
+        if n:
+            worst = max(worst, float(np.max(np.abs(gs - sims[f]))))
+    return worst
+
+
+@pytest.mark.parametrize("L,frames", [(64, 400), (431, 2583), (100, 1500), (16, 100), (33, 33)])
+def test_dense_parity(ctx, L, frames):
+    ts = 20
+    nf = 4
+    plants = make_plants(2, L, nf, frames, ts)
+    db = synth_db(nf, frames, plants)
+    tgt = synth_target(ts, L)
+    worst = _check_dense(ctx, db, tgt, ts, L, norms_default())
+    assert worst <= TOL
+
+
+def test_dense_parity_ragged_and_short_files(ctx):
+    L, ts = 120, 5
+    frames = [1000, 119, 120, 121, 0, 2047, 1024 + 119, 1024 + 120]
+    db = synth_db(len(frames), frames)
+    tgt = synth_target(ts, L)
+    _check_dense(ctx, db, tgt, ts, L, norms_default())
+
+
+@pytest.mark.parametrize("weight", [0.0, 1.0, 0.25])
+def test_dense_parity_weights(ctx, weight):
+    L, ts = 80, 11
+    db = synth_db(3, 700, make_plants(1, L, 3, 700, ts))
+    tgt = synth_target(ts, L)
+    _check_dense(ctx, db, tgt, ts, L, norms_default(), weight=weight)
+
+
+def test_dense_parity_without_normalisation(ctx):
+    L, ts = 80, 11
+    db = synth_db(3, 700, make_plants(1, L, 3, 700, ts))
+    tgt = synth_target(ts, L)
+    _check_dense(ctx, db, tgt, ts, L, None)
+
+
+def test_max_boost_gate_gives_zero_sim(ctx):
+    """A quiet copy needs a boost above maxBoost: sim must be exactly 0f (impl/FeatureCorrelationImpl.scala:209)."""
+    L, ts, frames = 64, 9, 600
+    plants = [dict(file=0, offset=100, src_file=-1, src_offset=ts, length=L, amp=0.0, gain=0.05)]
+    db = synth_db(2, frames, plants)
+    tgt = synth_target(ts, L)
+    _check_dense(ctx, db, tgt, ts, L, norms_default(), max_boost=2.0)
+    sim, boost = ctx.corr_read_dense(0)
+    assert boost[100] > 2.0 and sim[100] == 0.0
+    # boost law of notes/BoostFactor.txt: loudness scaled by d**0.6 <-> boost 1/d; here loudness*0.05
+    assert abs(boost[100] - 0.05 ** (-1 / 0.6)) / boost[100] < 1e-3
+
+
+def test_long_target_two_lds_blocks(ctx):
+    """L > 192*16 frames makes the kernel stage each channel in two blocks."""
+    L, ts = 3300, 3
+    db = synth_db(2, 5000, make_plants(1, L, 2, 5000, ts))
+    tgt = synth_target(ts, L)
+    _check_dense(ctx, db, tgt, ts, L, norms_default())
+
+
+@pytest.mark.parametrize("num_matches,num_per_file,min_spacing", [(10, 1, 0), (5, 3, 0), (6, 2, 40 * STEP),
+                                                                  (1, 1, 0), (12, 4, 3 * STEP)])
+def test_search_matches_bit_exact(ctx, num_matches, num_per_file, min_spacing):
+    import strugatzki_amd as S
+    L, ts, nf, frames = 96, 17, 16, 900
+    plants = make_plants(6, L, nf, frames, ts)
+    db = synth_db(nf, frames, plants)
+    tgt = synth_target(ts, L)
+    norms = norms_default()
+    cfg = corr_config(ts, L, num_matches=num_matches, num_per_file=num_per_file, min_spacing=min_spacing)
+    want, _, _ = O.correlation_run(cfg, tgt, norms, db, dense=False)
+    _load(ctx, db, norms)
+    ctx.corr_set_target(tgt[ts:ts + L], 0.5, 8.0)
+    got = S.search(ctx, S.SearchParams(num_matches, num_per_file, min_spacing, STEP, capacity=1 << 16))
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert (g.file, g.start, g.stop) == (w.file, w.start, w.stop)
+        assert abs(g.sim - w.sim) <= TOL
+        assert abs(g.boost_in - w.boost_in) <= 2e-6 * abs(w.boost_in)
+        assert g.boost_out == 1.0
+
+
+def test_search_falls_back_to_dense_on_candidate_overflow(ctx):
+    import strugatzki_amd as S
+    L, ts, nf, frames = 64, 4, 6, 500
+    db = synth_db(nf, frames)
+    tgt = synth_target(ts, L)
+    norms = norms_default()
+    cfg = corr_config(ts, L, num_matches=2, num_per_file=2)
+    want, _, _ = O.correlation_run(cfg, tgt, norms, db, dense=False)
+    _load(ctx, db, norms)
+    ctx.corr_set_target(tgt[ts:ts + L], 0.5, 8.0)
+    got = S.search(ctx, S.SearchParams(2, 2, 0, STEP, capacity=1))
+    assert [(g.file, g.start, g.stop) for g in got] == [(w.file, w.start, w.stop) for w in want]
+
+
+def test_synthetic_generator_matches_oracle_bits(ctx):
+    L, ts, frames = 50, 8, 300
+    plants = make_plants(2, L, 3, frames, ts)
+    db = synth_db(3, frames, plants)
+    ctx.db_reset(NUM_CH)
+    for f in range(3):
+        ctx.db_add_synthetic(SEED, f, frames, native_plants(plants))
+    for f in range(3):
+        assert np.array_equal(ctx.db_read_file(f), db[f])
+
+
+def test_identity_window_scores_one(ctx):
+    """correlate(a, a) == 1.0 (impl/MathUtil.scala:195): the target cut out of a database file."""
+    L, frames = 200, 1200
+    db = synth_db(1, frames)
+    tgt = db[0][300:300 + L]
+    _load(ctx, db, norms_default())
+    ctx.corr_set_target(tgt, 0.5, 8.0)
+    ctx.corr_run(0, 1)
+    sim, boost = ctx.corr_read_dense(0)
+    assert abs(sim[300] - 1.0) <= 1e-6 and abs(boost[300] - 1.0) <= 1e-6
+    assert int(np.argmax(sim)) == 300
