@@ -168,14 +168,27 @@ def main() -> int:
         torch.cuda.synchronize()
         ctx.synchronize()
 
+    # Host side hygiene of a long-running search service: the interpreter's full
+    # garbage collections walk every object torch created at import (tens of ms);
+    # park those objects in the permanent generation before the loop.
+    import gc
+    gc.collect()
+    gc.freeze()
+
+    matches = []
     for _ in range(args.warmup):
         matches = step()
     kernel_ms = []
     sync()
     t0 = time.perf_counter()
+    step_ms = []
     for _ in range(args.steps):
+        ts = time.perf_counter()
         matches = step()
+        step_ms.append((time.perf_counter() - ts) * 1e3)
         kernel_ms.append(ctx.corr_last_kernel_ms())
+    if os.environ.get("SGZ_DEBUG"):
+        print("step ms:", " ".join(f"{x:.2f}" for x in step_ms), file=sys.stderr)
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:

@@ -145,6 +145,11 @@ SGZ_API int sgz_corr_run(sgz_context *ctx, int file_begin, int file_end);
 /* Copies sim / boost of all windows of one file to the host (either pointer
  * may be NULL).  Synchronises the stream. */
 SGZ_API int sgz_corr_read_dense(sgz_context *ctx, int file, float *sim_out, float *boost_out);
+/* Same for the consecutive files [file_begin, file_end): their windows are
+ * written back to back in file order.  Waits only for the sgz_corr_run calls
+ * that produced these files, not for later work on the stream. */
+SGZ_API int sgz_corr_read_dense_range(sgz_context *ctx, int file_begin, int file_end, float *sim_out,
+                                      float *boost_out);
 
 /* Collects the windows of files [file_begin, file_end) whose sim is > threshold
  * (the strict comparison of impl/FeatureCorrelationImpl.scala:234) into `out`

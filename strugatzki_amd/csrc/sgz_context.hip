@@ -27,6 +27,11 @@ int sgz_create(int device, void *hip_stream, sgz_context **out)
         }
         ctx->own_stream = true;
     }
+    if (hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess) {
+        if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return SGZ_E_HIP;
+    }
     *out = ctx;
     return SGZ_OK;
 }
@@ -38,10 +43,13 @@ void sgz_destroy(sgz_context *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     for (auto &f : ctx->files)
         if (f.owned && f.d_raw) (void)hipFree(f.d_raw);
-    void *bufs[] = {ctx->d_aprime, ctx->d_files, ctx->d_tiles, ctx->d_ptiles, ctx->d_planar, ctx->d_prefix,
-                    ctx->d_sim,    ctx->d_boost, ctx->d_count, ctx->d_cand};
+    void *bufs[] = {ctx->d_aprime, ctx->d_files, ctx->d_tiles, ctx->d_ptiles, ctx->d_planar, ctx->d_prefix, ctx->d_tbase,
+                    ctx->d_sim,    ctx->d_boost, ctx->d_cand};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
+    for (auto &r : ctx->runs) (void)hipEventDestroy(r.done);
+    for (auto &e : ctx->event_pool) (void)hipEventDestroy(e);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);

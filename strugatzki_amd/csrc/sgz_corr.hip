@@ -11,14 +11,17 @@
 //                 "chunk-major" planar layout [ch][j][m] (frame = 16*m + j) plus
 //                 per-frame first / second moments of the loudness channel and of
 //                 the MFCC channels
-//   scan_kernel   per-file prefix sums of those moments (window mean / std-dev
-//                 become two subtractions)
+//                 and their prefix sums inside each 1024-frame tile
+//   tile_scan_kernel  exclusive scan of the tile totals per file (window mean /
+//                 std-dev become two subtractions of prefix values)
 //   corr_kernel   cross terms sum_i a'[c][i] * b[c][o+i] for 1024 windows per
 //                 workgroup, fp64 FMA, then boost / similarity per window
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "sgz_internal.hpp"
@@ -94,9 +97,11 @@ __global__ void synth_kernel(float *out, unsigned long long seed, long long file
 __global__ __launch_bounds__(256) void prep_kernel(const FileDesc *__restrict__ files,
                                                    const PrepTile *__restrict__ ptiles,
                                                    double *__restrict__ planar, double *__restrict__ prefix,
-                                                   NormParams nrm, int numCh, int cb, double kT, double kS)
+                                                   double *__restrict__ tbase, NormParams nrm, int numCh, int cb,
+                                                   double kT, double kS)
 {
     extern __shared__ __attribute__((aligned(16))) float xs[];
+    __shared__ double wtot[4][4];
     const PrepTile pt = ptiles[blockIdx.x];
     const FileDesc fd = files[pt.file];
     const int jstride = cb + 1;
@@ -105,110 +110,167 @@ __global__ __launch_bounds__(256) void prep_kernel(const FileDesc *__restrict__ 
     const int tileFrames = cb * kR;
     const int tid = threadIdx.x;
 
-    // phase 1: coalesced read of the interleaved frames, normalise in fp32
+    // phase 1: coalesced read of the interleaved frames, normalise in fp32.
+    // (fr, c) of element e = tid + 256*k advance by a fixed (dfr, dc) per k.
     const int total = tileFrames * numCh;
     const float *src = fd.raw + f0 * numCh;
     const long long validElems = (fd.frames - f0) * numCh;  // may be <= 0 for padding tiles
-    for (int e = tid; e < total; e += 256) {
-        const int fr = e / numCh;
-        const int c = e - fr * numCh;
-        float v = 0.0f;
-        if (e < validElems) {
-            v = src[e];
-            if (nrm.enabled) v = (v - nrm.mn[c]) / nrm.d[c];
+    {
+        const int dfr = 256 / numCh, dc = 256 - dfr * numCh;
+        int fr = tid / numCh, c = tid - fr * numCh;
+        for (int e = tid; e < total; e += 256) {
+            float v = 0.0f;
+            if (e < validElems) {
+                v = src[e];
+                if (nrm.enabled) v = (v - nrm.mn[c]) / nrm.d[c];
+            }
+            xs[c * cstride + (fr & (kR - 1)) * jstride + (fr >> 4)] = v;
+            fr += dfr;
+            c += dc;
+            if (c >= numCh) {
+                c -= numCh;
+                fr += 1;
+            }
         }
-        xs[c * cstride + (fr & (kR - 1)) * jstride + (fr >> 4)] = v;
     }
     __syncthreads();
 
     // phase 2: chunk-major planar fp64, centred; frames past the end are 0
     double *dst = planar + fd.planar_off;
     const int rows = numCh * kR;
-    for (int idx = tid; idx < rows * cb; idx += 256) {
-        const int mm = idx % cb;
-        const int row = idx / cb;
-        const int c = row >> 4;
-        const int j = row & (kR - 1);
-        const long long m = (long long)pt.chunk0 + mm;
-        if (m < fd.M) {
-            const long long fr = m * kR + j;
-            double v = 0.0;
-            if (fr < fd.frames) v = (double)xs[c * cstride + j * jstride + mm] - (c == 0 ? kT : kS);
-            dst[(long long)row * fd.M + m] = v;
+    {
+        // idx = tid + 256*k over [rows][cb]; cb is a power of two
+        const int cbShift = 31 - __clz(cb);
+        for (int idx = tid; idx < rows * cb; idx += 256) {
+            const int mm = idx & (cb - 1);
+            const int row = idx >> cbShift;
+            const int c = row >> 4;
+            const int j = row & (kR - 1);
+            const long long m = (long long)pt.chunk0 + mm;
+            if (m < fd.M) {
+                const long long fr = m * kR + j;
+                double v = 0.0;
+                if (fr < fd.frames) v = (double)xs[c * cstride + j * jstride + mm] - (c == 0 ? kT : kS);
+                dst[(long long)row * fd.M + m] = v;
+            }
         }
     }
 
-    // phase 3: per-frame moments, stored at index frame+1 of the prefix arrays
-    double *pre = prefix + fd.prefix_off;
-    const long long n1 = fd.frames + 1;
-    for (int fr = tid; fr < tileFrames; fr += 256) {
-        const long long gf = f0 + fr;
-        if (gf < fd.frames) {
-            const int j = fr & (kR - 1), mm = fr >> 4;
-            const double t = (double)xs[j * jstride + mm] - kT;
-            double s1 = 0.0, s2 = 0.0;
-            for (int c = 1; c < numCh; c++) {
-                const double d = (double)xs[c * cstride + j * jstride + mm] - kS;
-                s1 += d;
-                s2 = fma(d, d, s2);
+    // phase 3: per-frame moments (loudness: x, x^2; MFCC rows: sum x, sum x^2, all centred) and their
+    // inclusive prefix sums inside this tile; the tile totals go to tbase for the cross-tile scan.
+    if (f0 < fd.frames) {
+        const int per = tileFrames >= 256 ? tileFrames / 256 : 1;  // consecutive frames per thread
+        double run[4] = {0.0, 0.0, 0.0, 0.0};
+        double m[4][4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int fr = tid * per + k;
+            const long long gf = f0 + fr;
+            m[k][0] = m[k][1] = m[k][2] = m[k][3] = 0.0;
+            if (k < per && fr < tileFrames && gf < fd.frames) {
+                const int j = fr & (kR - 1), mm = fr >> 4;
+                const double t = (double)xs[j * jstride + mm] - kT;
+                double s1 = 0.0, s2 = 0.0;
+                for (int c = 1; c < numCh; c++) {
+                    const double d = (double)xs[c * cstride + j * jstride + mm] - kS;
+                    s1 += d;
+                    s2 = fma(d, d, s2);
+                }
+                m[k][0] = t;
+                m[k][1] = t * t;
+                m[k][2] = s1;
+                m[k][3] = s2;
             }
-            pre[gf + 1] = t;
-            pre[n1 + gf + 1] = t * t;
-            pre[2 * n1 + gf + 1] = s1;
-            pre[3 * n1 + gf + 1] = s2;
+#pragma unroll
+            for (int q = 0; q < 4; q++) run[q] += m[k][q];
+        }
+        // exclusive scan of run[] over the 256 threads
+        double inc[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) inc[q] = run[q];
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const double up = __shfl_up(inc[q], off, 64);
+                if ((tid & 63) >= off) inc[q] += up;
+            }
+        }
+        if ((tid & 63) == 63) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) wtot[tid >> 6][q] = inc[q];
+        }
+        __syncthreads();
+        double base[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            double bsum = 0.0;
+            for (int wv = 0; wv < (tid >> 6); wv++) bsum += wtot[wv][q];
+            base[q] = bsum + inc[q] - run[q];
+        }
+        double *pre = prefix + fd.prefix_off;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int fr = tid * per + k;
+            const long long gf = f0 + fr;
+            if (k < per && fr < tileFrames && gf < fd.frames) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    base[q] += m[k][q];
+                    pre[q * fd.frames + gf] = base[q];
+                }
+            }
+        }
+        if (tid == 255) {
+            const int tileIdx = pt.chunk0 / cb;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                tbase[fd.tbase_off + (long long)q * fd.nptiles + tileIdx] = wtot[0][q] + wtot[1][q] + wtot[2][q] + inc[q];
         }
     }
 }
 
 // ---------------------------------------------------------------------------
-// scan_kernel: in-place inclusive scan of P[1..n] per (array, file); P[0] = 0.
+// tile_scan_kernel: per file and moment, turns the tile totals into exclusive
+// tile bases (one wave per moment).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void scan_kernel(const FileDesc *__restrict__ files, int fileBegin,
-                                                    double *__restrict__ prefix)
+__global__ __launch_bounds__(256) void tile_scan_kernel(const FileDesc *__restrict__ files, int fileBegin,
+                                                        double *__restrict__ tbase)
 {
-    __shared__ double wsum[16];
-    const FileDesc fd = files[fileBegin + blockIdx.y];
-    const long long n = fd.frames;
-    double *p = prefix + fd.prefix_off + (long long)blockIdx.x * (n + 1);
-    const int tid = threadIdx.x;
-    const long long per = (n + 1023) / 1024;
-    const long long b = 1 + (long long)tid * per;
-    const long long e = std::min(n + 1, b + per);
-    double local = 0.0;
-    for (long long i = b; i < e; i++) local += p[i];
-    // inclusive scan of `local` across the wave, then across the 16 waves
-    double inc = local;
+    const FileDesc fd = files[fileBegin + blockIdx.x];
+    const int q = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double *p = tbase + fd.tbase_off + (long long)q * fd.nptiles;
+    double carry = 0.0;
+    for (long long i0 = 0; i0 < fd.nptiles; i0 += 64) {
+        const long long i = i0 + lane;
+        const double v = i < fd.nptiles ? p[i] : 0.0;
+        double inc = v;
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const double up = __shfl_up(inc, off, 64);
-        if ((tid & 63) >= off) inc += up;
+        for (int off = 1; off < 64; off <<= 1) {
+            const double up = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += up;
+        }
+        if (i < fd.nptiles) p[i] = carry + inc - v;
+        carry += __shfl(inc, 63, 64);
     }
-    if ((tid & 63) == 63) wsum[tid >> 6] = inc;
-    __syncthreads();
-    double base = 0.0;
-    for (int wv = 0; wv < (tid >> 6); wv++) base += wsum[wv];
-    double run = base + inc - local;  // exclusive prefix of this thread
-    for (long long i = b; i < e; i++) {
-        run += p[i];
-        p[i] = run;
-    }
-    if (tid == 0) p[0] = 0.0;
 }
 
 // ---------------------------------------------------------------------------
 // corr_kernel
 //
-// Workgroup = 4 waves, one tile of 1024 consecutive windows of one file.  Lane t
+// Workgroup = 8 waves, one tile of 1024 consecutive windows of one file.  Lane t
 // owns windows o0 + 16t .. o0 + 16t + 15 (16 fp64 accumulators).  A "step" is 16
 // consecutive lags: with x[0..31) the 31 frames starting at the lane's first
 // window + lag, acc[r] += a'[lag + q] * x[q + r] for q, r in 0..15, i.e. 256 FMAs
 // for 16 newly read frames and 16 target values.  The target values are
 // wave-uniform (scalar loads feeding the FMA's SGPR operand); the frames come
 // from an LDS image of the planar channel block in chunk-major order, so that
-// the 64 lanes read 64 consecutive doubles per ds_read_b64.  The 4 waves split
-// the lag steps of each (channel, block) phase; partial sums meet in LDS at the
-// end.  Staging of the next phase's block (global -> registers -> LDS) is
-// issued before and retired after the FMA work of the current phase.
+// the 64 lanes read 64 consecutive doubles per ds_read_b64.  The 8 waves split
+// the lag steps of each (channel, block) phase; their partial sums are added in
+// wave order into a small LDS array (fixed order: results are reproducible).
+// Staging of the next phase's block (global -> registers -> LDS) is issued
+// before and retired after the FMA work of the current phase.
+// Two workgroups per CU = 4 waves per SIMD: 2 x (64 KiB staging + 16 KiB sums).
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void load_chunk(double (&x)[kR], const double *p)
 {
@@ -230,8 +292,17 @@ __device__ __forceinline__ void fma_step(double (&acc)[kR], const double *__rest
     }
 }
 
+// Prefix sums of the per-frame moments: P(q, i) = sum over frames < i.
 struct Epilogue {
-    const double *pt1, *pt2, *ps1, *ps2;
+    const double *pre;    // 4 arrays of `frames` in-tile inclusive sums
+    const double *tbase;  // 4 arrays of `nptiles` tile bases
+    long long frames, nptiles;
+    int tileShift;        // log2(frames per prep tile)
+    __device__ __forceinline__ double P(int q, long long i) const
+    {
+        if (i == 0) return 0.0;
+        return pre[q * frames + (i - 1)] + tbase[q * nptiles + ((i - 1) >> tileShift)];
+    }
 };
 
 __device__ __forceinline__ void window_result(const CorrParams &cp, const Epilogue &ep, long long o,
@@ -239,7 +310,7 @@ __device__ __forceinline__ void window_result(const CorrParams &cp, const Epilog
 {
     const double nT = (double)cp.L;
     const double nS = (double)cp.L * (double)(cp.numCh - 1);
-    const double dmT = (ep.pt1[o + cp.L] - ep.pt1[o]) / nT;  // window mean - kT
+    const double dmT = (ep.P(0, o + cp.L) - ep.P(0, o)) / nT;  // window mean - kT
     const double avgD = cp.kT + dmT;
     const float avgF = (float)avgD;  // MathUtil.avg returns Float
     const double lnAvgB = log((double)avgF);
@@ -248,15 +319,15 @@ __device__ __forceinline__ void window_result(const CorrParams &cp, const Epilog
     if (boost <= cp.maxBoost) {
         float temporal = 0.0f, spectral = 0.0f;
         if (cp.w > 0.0f) {
-            double var = (ep.pt2[o + cp.L] - ep.pt2[o]) / nT - dmT * dmT;
+            double var = (ep.P(1, o + cp.L) - ep.P(1, o)) / nT - dmT * dmT;
             if (var < 0.0) var = 0.0;
             const double bStd = sqrt(var);
             const double cross = crossT - dmT * cp.sumAT;
             temporal = (float)(cross / (cp.aStdT * bStd * nT));
         }
         if (cp.w < 1.0f) {
-            const double dmS = (ep.ps1[o + cp.L] - ep.ps1[o]) / nS;
-            double var = (ep.ps2[o + cp.L] - ep.ps2[o]) / nS - dmS * dmS;
+            const double dmS = (ep.P(2, o + cp.L) - ep.P(2, o)) / nS;
+            double var = (ep.P(3, o + cp.L) - ep.P(3, o)) / nS - dmS * dmS;
             if (var < 0.0) var = 0.0;
             const double bStd = sqrt(var);
             const double cross = crossS - dmS * cp.sumAS;
@@ -268,17 +339,39 @@ __device__ __forceinline__ void window_result(const CorrParams &cp, const Epilog
     boostOut = boost;
 }
 
-constexpr int kStageIters = (kR * kMT) / (kWaves * 64 * 2);  // double2 copies per thread per block
+constexpr int kThreads = kWaves * 64;
+constexpr int kStageCols = 256;                           // columns one staging pass covers (>= kMT)
+constexpr int kStageIters = (kR * kStageCols) / (kThreads * 2);  // double2 copies per thread per block
+static_assert(kStageCols >= kMT && kMT % 2 == 0, "staging pass must cover a whole LDS row");
+constexpr int kStageDoubles = 2 * kR * kMT;               // two staging buffers
+constexpr int kRedDoubles = kR * 64;                      // one sum array (16 windows x 64 lanes)
+constexpr size_t kCorrLdsBytes = (size_t)(kStageDoubles + 2 * kRedDoubles) * sizeof(double);
 
-__global__ __launch_bounds__(kWaves * 64, 2) void corr_kernel(const FileDesc *__restrict__ files,
-                                                              const TileDesc *__restrict__ tiles,
-                                                              const double *__restrict__ planar,
-                                                              const double *__restrict__ prefix,
-                                                              const double *__restrict__ aprime, CorrParams cp,
-                                                              float *__restrict__ simOut,
-                                                              float *__restrict__ boostOut)
+// Adds every wave's 16 partial sums into red[r][lane], wave 0 first.
+__device__ __forceinline__ void reduce_waves(double *red, const double (&acc)[kR], int wave, int lane)
 {
-    extern __shared__ __attribute__((aligned(16))) double lds[];  // 2 x [kR][kMT]
+    for (int wv = 0; wv < kWaves; wv++) {
+        if (wave == wv) {
+#pragma unroll
+            for (int r = 0; r < kR; r++) {
+                const double prev = wv == 0 ? 0.0 : red[r * 64 + lane];
+                red[r * 64 + lane] = prev + acc[r];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(kThreads, 4) void corr_kernel(const FileDesc *__restrict__ files,
+                                                           const TileDesc *__restrict__ tiles,
+                                                           const double *__restrict__ planar,
+                                                           const double *__restrict__ prefix,
+                                                           const double *__restrict__ tbase,
+                                                           const double *__restrict__ aprime, CorrParams cp,
+                                                           float *__restrict__ simOut,
+                                                           float *__restrict__ boostOut)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];  // 2 x [kR][kMT] + 2 x [kR][64]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -288,18 +381,17 @@ __global__ __launch_bounds__(kWaves * 64, 2) void corr_kernel(const FileDesc *__
     const double *fplanar = planar + fd.planar_off;
     const int Lpad = cp.S * kR;
     const int nPh = cp.numCh * cp.nb;
+    double *redS = lds + kStageDoubles;
+    double *redT = redS + kRedDoubles;
 
-    double acc[kR], accT[kR];
+    double acc[kR];
 #pragma unroll
-    for (int r = 0; r < kR; r++) {
-        acc[r] = 0.0;
-        accT[r] = 0.0;
-    }
+    for (int r = 0; r < kR; r++) acc[r] = 0.0;
 
     // staging geometry: thread copies (row = it*rowsPerIt + tid/128, cols 2*(tid%128), +1)
-    constexpr int rowsPerIt = (kWaves * 64) / (kMT / 2);
-    const int srow = tid / (kMT / 2);
-    const int scol = 2 * (tid % (kMT / 2));
+    constexpr int rowsPerIt = kThreads / (kStageCols / 2);
+    const int srow = tid / (kStageCols / 2);
+    const int scol = 2 * (tid % (kStageCols / 2));
     double2 st[kStageIters];
 
     auto stage_load = [&](int ph) {
@@ -320,7 +412,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void corr_kernel(const FileDesc *__
 #pragma unroll
         for (int it = 0; it < kStageIters; it++) {
             const int row = it * rowsPerIt + srow;
-            *reinterpret_cast<double2 *>(dst + row * kMT) = st[it];
+            if (scol < kMT) *reinterpret_cast<double2 *>(dst + row * kMT) = st[it];
         }
     };
 
@@ -340,74 +432,56 @@ __global__ __launch_bounds__(kWaves * 64, 2) void corr_kernel(const FileDesc *__
         const int n = se - sb;
         const double *a = aprime + (long long)c * Lpad + (long long)(s0 + sb) * kR;
         const double *xp = lds + (ph & 1) * (kR * kMT) + lane + sb;
+        // A second, opaque copy of the pointer keeps the compiler from pairing the
+        // loads of adjacent chunks into ds_read2_b64 (half the LDS rate of
+        // ds_read_b64, and its narrow offset field costs an address add per row).
+        const double *xq = xp + 1;
+        asm volatile("" : "+v"(xq));
 
         double xa[kR], xb[kR];
         load_chunk(xa, xp);
         int s = 0;
         for (; s + 2 <= n; s += 2) {
-            load_chunk(xb, xp + s + 1);
+            load_chunk(xb, xq + s);
             fma_step(acc, a + s * kR, xa, xb);
             load_chunk(xa, xp + s + 2);
             fma_step(acc, a + (s + 1) * kR, xb, xa);
         }
         if (s < n) {
-            load_chunk(xb, xp + s + 1);
+            load_chunk(xb, xq + s);
             fma_step(acc, a + s * kR, xa, xb);
         }
 
-        if (c == 0 && kb == cp.nb - 1) {
-#pragma unroll
-            for (int r = 0; r < kR; r++) {
-                accT[r] = acc[r];
-                acc[r] = 0.0;
-            }
-        }
         if (ph + 1 < nPh) stage_store((ph + 1) & 1);
         __syncthreads();
-    }
-
-    // cross-wave reduction through LDS: red[part][wave][r][lane]
-    double *redS = lds;
-    double *redT = lds + kWaves * kR * 64;
+        if (c == 0 && kb == cp.nb - 1) {  // loudness channel done: its sums go to redT
+            reduce_waves(redT, acc, wave, lane);
 #pragma unroll
-    for (int r = 0; r < kR; r++) {
-        redS[(wave * kR + r) * 64 + lane] = acc[r];
-        redT[(wave * kR + r) * 64 + lane] = accT[r];
+            for (int r = 0; r < kR; r++) acc[r] = 0.0;
+        }
     }
-    __syncthreads();
+    reduce_waves(redS, acc, wave, lane);
 
     Epilogue ep;
-    const long long n1 = fd.frames + 1;
-    ep.pt1 = prefix + fd.prefix_off;
-    ep.pt2 = ep.pt1 + n1;
-    ep.ps1 = ep.pt2 + n1;
-    ep.ps2 = ep.ps1 + n1;
+    ep.pre = prefix + fd.prefix_off;
+    ep.tbase = tbase + fd.tbase_off;
+    ep.frames = fd.frames;
+    ep.nptiles = fd.nptiles;
+    ep.tileShift = cp.prepTileShift;
 
-    // thread handles lane l = tid % 64, r = 4*(tid/64) .. +3  -> 4 consecutive windows
+    // thread handles lane l = tid % 64 and r = 2*(tid/64), +1  -> 2 consecutive windows
+    constexpr int perThread = kR / kWaves;
     const int g = tid >> 6;
-    float simv[4], boostv[4];
-    const long long oBase = (long long)td.o0 + (long long)lane * kR + 4 * g;
+    const long long oBase = (long long)td.o0 + (long long)lane * kR + perThread * g;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int r = 4 * g + k;
-        double cs = 0.0, ct = 0.0;
-#pragma unroll
-        for (int wv = 0; wv < kWaves; wv++) {
-            cs += redS[(wv * kR + r) * 64 + lane];
-            ct += redT[(wv * kR + r) * 64 + lane];
-        }
+    for (int k = 0; k < perThread; k++) {
+        const int r = perThread * g + k;
         const long long o = oBase + k;
-        simv[k] = 0.0f;
-        boostv[k] = 0.0f;
-        if (o < fd.num_windows) window_result(cp, ep, o, ct, cs, simv[k], boostv[k]);
-    }
-    float *so = simOut + fd.win_off + oBase;
-    float *bo = boostOut + fd.win_off + oBase;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        if (oBase + k < fd.num_windows) {
-            so[k] = simv[k];
-            bo[k] = boostv[k];
+        if (o < fd.num_windows) {
+            float sim, boost;
+            window_result(cp, ep, o, redT[r * 64 + lane], redS[r * 64 + lane], sim, boost);
+            simOut[fd.win_off + o] = sim;
+            boostOut[fd.win_off + o] = boost;
         }
     }
 }
@@ -466,7 +540,10 @@ int build_layout(sgz_context *ctx)
     ctx->tile_begin.assign(nf + 1, 0);
     ctx->ptile_begin.assign(nf + 1, 0);
     ctx->prep_cb = pick_prep_cb(ctx->numCh);
-    long long planar = 0, prefix = 0, wins = 0;
+    long long planar = 0, prefix = 0, wins = 0, tb = 0;
+    const long long prepTileFrames = (long long)ctx->prep_cb * kR;
+    ctx->cp.prepTileShift = 0;
+    while ((1ll << ctx->cp.prepTileShift) < prepTileFrames) ctx->cp.prepTileShift++;
     for (int f = 0; f < nf; f++) {
         FileDesc &fd = ctx->h_files[f];
         fd.raw = ctx->files[f].d_raw;
@@ -482,10 +559,11 @@ int build_layout(sgz_context *ctx)
         fd.prefix_off = prefix;
         fd.win_off = wins;
         planar += (long long)ctx->numCh * kR * M;
-        prefix += 4 * (fd.frames + 1);
+        prefix += 4 * fd.frames;
+        fd.nptiles = (fd.frames + prepTileFrames - 1) / prepTileFrames;
+        fd.tbase_off = tb;
+        tb += 4 * fd.nptiles;
         wins += fd.num_windows;
-        // keep every file's window block 16-byte aligned for the float4-wide tail of a tile
-        wins = (wins + 3) & ~3ll;
         ctx->tile_begin[f] = (int)ctx->h_tiles.size();
         for (long long t = 0; t < ntiles; t++) ctx->h_tiles.push_back(TileDesc{f, (int)(t * kTileW)});
         ctx->ptile_begin[f] = (int)ctx->h_ptiles.size();
@@ -503,6 +581,7 @@ int build_layout(sgz_context *ctx)
     if ((rc = ensure(ctx, ctx->d_ptiles, ctx->d_ptiles_cap, ctx->h_ptiles.size()))) return rc;
     if ((rc = ensure(ctx, ctx->d_planar, ctx->planar_cap, (size_t)planar))) return rc;
     if ((rc = ensure(ctx, ctx->d_prefix, ctx->prefix_cap, (size_t)prefix))) return rc;
+    if ((rc = ensure(ctx, ctx->d_tbase, ctx->tbase_cap, (size_t)tb))) return rc;
     if ((rc = ensure(ctx, ctx->d_sim, ctx->dense_cap, (size_t)wins))) return rc;
     if ((rc = ensure(ctx, ctx->d_boost, ctx->boost_cap, (size_t)wins))) return rc;
     // the three tables are consumed by kernels queued later on ctx->stream
@@ -515,6 +594,8 @@ int build_layout(sgz_context *ctx)
         SGZ_HIP(ctx, hipMemcpyAsync(ctx->d_ptiles, ctx->h_ptiles.data(), sizeof(PrepTile) * ctx->h_ptiles.size(),
                                     hipMemcpyHostToDevice, ctx->stream));
     SGZ_HIP(ctx, hipStreamSynchronize(ctx->stream));  // host vectors may be rebuilt afterwards
+    for (auto &r : ctx->runs) ctx->event_pool.push_back(r.done);
+    ctx->runs.clear();
     ctx->layout_dirty = false;
     return SGZ_OK;
 }
@@ -763,37 +844,86 @@ int sgz_corr_run(sgz_context *ctx, int file_begin, int file_end)
     const int cb = ctx->prep_cb;
     const size_t prepLds = (size_t)ctx->numCh * (kR * (cb + 1) + 1) * sizeof(float);
     hipLaunchKernelGGL(prep_kernel, dim3(pt1 - pt0), dim3(256), prepLds, ctx->stream, ctx->d_files,
-                       ctx->d_ptiles + pt0, ctx->d_planar, ctx->d_prefix, ctx->norm, ctx->numCh, cb, ctx->cp.kT,
+                       ctx->d_ptiles + pt0, ctx->d_planar, ctx->d_prefix, ctx->d_tbase, ctx->norm, ctx->numCh, cb, ctx->cp.kT,
                        ctx->cp.kS);
     SGZ_HIP(ctx, hipGetLastError());
-    hipLaunchKernelGGL(scan_kernel, dim3(4, file_end - file_begin), dim3(1024), 0, ctx->stream, ctx->d_files,
-                       file_begin, ctx->d_prefix);
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(file_end - file_begin), dim3(256), 0, ctx->stream, ctx->d_files,
+                       file_begin, ctx->d_tbase);
     SGZ_HIP(ctx, hipGetLastError());
-    const size_t corrLds = 2 * (size_t)kR * kMT * sizeof(double);
-    static_assert(2 * kR * kMT >= 2 * kWaves * kR * 64, "reduction scratch must fit the staging buffers");
+    const size_t corrLds = kCorrLdsBytes;
+    if (getenv("SGZ_DEBUG")) {
+        int nb = -1;
+        hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, corr_kernel, kThreads, corrLds);
+        fprintf(stderr, "[sgz] corr_kernel: %d tiles, lds %zu B, max active blocks/CU %d (%s)\n", t1 - t0, corrLds,
+                nb, hipGetErrorString(oe));
+    }
     SGZ_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    hipLaunchKernelGGL(corr_kernel, dim3(t1 - t0), dim3(kWaves * 64), corrLds, ctx->stream, ctx->d_files,
-                       ctx->d_tiles + t0, ctx->d_planar, ctx->d_prefix, ctx->d_aprime, ctx->cp, ctx->d_sim,
+    hipLaunchKernelGGL(corr_kernel, dim3(t1 - t0), dim3(kThreads), corrLds, ctx->stream, ctx->d_files,
+                       ctx->d_tiles + t0, ctx->d_planar, ctx->d_prefix, ctx->d_tbase, ctx->d_aprime, ctx->cp, ctx->d_sim,
                        ctx->d_boost);
     SGZ_HIP(ctx, hipGetLastError());
     SGZ_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     ctx->ev_valid = true;
+    // completion marker of this run, so that reading results of an earlier run
+    // does not have to wait for later ones
+    {
+        sgz_context::Run run;
+        run.fb = file_begin;
+        run.fe = file_end;
+        if (!ctx->event_pool.empty()) {
+            run.done = ctx->event_pool.back();
+            ctx->event_pool.pop_back();
+        } else {
+            SGZ_HIP(ctx, hipEventCreateWithFlags(&run.done, hipEventDisableTiming));
+        }
+        SGZ_HIP(ctx, hipEventRecord(run.done, ctx->stream));
+        // a newer run over the same files supersedes older markers
+        for (size_t i = 0; i < ctx->runs.size();) {
+            if (ctx->runs[i].fb >= file_begin && ctx->runs[i].fe <= file_end) {
+                ctx->event_pool.push_back(ctx->runs[i].done);
+                ctx->runs.erase(ctx->runs.begin() + (std::ptrdiff_t)i);
+            } else {
+                i++;
+            }
+        }
+        ctx->runs.push_back(run);
+    }
+    return SGZ_OK;
+}
+
+int sgz_corr_read_dense_range(sgz_context *ctx, int file_begin, int file_end, float *sim_out, float *boost_out)
+{
+    if (!ctx) return SGZ_E_ARG;
+    if (ctx->layout_dirty || !ctx->have_target) return ctx->fail(SGZ_E_STATE, "no correlation results");
+    const int nf = (int)ctx->files.size();
+    if (file_begin < 0 || file_end > nf || file_begin > file_end) return ctx->fail(SGZ_E_ARG, "bad file range");
+    if (file_begin == file_end) return SGZ_OK;
+    SGZ_HIP(ctx, hipSetDevice(ctx->device));
+    // wait (on the copy stream only) for the runs that produced these files
+    bool covered = false;
+    for (const auto &run : ctx->runs) {
+        if (run.fb < file_end && run.fe > file_begin) {
+            SGZ_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, run.done, 0));
+            covered = true;
+        }
+    }
+    if (!covered) return ctx->fail(SGZ_E_STATE, "sgz_corr_run has not covered these files");
+    const long long w0 = ctx->h_files[file_begin].win_off;
+    const long long w1 = ctx->h_files[file_end - 1].win_off + ctx->h_files[file_end - 1].num_windows;
+    const size_t bytes = sizeof(float) * (size_t)(w1 - w0);
+    if (bytes && sim_out)
+        SGZ_HIP(ctx, hipMemcpyAsync(sim_out, ctx->d_sim + w0, bytes, hipMemcpyDeviceToHost, ctx->copy_stream));
+    if (bytes && boost_out)
+        SGZ_HIP(ctx, hipMemcpyAsync(boost_out, ctx->d_boost + w0, bytes, hipMemcpyDeviceToHost, ctx->copy_stream));
+    SGZ_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
     return SGZ_OK;
 }
 
 int sgz_corr_read_dense(sgz_context *ctx, int file, float *sim_out, float *boost_out)
 {
     if (!ctx) return SGZ_E_ARG;
-    if (ctx->layout_dirty || !ctx->have_target) return ctx->fail(SGZ_E_STATE, "no correlation results");
     if (file < 0 || file >= (int)ctx->files.size()) return ctx->fail(SGZ_E_ARG, "bad file index");
-    SGZ_HIP(ctx, hipSetDevice(ctx->device));
-    const FileDesc &fd = ctx->h_files[file];
-    SGZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const size_t bytes = sizeof(float) * (size_t)fd.num_windows;
-    if (bytes && sim_out) SGZ_HIP(ctx, hipMemcpy(sim_out, ctx->d_sim + fd.win_off, bytes, hipMemcpyDeviceToHost));
-    if (bytes && boost_out)
-        SGZ_HIP(ctx, hipMemcpy(boost_out, ctx->d_boost + fd.win_off, bytes, hipMemcpyDeviceToHost));
-    return SGZ_OK;
+    return sgz_corr_read_dense_range(ctx, file, file + 1, sim_out, boost_out);
 }
 
 int sgz_corr_compact_device(sgz_context *ctx, int file_begin, int file_end, float threshold,
@@ -824,16 +954,26 @@ int sgz_corr_compact(sgz_context *ctx, int file_begin, int file_end, float thres
     if (!count || capacity < 0 || (capacity > 0 && !out)) return ctx->fail(SGZ_E_ARG, "bad output buffers");
     SGZ_HIP(ctx, hipSetDevice(ctx->device));
     int rc;
-    if (!ctx->d_count) SGZ_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_count), sizeof(unsigned long long)));
-    if ((rc = ensure(ctx, ctx->d_cand, ctx->cand_cap, (size_t)capacity))) return rc;
-    if ((rc = sgz_corr_compact_device(ctx, file_begin, file_end, threshold, ctx->d_cand, capacity, ctx->d_count)))
+    // device buffer = [one record-sized header holding the count][capacity records]
+    if ((rc = ensure(ctx, ctx->d_cand, ctx->cand_cap, (size_t)capacity + 1))) return rc;
+    unsigned long long *d_count = reinterpret_cast<unsigned long long *>(ctx->d_cand);
+    if ((rc = sgz_corr_compact_device(ctx, file_begin, file_end, threshold, ctx->d_cand + 1, capacity, d_count)))
         return rc;
-    unsigned long long n = 0;
-    SGZ_HIP(ctx, hipMemcpyAsync(&n, ctx->d_count, sizeof n, hipMemcpyDeviceToHost, ctx->stream));
+    // first transfer: header + as many records as usually suffice
+    const size_t first = (size_t)std::min<int64_t>(capacity, 1023);
+    ctx->h_cand.resize(first + 1);
+    SGZ_HIP(ctx, hipMemcpyAsync(ctx->h_cand.data(), ctx->d_cand, sizeof(sgz_candidate) * (first + 1),
+                                hipMemcpyDeviceToHost, ctx->stream));
     SGZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    unsigned long long n = 0;
+    std::memcpy(&n, ctx->h_cand.data(), sizeof n);
     *count = (int64_t)n;
     const size_t got = (size_t)std::min<unsigned long long>(n, (unsigned long long)capacity);
-    if (got) SGZ_HIP(ctx, hipMemcpy(out, ctx->d_cand, sizeof(sgz_candidate) * got, hipMemcpyDeviceToHost));
+    const size_t inFirst = std::min(got, first);
+    if (inFirst) std::memcpy(out, ctx->h_cand.data() + 1, sizeof(sgz_candidate) * inFirst);
+    if (got > first)
+        SGZ_HIP(ctx, hipMemcpy(out + first, ctx->d_cand + 1 + first, sizeof(sgz_candidate) * (got - first),
+                               hipMemcpyDeviceToHost));
     std::sort(out, out + got, [](const sgz_candidate &a, const sgz_candidate &b) {
         return a.file != b.file ? a.file < b.file : a.offset < b.offset;
     });

@@ -14,8 +14,8 @@ namespace sgz {
 // ---- geometry of the correlation kernel ------------------------------------
 constexpr int kR = 16;             // windows per lane == lags per step == frames per chunk
 constexpr int kTileW = 64 * kR;    // windows per workgroup tile
-constexpr int kWaves = 4;          // waves per workgroup; they split the lag range
-constexpr int kMT = 256;           // LDS row stride (chunks) of one staged channel block
+constexpr int kWaves = 8;          // waves per workgroup; they split the lag range
+constexpr int kMT = 240;           // LDS row stride (chunks) of one staged channel block
 constexpr int kSBMax = kMT - 64;   // most lag steps one staged block can serve
 
 // One database file as the kernels see it.
@@ -24,7 +24,9 @@ struct FileDesc {
     long long frames;
     long long M;             // chunks per planar row (padded)
     long long planar_off;    // offset in doubles into the planar buffer, layout [numCh][kR][M]
-    long long prefix_off;    // offset in doubles into the prefix buffer, 4 arrays of frames+1
+    long long prefix_off;    // offset in doubles into the prefix buffer, 4 arrays of `frames` in-tile sums
+    long long tbase_off;     // offset in doubles into the tile-base buffer, 4 arrays of nptiles
+    long long nptiles;       // prep tiles that hold frames of this file
     long long win_off;       // offset of this file's windows in the dense sim / boost arrays
     long long num_windows;
 };
@@ -51,6 +53,7 @@ struct CorrParams {
     int S;        // lag steps (even), S * kR >= L
     int nb;       // staged blocks per channel
     int SB;       // steps per staged block (even, <= kSBMax)
+    int prepTileShift;  // log2(frames per prep tile)
     double kT, kS;            // centring constants of the planar data
     double aStdT, aStdS;      // target std-devs
     double sumAT, sumAS;      // sum of the centred target (rounding residue)
@@ -101,13 +104,24 @@ struct sgz_context {
     size_t planar_cap = 0;
     double *d_prefix = nullptr;
     size_t prefix_cap = 0;
+    double *d_tbase = nullptr;
+    size_t tbase_cap = 0;
     float *d_sim = nullptr;
     float *d_boost = nullptr;
     size_t dense_cap = 0, boost_cap = 0;
 
-    unsigned long long *d_count = nullptr;   // compaction counter
-    sgz_candidate *d_cand = nullptr;
+    sgz_candidate *d_cand = nullptr;         // [count header][records]
     size_t cand_cap = 0;
+    std::vector<sgz_candidate> h_cand;
+
+    // completion markers of the sgz_corr_run calls whose results are still current
+    struct Run {
+        int fb, fe;
+        hipEvent_t done;
+    };
+    std::vector<Run> runs;
+    std::vector<hipEvent_t> event_pool;
+    hipStream_t copy_stream = nullptr;       // device-to-host result copies
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;

@@ -116,6 +116,19 @@ class Context:
         self._check(lib.sgz_corr_read_dense(self._h, file, N.ptr(sim), N.ptr(boost)))
         return sim, boost
 
+    def corr_read_dense_range(self, file_begin: int, file_end: int) -> list[tuple[np.ndarray, np.ndarray]]:
+        """(sim, boost) of every file in [file_begin, file_end), fetched with one pair of copies."""
+        counts = [max(0, self.corr_num_windows(f)) for f in range(file_begin, file_end)]
+        total = int(sum(counts))
+        sim = np.empty(total, dtype=np.float32)
+        boost = np.empty(total, dtype=np.float32)
+        self._check(lib.sgz_corr_read_dense_range(self._h, file_begin, file_end, N.ptr(sim), N.ptr(boost)))
+        out, pos = [], 0
+        for n in counts:
+            out.append((sim[pos:pos + n], boost[pos:pos + n]))
+            pos += n
+        return out
+
     def corr_compact(self, file_begin: int, file_end: int, threshold: float, capacity: int) -> np.ndarray:
         """Candidates with sim > threshold, sorted by (file, offset); raises on overflow."""
         out = np.empty(max(capacity, 1), dtype=N.CANDIDATE_DTYPE)

@@ -39,11 +39,14 @@ class SearchParams:
 
 def _feed_dense_head(ctx: Context, sel: Selector, files: Sequence[int], global_ids: Sequence[int]) -> int:
     """Feeds files densely, in order, until the selector is full. Returns how many were fed."""
+    files = list(files)
+    if not files:
+        return 0
+    dense = ctx.corr_read_dense_range(files[0], files[-1] + 1)  # `files` is a consecutive range
     fed = 0
-    for local, gid in zip(files, global_ids):
+    for (sim, boost), gid in zip(dense, global_ids):
         if sel.is_full:
             break
-        sim, boost = ctx.corr_read_dense(local)
         sel.feed_dense(gid, sim, boost)
         fed += 1
     return fed
