@@ -38,18 +38,15 @@ class SearchParams:
 
 
 def _feed_dense_head(ctx: Context, sel: Selector, files: Sequence[int], global_ids: Sequence[int]) -> int:
-    """Feeds files densely, in order, until the selector is full. Returns how many were fed."""
+    """Feeds all given files densely, in order (dense feeding is exact whether or
+    not the set is already full). Returns how many were fed."""
     files = list(files)
     if not files:
         return 0
     dense = ctx.corr_read_dense_range(files[0], files[-1] + 1)  # `files` is a consecutive range
-    fed = 0
     for (sim, boost), gid in zip(dense, global_ids):
-        if sel.is_full:
-            break
         sel.feed_dense(gid, sim, boost)
-        fed += 1
-    return fed
+    return len(files)
 
 
 def search(ctx: Context, p: SearchParams) -> list[N.Match]:

@@ -1,0 +1,85 @@
+"""world_size-2 gloo test of the sharded search (runs on CPU).
+
+The GPU part of a rank (dense similarities, compaction) is stood in for by the
+oracle's dense arrays; what is exercised is the product's distributed logic:
+file sharding, head replay, candidate exchange (the one all-gather) and the
+merged tail replay -- which must reproduce the single-process result exactly.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from common import STEP, O, corr_config, make_plants, norms_default, synth_db, synth_target
+
+
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, case, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from strugatzki_amd import _native as N
+        from strugatzki_amd.engine import Selector, match_tuple
+        from strugatzki_amd.search import exchange_candidates, finish_selection, shard_files
+
+        num_matches, num_per_file, min_spacing, nf, L, sims, boosts = case
+        head = num_matches
+        sel = Selector(num_matches, num_per_file, min_spacing, STEP, L)
+        for g in range(head):  # every rank replays all replicated head files densely
+            sel.feed_dense(g, sims[g], boosts[g])
+        assert sel.is_full
+        thr = np.float32(sel.threshold)
+        cap = 4096
+        rec = np.zeros(cap, dtype=N.CANDIDATE_DTYPE)
+        n = 0
+        for g in shard_files(nf, head, rank, world):  # this rank's slice of the tail
+            idx = np.flatnonzero(sims[g] > thr)
+            rec["file"][n:n + len(idx)] = g
+            rec["offset"][n:n + len(idx)] = idx
+            rec["sim"][n:n + len(idx)] = sims[g][idx]
+            rec["boost"][n:n + len(idx)] = boosts[g][idx]
+            n += len(idx)
+        rec_t = torch.from_numpy(rec.view(np.int32).reshape(cap, 4).copy())
+        cnt_t = torch.tensor([n], dtype=torch.int64)
+        cands = exchange_candidates(rec_t, cnt_t, cap)
+        got = finish_selection(sel, cands)
+        ret[rank] = [match_tuple(m) for m in got]
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("num_matches,num_per_file,min_spacing", [(6, 1, 0), (5, 2, 30 * STEP)])
+def test_two_rank_exchange_reproduces_single_process_result(num_matches, num_per_file, min_spacing):
+    L, ts, nf, frames = 64, 7, 20, 500
+    plants = make_plants(6, L, nf, frames, ts)
+    db = synth_db(nf, frames, plants)
+    tgt = synth_target(ts, L)
+    cfg = corr_config(ts, L, num_matches=num_matches, num_per_file=num_per_file, min_spacing=min_spacing)
+    want, sims, boosts = O.correlation_run(cfg, tgt, norms_default(), db)
+    case = (num_matches, num_per_file, min_spacing, nf, L, sims, boosts)
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), case, ret), nprocs=world, join=True)
+    expect = [O.match_tuple(w) for w in want]
+    assert ret[0] == expect and ret[1] == expect
+
+
+def test_shard_files_partitions_the_tail():
+    from strugatzki_amd.search import shard_files
+    parts = [shard_files(37, 5, r, 4) for r in range(4)]
+    assert sorted(sum(parts, [])) == list(range(5, 37))
+    assert max(map(len, parts)) - min(map(len, parts)) <= 1

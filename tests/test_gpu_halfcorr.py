@@ -1,0 +1,94 @@
+"""GPU parity of FeatureSegmentation / SelfSimilarity (MathUtil.correlateHalf) against the oracle."""
+import numpy as np
+import pytest
+
+from common import NUM_CH, SEED, STEP, O, norms_default
+
+pytestmark = pytest.mark.gpu
+
+
+def _frames(n, seed_file=3):
+    a = O.synth_file(SEED, seed_file, n, NUM_CH)
+    b = O.synth_file(SEED, seed_file + 1, n, NUM_CH) * np.float32(0.6)
+    k = n // 2
+    return np.concatenate([a[:k], b[k:]])
+
+
+@pytest.mark.parametrize("span,corr_len,weight,normalize", [
+    ((None, None), 22050, 0.5, True),
+    ((100 * STEP, 900 * STEP), 22050, 0.5, True),
+    ((None, 700 * STEP), 11000, 0.0, True),
+    ((33 * STEP, None), 5000, 1.0, False),
+    ((None, None), 44100, 0.3, True),
+])
+def test_segmentation_curve_and_breaks(ctx, span, corr_len, weight, normalize):
+    from strugatzki_amd.engine import segm_select
+    frames = _frames(1200)
+    norms = norms_default() if normalize else None
+    cfg = O.SegmConfig(int(span[0] is not None), int(span[1] is not None), span[0] or 0, span[1] or 0, corr_len,
+                       weight, int(normalize), 6, 22050, STEP, NUM_CH - 1)
+    want, dense = O.segmentation_run(cfg, frames, norms)
+    H = O.full_to_feat(corr_len, STEP)
+    a0 = max(0, O.full_to_feat(span[0], STEP)) if span[0] is not None else 0
+    a1 = min(frames.shape[0], O.full_to_feat(span[1], STEP)) if span[1] is not None else frames.shape[0]
+    ctx.db_reset(NUM_CH)
+    ctx.set_norms(norms)
+    got = ctx.segm_curve(frames, a0, a1, H, weight)
+    assert got.shape == dense.shape
+    np.testing.assert_allclose(got, dense, rtol=0, atol=1e-5)
+    assert np.array_equal(got, dense)  # the kernel keeps the reference's summation order
+    br = segm_select(got, a0, H, STEP, 6, 22050)
+    assert [(b.sim, b.pos) for b in br] == [(w.sim, w.pos) for w in want]
+
+
+def test_segmentation_window_longer_than_span_gives_nothing(ctx):
+    frames = _frames(60)
+    ctx.db_reset(NUM_CH)
+    ctx.set_norms(norms_default())
+    assert ctx.segm_curve(frames, 0, 60, 43, 0.5).shape == (0,)
+
+
+@pytest.mark.parametrize("decim,corr_len,warp,ceil,inv", [(1, 4 * STEP, 1.0, 1.0, False), (3, 8 * STEP, 0.5, 0.8, True),
+                                                         (2, 44100, 2.0, 1.0, False)])
+def test_selfsim_matrix_and_image(ctx, decim, corr_len, warp, ceil, inv):
+    frames = _frames(260)
+    norms = norms_default()
+    cfg = O.SelfSimConfig(0, 0, 0, 0, corr_len, decim, 0.5, 0, warp, ceil, int(inv), 1, STEP, NUM_CH - 1)
+    ext, d, af_start, _ = O.selfsim_geometry(cfg, frames.shape[0], frames.shape[0])
+    want_sim, want_img = O.selfsim_run(cfg, frames, None, norms)
+    ctx.db_reset(NUM_CH)
+    ctx.set_norms(norms)
+    H = O.full_to_feat(corr_len, STEP)
+    sim, img = ctx.selfsim(frames, None, af_start, H, d, ext, 0.5, 0, warp, ceil, inv)
+    np.testing.assert_allclose(sim, want_sim, rtol=0, atol=1e-5)
+    assert np.array_equal(sim, sim.T)
+    dpx = np.abs((img & 0xFF).astype(np.int64) - (want_img & 0xFF).astype(np.int64))
+    assert dpx.max() <= 1 and (dpx > 0).mean() < 0.01
+    assert np.array_equal(img & 0xFF, (img >> 8) & 0xFF) and np.array_equal(img & 0xFF, (img >> 16) & 0xFF)
+
+
+def test_cross_file_similarity(ctx):
+    """metaInput2: left windows from file 1, right windows from file 2 (impl/SelfSimilarityImpl.scala:131-141)."""
+    f1, f2 = _frames(200, 3), _frames(180, 9)
+    norms = norms_default()
+    cfg = O.SelfSimConfig(0, 0, 0, 0, 6 * STEP, 2, 0.5, 0, 1.0, 1.0, 0, 1, STEP, NUM_CH - 1)
+    ext, d, af_start, _ = O.selfsim_geometry(cfg, 200, 180)
+    want_sim, _ = O.selfsim_run(cfg, f1, f2, norms, want_img=False)
+    ctx.db_reset(NUM_CH)
+    ctx.set_norms(norms)
+    sim, _ = ctx.selfsim(f1, f2, af_start, 6, d, ext, 0.5, want_img=False)
+    # the reference mirrors the upper triangle (left <= right) into the lower one
+    np.testing.assert_allclose(sim, want_sim, rtol=0, atol=1e-5)
+
+
+def test_selfsim_rejects_bad_arguments(ctx):
+    import strugatzki_amd as S
+    frames = _frames(100)
+    ctx.db_reset(NUM_CH)
+    ctx.set_norms(None)
+    with pytest.raises(S.NativeError):
+        ctx.selfsim(frames, None, 0, 4, 1, 10, 0.5, color_warp=0.0)
+    with pytest.raises(S.NativeError):
+        ctx.selfsim(frames, None, 0, 4, 1, 200, 0.5)  # windows past the end
+    with pytest.raises(S.NativeError):
+        ctx.selfsim(frames, None, 0, 4, 1, 10, 0.5, colors=1)  # psycho-optical palette not implemented
