@@ -198,11 +198,12 @@ SGZ_API int sgz_sel_result(const sgz_selector *sel, sgz_match *out, int capacity
  * [af_start, af_stop - 2*half_win] the correlateHalf similarity of
  * impl/FeatureSegmentationImpl.scala:107-120 (MathUtil.correlateHalf,
  * impl/MathUtil.scala:80-99).  `frames` is host memory (raw interleaved,
- * num_frames x num_channels as set by sgz_db_reset / sgz_set_norms);
- * sim_out receives max(0, af_stop - af_start - 2*half_win + 1) values. */
+ * num_frames x num_channels); `norms` is [num_channels][2] (min, max) or NULL
+ * for no normalisation; sim_out receives
+ * max(0, af_stop - af_start - 2*half_win + 1) values. */
 SGZ_API int sgz_segm_curve(sgz_context *ctx, const float *frames, int64_t num_frames, int num_channels,
-                   int af_start, int af_stop, int half_win, float temporal_weight,
-                   float *sim_out, int64_t *num_out);
+                           const float *norms, int af_start, int af_stop, int half_win,
+                           float temporal_weight, float *sim_out, int64_t *num_out);
 
 /* Break bookkeeping of impl/FeatureSegmentationImpl.scala:55-83,121-125 over a
  * dense novelty curve.  Host code.  Returns the number of breaks written
@@ -215,15 +216,57 @@ SGZ_API int sgz_segm_select(const float *sims, int64_t n, int af_start, int half
 /* The decimated similarity matrix of impl/SelfSimilarityImpl.scala:123-165:
  * entry (x, y) compares the half window of file 1 at frame af_start + x*decim
  * with that of file 2 at af_start + y*decim; img_ext = numCorrs / decim
- * (:81-91).  frames2 may equal frames1.  sim_out (nullable) receives
+ * (:81-91).  frames2 may equal frames1; norms as for sgz_segm_curve.  sim_out (nullable) receives
  * img_ext*img_ext floats, [x][y] with x = left; img_out (nullable) receives
  * the TYPE_INT_RGB raster of :150-155 (gray colour scheme only: colors must be
  * 0).  Both triangles are filled from the upper one, as the reference does. */
 SGZ_API int sgz_selfsim_run(sgz_context *ctx, const float *frames1, int64_t num_frames1,
                     const float *frames2, int64_t num_frames2, int num_channels,
-                    int af_start, int half_win, int decim, int img_ext,
+                    const float *norms, int af_start, int half_win, int decim, int img_ext,
                     float temporal_weight, int colors, float color_warp, float color_ceil,
                     int color_inv, float *sim_out, int32_t *img_out);
+
+/* ---- whole processors from their XML configs (host side) ------------------ */
+
+/* Progress observer: called with a value in [0, 1] between GPU launches; a
+ * return of 0 aborts the run (the reference polls checkAborted() and reports
+ * `progress`, e.g. impl/FeatureCorrelationImpl.scala:164,402). */
+typedef int (*sgz_progress_fn)(double progress, void *user);
+
+/* FeatureCorrelation.run: `config_xml` is a <correlate> document
+ * (FeatureCorrelation.scala:231-244).  Scans the database folder, loads the
+ * feature files, runs the search; *result_xml receives "<matches>" holding one
+ * <match> element per result (FeatureCorrelation.scala:55-63), to be released
+ * with sgz_free_string.  Replaces impl/FeatureCorrelationImpl.body() (:32-412). */
+SGZ_API int sgz_run_correlation_xml(sgz_context *ctx, const char *config_xml, sgz_progress_fn cb, void *user,
+                                    char **result_xml);
+/* FeatureSegmentation.run: <segmentation> in (FeatureSegmentation.scala:179-189),
+ * "<breaks>" of <break> elements out.  Replaces impl/FeatureSegmentationImpl.body(). */
+SGZ_API int sgz_run_segmentation_xml(sgz_context *ctx, const char *config_xml, sgz_progress_fn cb, void *user,
+                                     char **result_xml);
+/* SelfSimilarity.run: <selfsimilarity> in (SelfSimilarity.scala:223-238); writes the
+ * PNG named by <output>.  Replaces impl/SelfSimilarityImpl.body(). */
+SGZ_API int sgz_run_selfsimilarity_xml(sgz_context *ctx, const char *config_xml, sgz_progress_fn cb, void *user);
+/* Text of the last failure of an sgz_run_* / sgz_*_xml / file call on this thread. */
+SGZ_API const char *sgz_host_last_error(void);
+SGZ_API void sgz_free_string(char *s);
+
+/* Parses a config / result document of the given kind ("feature", "correlate",
+ * "match", "segmentation", "break", "selfsimilarity") and prints it again:
+ * X.fromXML(x.toXML) of the reference (StrugatzkiSuite.scala:25-29,53-58,64-68,86-91). */
+SGZ_API int sgz_config_roundtrip_xml(const char *kind, const char *xml, char **out_xml);
+/* The default configuration of a processor as XML (ConfigBuilder defaults,
+ * e.g. FeatureCorrelation.scala:168-206). */
+SGZ_API int sgz_default_config_xml(const char *kind, char **out_xml);
+
+/* Writes interleaved float frames as a 32-bit float AIFF-C, the feature file
+ * format (impl/NonRealtimeProcessor.scala:164-165). */
+SGZ_API int sgz_write_float_aiff(const char *path, const float *frames, int64_t num_frames, int num_channels,
+                                 double sample_rate);
+/* Reads an AIFF / AIFF-C / WAVE file; frames_out may be NULL to query the size
+ * (AudioFile.openRead + read, e.g. impl/FeatureCorrelationImpl.scala:81-89). */
+SGZ_API int sgz_read_audio_file(const char *path, float *frames_out, int64_t capacity_frames,
+                                int64_t *num_frames, int *num_channels, double *sample_rate);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,185 @@
+// strugatzki_amd.hpp -- C++ host-side mirror of the reference's public API for
+// the similarity hot path: the Config types with the reference's field names,
+// defaults and XML element names, the result records, and run() functions that
+// do what the reference's impl.XImpl.body() does -- with the arithmetic on the
+// GPU behind the C ABI of strugatzki_amd.h.
+//
+// Reference (paths relative to src/main/scala/de/sciss/strugatzki/):
+//   FeatureExtraction.scala:112-207   FeatureCorrelation.scala:36-101,168-273
+//   FeatureSegmentation.scala:40-57,134-212   SelfSimilarity.scala:30-56,153-283
+//
+// Where the reference reports errors by exceptions (require -> IllegalArgument-
+// Exception, I/O -> IOException) these functions throw strugatzki::Error carrying
+// the matching SGZ_E_* code.
+#pragma once
+
+#include <cstdint>
+#include <functional>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "strugatzki_amd.h"
+
+namespace strugatzki {
+
+class Error : public std::runtime_error {
+public:
+    Error(int code, const std::string &what) : std::runtime_error(what), code_(code) {}
+    int code() const { return code_; }
+
+private:
+    int code_;
+};
+
+// de.sciss.span.Span.NonVoid: Span(start, stop), Span.from(start), Span.until(stop), Span.all
+struct Span {
+    std::optional<int64_t> start, stop;
+    static Span all() { return {}; }
+    static Span of(int64_t a, int64_t b) { return Span{a, b}; }
+    bool operator==(const Span &o) const { return start == o.start && stop == o.stop; }
+};
+
+// ---- FeatureExtraction.Config ------------------------------------------------
+enum class ChannelsBehavior : int { Mix = 0, First = 1, Last = 2 };
+
+struct FeatureExtractionConfig {
+    std::string audioInput = "input.aif";
+    std::string featureOutput;  // the reference defaults to a fresh temp file
+    std::optional<std::string> metaOutput;
+    int numCoeffs = 13;
+    int fftSize = 1024;
+    int fftOverlap = 2;
+    ChannelsBehavior channelsBehavior = ChannelsBehavior::Mix;
+
+    std::string toXML() const;                                  // <feature>...</feature>
+    static FeatureExtractionConfig fromXML(const std::string &xml);
+    static FeatureExtractionConfig fromXMLFile(const std::string &path);
+    bool operator==(const FeatureExtractionConfig &o) const;
+};
+
+// ---- FeatureCorrelation ------------------------------------------------------
+struct Punch {
+    Span span = Span::of(0, 44100);
+    float temporalWeight = 0.5f;
+    bool operator==(const Punch &o) const { return span == o.span && temporalWeight == o.temporalWeight; }
+};
+
+struct Match {
+    float sim = 0;
+    std::string file;  // audio file of the database entry
+    Span punch;
+    float boostIn = 1, boostOut = 1;
+    std::string toXML() const;  // <match>...</match>
+    static Match fromXML(const std::string &xml);
+    bool operator==(const Match &o) const;
+};
+
+struct FeatureCorrelationConfig {
+    std::string databaseFolder = "database";
+    std::string metaInput = "input_feat.xml";
+    Punch punchIn;
+    std::optional<Punch> punchOut;
+    int64_t minPunch = 22050;
+    int64_t maxPunch = 88200;
+    bool normalize = true;
+    float maxBoost = 8.0f;
+    int numMatches = 1;
+    int numPerFile = 1;
+    int64_t minSpacing = 0;
+
+    std::string toXML() const;  // <correlate>...</correlate>
+    static FeatureCorrelationConfig fromXML(const std::string &xml);
+    bool operator==(const FeatureCorrelationConfig &o) const;
+};
+
+// ---- FeatureSegmentation -----------------------------------------------------
+struct Break {
+    float sim = 0;
+    int64_t pos = 0;
+    std::string toXML() const;  // <break>...</break>
+    static Break fromXML(const std::string &xml);
+    bool operator==(const Break &o) const { return sim == o.sim && pos == o.pos; }
+};
+
+struct FeatureSegmentationConfig {
+    std::string databaseFolder = "database";
+    std::string metaInput = "input_feat.xml";
+    Span span = Span::all();
+    int64_t corrLen = 22050;
+    float temporalWeight = 0.5f;
+    bool normalize = true;
+    int numBreaks = 1;
+    int64_t minSpacing = 22050;
+
+    std::string toXML() const;  // <segmentation>...</segmentation>
+    static FeatureSegmentationConfig fromXML(const std::string &xml);
+    bool operator==(const FeatureSegmentationConfig &o) const;
+};
+
+// ---- SelfSimilarity ----------------------------------------------------------
+enum class ColorScheme : int { GrayScale = 0, PsychoOptical = 1 };  // logical names "gray", "psycho"
+
+struct SelfSimilarityConfig {
+    std::string databaseFolder = "database";
+    std::string metaInput = "input_feat.xml";
+    std::optional<std::string> metaInput2;
+    std::string imageOutput = "output_selfsim.png";
+    Span span = Span::all();
+    int64_t corrLen = 44100;
+    int decimation = 1;
+    float temporalWeight = 0.5f;
+    ColorScheme colors = ColorScheme::PsychoOptical;
+    float colorWarp = 1.0f;
+    float colorCeil = 1.0f;
+    bool colorInv = false;
+    bool normalize = true;
+
+    std::string toXML() const;  // <selfsimilarity>...</selfsimilarity>
+    static SelfSimilarityConfig fromXML(const std::string &xml);
+    bool operator==(const SelfSimilarityConfig &o) const;
+};
+
+// ---- processors ----------------------------------------------------------------
+// Progress in [0, 1]; returning false aborts the run (Processor.Aborted in the
+// reference, polled by checkAborted() -- here between GPU launches).
+using Observer = std::function<bool(double)>;
+
+// Name of the normalisation file inside the database folder (Strugatzki.scala:36).
+constexpr const char *kNormalizeName = "feat_norms.aif";
+
+// impl/FeatureCorrelationImpl.body(): scans the database folder, loads every
+// compatible feature file to the GPU, correlates, selects.  Database entries
+// are visited in lexicographic order of their meta file names (the reference
+// iterates a Set[File], whose order is unspecified).  Matches come back in
+// descending similarity.  punchOut is not supported yet.
+std::vector<Match> runFeatureCorrelation(sgz_context *ctx, const FeatureCorrelationConfig &cfg,
+                                         const Observer &obs = nullptr);
+
+// impl/FeatureSegmentationImpl.body(): breaks in ascending similarity.
+std::vector<Break> runFeatureSegmentation(sgz_context *ctx, const FeatureSegmentationConfig &cfg,
+                                          const Observer &obs = nullptr);
+
+// impl/SelfSimilarityImpl.body(): writes cfg.imageOutput (PNG, 8-bit RGB).  Only
+// ColorScheme::GrayScale is implemented (the psycho-optical palette is a
+// third-party table that is not part of the reference sources).
+void runSelfSimilarity(sgz_context *ctx, const SelfSimilarityConfig &cfg, const Observer &obs = nullptr);
+
+// impl/FeatureExtractionImpl.body(): audio file -> feature AIFF (+ meta XML).
+void runFeatureExtraction(sgz_context *ctx, const FeatureExtractionConfig &cfg, const Observer &obs = nullptr);
+
+// ---- feature / audio files -----------------------------------------------------
+struct AudioData {
+    int numChannels = 0;
+    double sampleRate = 0;
+    int64_t numFrames = 0;
+    std::vector<float> frames;  // interleaved
+};
+// Reads AIFF / AIFF-C (16/24/32-bit PCM, fl32, fl64) and RIFF-WAVE (PCM, float).
+AudioData readAudioFile(const std::string &path);
+// Writes a 32-bit float AIFF-C ("fl32", big endian), the format the reference
+// produces for feature files (impl/NonRealtimeProcessor.scala:164-165).
+void writeFloatAiff(const std::string &path, const AudioData &data);
+
+}  // namespace strugatzki

@@ -91,7 +91,7 @@ SIGNATURES = {
     "sgz_sel_result": (C.c_int, [_vp, C.POINTER(Match), C.c_int]),
     "sgz_segm_curve": (
         C.c_int,
-        [_vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _vp, C.POINTER(C.c_int64)],
+        [_vp, _vp, C.c_int64, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_float, _vp, C.POINTER(C.c_int64)],
     ),
     "sgz_segm_select": (
         C.c_int,
@@ -99,10 +99,24 @@ SIGNATURES = {
     ),
     "sgz_selfsim_run": (
         C.c_int,
-        [_vp, _vp, C.c_int64, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+        [_vp, _vp, C.c_int64, _vp, C.c_int64, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
          C.c_int, C.c_float, C.c_float, C.c_int, _vp, _vp],
     ),
+    "sgz_run_correlation_xml": (C.c_int, [_vp, C.c_char_p, _vp, _vp, C.POINTER(_vp)]),
+    "sgz_run_segmentation_xml": (C.c_int, [_vp, C.c_char_p, _vp, _vp, C.POINTER(_vp)]),
+    "sgz_run_selfsimilarity_xml": (C.c_int, [_vp, C.c_char_p, _vp, _vp]),
+    "sgz_host_last_error": (C.c_char_p, []),
+    "sgz_free_string": (None, [_vp]),
+    "sgz_config_roundtrip_xml": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(_vp)]),
+    "sgz_default_config_xml": (C.c_int, [C.c_char_p, C.POINTER(_vp)]),
+    "sgz_write_float_aiff": (C.c_int, [C.c_char_p, _vp, C.c_int64, C.c_int, C.c_double]),
+    "sgz_read_audio_file": (
+        C.c_int,
+        [C.c_char_p, _vp, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_double)],
+    ),
 }
+
+PROGRESS_FN = C.CFUNCTYPE(C.c_int, C.c_double, C.c_void_p)
 
 
 def _load() -> C.CDLL:

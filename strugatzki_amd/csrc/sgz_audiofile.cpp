@@ -1,0 +1,297 @@
+// Audio / feature file I/O: AIFF, AIFF-C and RIFF-WAVE readers, AIFF-C "fl32"
+// writer.  Feature files are float AIFFs with numCoeffs+1 interleaved channels
+// at the feature rate (reference: impl/NonRealtimeProcessor.scala:164-165; read
+// back at impl/FeatureCorrelationImpl.scala:62-67,81-89,169,195).
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+
+#include "strugatzki_amd.hpp"
+
+namespace strugatzki {
+namespace {
+
+struct Reader {
+    std::vector<unsigned char> d;
+    size_t p = 0;
+    const std::string &path;
+    Reader(const std::string &pth) : path(pth)
+    {
+        std::ifstream f(pth, std::ios::binary);
+        if (!f) throw Error(SGZ_E_IO, "cannot open " + pth);
+        f.seekg(0, std::ios::end);
+        const std::streamoff n = f.tellg();
+        f.seekg(0);
+        d.resize((size_t)n);
+        if (n) f.read(reinterpret_cast<char *>(d.data()), n);
+        if (!f) throw Error(SGZ_E_IO, "cannot read " + pth);
+    }
+    void need(size_t n) const
+    {
+        if (p + n > d.size()) throw Error(SGZ_E_IO, "unexpected end of file in " + path);
+    }
+    uint32_t be32()
+    {
+        need(4);
+        const uint32_t v = (uint32_t)d[p] << 24 | (uint32_t)d[p + 1] << 16 | (uint32_t)d[p + 2] << 8 | d[p + 3];
+        p += 4;
+        return v;
+    }
+    uint16_t be16()
+    {
+        need(2);
+        const uint16_t v = (uint16_t)(d[p] << 8 | d[p + 1]);
+        p += 2;
+        return v;
+    }
+    uint32_t le32()
+    {
+        need(4);
+        const uint32_t v = (uint32_t)d[p + 3] << 24 | (uint32_t)d[p + 2] << 16 | (uint32_t)d[p + 1] << 8 | d[p];
+        p += 4;
+        return v;
+    }
+    uint16_t le16()
+    {
+        need(2);
+        const uint16_t v = (uint16_t)(d[p + 1] << 8 | d[p]);
+        p += 2;
+        return v;
+    }
+    std::string tag()
+    {
+        need(4);
+        std::string t(reinterpret_cast<const char *>(&d[p]), 4);
+        p += 4;
+        return t;
+    }
+};
+
+// 80-bit IEEE 754 extended (big endian) <-> double
+double fromExt80(const unsigned char *b)
+{
+    const int sign = b[0] >> 7;
+    const int exp = ((b[0] & 0x7F) << 8) | b[1];
+    uint64_t mant = 0;
+    for (int i = 0; i < 8; i++) mant = (mant << 8) | b[2 + i];
+    if (exp == 0 && mant == 0) return 0.0;
+    const double v = std::ldexp((double)mant, exp - 16383 - 63);
+    return sign ? -v : v;
+}
+void toExt80(double v, unsigned char *b)
+{
+    std::memset(b, 0, 10);
+    if (v == 0.0) return;
+    int sign = 0;
+    if (v < 0) {
+        sign = 1;
+        v = -v;
+    }
+    int e;
+    const double fr = std::frexp(v, &e);  // v = fr * 2^e, fr in [0.5, 1)
+    const uint64_t mant = (uint64_t)std::ldexp(fr, 64);
+    const int exp = e - 1 + 16383;
+    b[0] = (unsigned char)((sign << 7) | ((exp >> 8) & 0x7F));
+    b[1] = (unsigned char)(exp & 0xFF);
+    for (int i = 0; i < 8; i++) b[2 + i] = (unsigned char)(mant >> (56 - 8 * i));
+}
+
+enum class Fmt { Int, Float32, Float64 };
+
+void decode(const unsigned char *src, size_t count, int bits, Fmt fmt, bool bigEndian, bool wavUnsigned8,
+            float *dst)
+{
+    const int bytes = bits / 8;
+    for (size_t i = 0; i < count; i++) {
+        const unsigned char *s = src + i * (size_t)bytes;
+        unsigned char t[8];
+        for (int k = 0; k < bytes; k++) t[k] = bigEndian ? s[k] : s[bytes - 1 - k];  // t is big endian
+        if (fmt == Fmt::Float32) {
+            const uint32_t u = (uint32_t)t[0] << 24 | (uint32_t)t[1] << 16 | (uint32_t)t[2] << 8 | t[3];
+            float f;
+            std::memcpy(&f, &u, 4);
+            dst[i] = f;
+        } else if (fmt == Fmt::Float64) {
+            uint64_t u = 0;
+            for (int k = 0; k < 8; k++) u = (u << 8) | t[k];
+            double f;
+            std::memcpy(&f, &u, 8);
+            dst[i] = (float)f;
+        } else if (bytes == 1) {
+            dst[i] = wavUnsigned8 ? ((int)s[0] - 128) / 128.0f : (float)(signed char)s[0] / 128.0f;
+        } else {
+            int32_t v = (int32_t)(signed char)t[0];
+            for (int k = 1; k < bytes; k++) v = (int32_t)((uint32_t)v << 8 | t[k]);
+            dst[i] = (float)((double)v / (double)(1ll << (bits - 1)));
+        }
+    }
+}
+
+AudioData readAiff(Reader &r)
+{
+    r.p = 8;
+    const std::string form = r.tag();
+    const bool aifc = form == "AIFC";
+    if (!aifc && form != "AIFF") throw Error(SGZ_E_IO, "not an AIFF file: " + r.path);
+    AudioData a;
+    int bits = 0;
+    Fmt fmt = Fmt::Int;
+    bool big = true, haveComm = false;
+    size_t ssnd = 0, ssndBytes = 0;
+    while (r.p + 8 <= r.d.size()) {
+        const std::string id = r.tag();
+        const uint32_t len = r.be32();
+        const size_t next = r.p + len + (len & 1);
+        if (id == "COMM") {
+            a.numChannels = (int16_t)r.be16();
+            a.numFrames = r.be32();
+            bits = (int16_t)r.be16();
+            r.need(10);
+            a.sampleRate = fromExt80(&r.d[r.p]);
+            r.p += 10;
+            if (aifc) {
+                const std::string comp = r.tag();
+                if (comp == "NONE" || comp == "twos") fmt = Fmt::Int;
+                else if (comp == "sowt") {
+                    fmt = Fmt::Int;
+                    big = false;
+                } else if (comp == "fl32" || comp == "FL32") {
+                    fmt = Fmt::Float32;
+                    bits = 32;
+                } else if (comp == "fl64" || comp == "FL64") {
+                    fmt = Fmt::Float64;
+                    bits = 64;
+                } else
+                    throw Error(SGZ_E_IO, "unsupported AIFF-C compression '" + comp + "' in " + r.path);
+            }
+            haveComm = true;
+        } else if (id == "SSND") {
+            const uint32_t offset = r.be32();
+            r.be32();  // block size
+            ssnd = r.p + offset;
+            ssndBytes = len - 8 - offset;
+        }
+        r.p = next;
+    }
+    if (!haveComm) throw Error(SGZ_E_IO, "AIFF without COMM chunk: " + r.path);
+    if (a.numChannels < 1 || bits < 8 || bits > 64 || bits % 8) throw Error(SGZ_E_IO, "unsupported AIFF layout: " + r.path);
+    const size_t count = (size_t)a.numFrames * a.numChannels;
+    if (count) {
+        if (!ssnd || ssndBytes < count * (size_t)(bits / 8) || ssnd + count * (size_t)(bits / 8) > r.d.size())
+            throw Error(SGZ_E_IO, "AIFF sound data truncated: " + r.path);
+        a.frames.resize(count);
+        decode(&r.d[ssnd], count, bits, fmt, big, false, a.frames.data());
+    }
+    return a;
+}
+
+AudioData readWav(Reader &r)
+{
+    r.p = 8;
+    if (r.tag() != "WAVE") throw Error(SGZ_E_IO, "not a WAVE file: " + r.path);
+    AudioData a;
+    int bits = 0, format = 0;
+    bool haveFmt = false;
+    size_t data = 0, dataBytes = 0;
+    while (r.p + 8 <= r.d.size()) {
+        const std::string id = r.tag();
+        const uint32_t len = r.le32();
+        const size_t next = r.p + len + (len & 1);
+        if (id == "fmt ") {
+            format = r.le16();
+            a.numChannels = r.le16();
+            a.sampleRate = r.le32();
+            r.le32();
+            r.le16();
+            bits = r.le16();
+            if (format == 0xFFFE && len >= 26) {  // WAVE_FORMAT_EXTENSIBLE: sub-format GUID starts with the real tag
+                r.p += 8;
+                format = r.le16();
+            }
+            haveFmt = true;
+        } else if (id == "data") {
+            data = r.p;
+            dataBytes = std::min<size_t>(len, r.d.size() - r.p);
+        }
+        r.p = next;
+    }
+    if (!haveFmt || !data) throw Error(SGZ_E_IO, "WAVE without fmt/data chunk: " + r.path);
+    if ((format != 1 && format != 3) || a.numChannels < 1 || bits % 8 || bits < 8 || bits > 64)
+        throw Error(SGZ_E_IO, "unsupported WAVE format in " + r.path);
+    const size_t fb = (size_t)a.numChannels * (bits / 8);
+    a.numFrames = (int64_t)(dataBytes / fb);
+    const size_t count = (size_t)a.numFrames * a.numChannels;
+    a.frames.resize(count);
+    const Fmt fmt = format == 3 ? (bits == 64 ? Fmt::Float64 : Fmt::Float32) : Fmt::Int;
+    if (count) decode(&r.d[data], count, bits, fmt, false, bits == 8, a.frames.data());
+    return a;
+}
+
+}  // namespace
+
+AudioData readAudioFile(const std::string &path)
+{
+    Reader r(path);
+    if (r.d.size() < 12) throw Error(SGZ_E_IO, "file too short: " + path);
+    const std::string magic(reinterpret_cast<const char *>(r.d.data()), 4);
+    if (magic == "FORM") return readAiff(r);
+    if (magic == "RIFF") return readWav(r);
+    throw Error(SGZ_E_IO, "unknown audio file format: " + path);
+}
+
+void writeFloatAiff(const std::string &path, const AudioData &a)
+{
+    if (a.numChannels < 1 || a.numFrames < 0 || a.frames.size() != (size_t)a.numFrames * a.numChannels)
+        throw Error(SGZ_E_ARG, "inconsistent AudioData");
+    std::vector<unsigned char> o;
+    auto be32 = [&](uint32_t v) {
+        for (int s = 24; s >= 0; s -= 8) o.push_back((unsigned char)(v >> s));
+    };
+    auto be16 = [&](uint16_t v) {
+        o.push_back((unsigned char)(v >> 8));
+        o.push_back((unsigned char)v);
+    };
+    auto tag = [&](const char *t) { o.insert(o.end(), t, t + 4); };
+    const char compName[] = "32-bit floating point";  // pascal string, 21 chars + length byte = 22 (even)
+    const uint32_t commLen = 2 + 4 + 2 + 10 + 4 + 1 + (uint32_t)(sizeof compName - 1);
+    const uint32_t dataBytes = (uint32_t)(a.frames.size() * 4);
+    const uint32_t ssndLen = 8 + dataBytes;
+    tag("FORM");
+    be32(4 + (8 + 4) + (8 + commLen) + (8 + ssndLen));
+    tag("AIFC");
+    tag("FVER");
+    be32(4);
+    be32(0xA2805140u);  // AIFC version 1
+    tag("COMM");
+    be32(commLen);
+    be16((uint16_t)a.numChannels);
+    be32((uint32_t)a.numFrames);
+    be16(32);
+    unsigned char ext[10];
+    toExt80(a.sampleRate, ext);
+    o.insert(o.end(), ext, ext + 10);
+    tag("fl32");
+    o.push_back((unsigned char)(sizeof compName - 1));
+    o.insert(o.end(), compName, compName + sizeof compName - 1);
+    tag("SSND");
+    be32(ssndLen);
+    be32(0);
+    be32(0);
+    const size_t base = o.size();
+    o.resize(base + dataBytes);
+    for (size_t i = 0; i < a.frames.size(); i++) {
+        uint32_t u;
+        std::memcpy(&u, &a.frames[i], 4);
+        o[base + 4 * i] = (unsigned char)(u >> 24);
+        o[base + 4 * i + 1] = (unsigned char)(u >> 16);
+        o[base + 4 * i + 2] = (unsigned char)(u >> 8);
+        o[base + 4 * i + 3] = (unsigned char)u;
+    }
+    std::ofstream f(path, std::ios::binary | std::ios::trunc);
+    if (!f) throw Error(SGZ_E_IO, "cannot create " + path);
+    f.write(reinterpret_cast<const char *>(o.data()), (std::streamsize)o.size());
+    if (!f) throw Error(SGZ_E_IO, "cannot write " + path);
+}
+
+}  // namespace strugatzki

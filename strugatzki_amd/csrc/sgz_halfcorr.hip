@@ -149,16 +149,30 @@ struct DevBuf {
 
 extern "C" {
 
-int sgz_segm_curve(sgz_context *ctx, const float *frames, int64_t num_frames, int num_channels, int af_start,
-                   int af_stop, int half_win, float temporal_weight, float *sim_out, int64_t *num_out)
+static NormParams make_norm(const float *norms, int numCh)
+{
+    NormParams n;
+    std::memset(&n, 0, sizeof n);
+    if (norms) {
+        n.enabled = 1;
+        for (int c = 0; c < numCh; c++) {
+            n.mn[c] = norms[2 * c];
+            n.d[c] = norms[2 * c + 1] - norms[2 * c];
+        }
+    }
+    return n;
+}
+
+int sgz_segm_curve(sgz_context *ctx, const float *frames, int64_t num_frames, int num_channels, const float *norms,
+                   int af_start, int af_stop, int half_win, float temporal_weight, float *sim_out,
+                   int64_t *num_out)
 {
     if (!ctx) return SGZ_E_ARG;
     if (!frames || num_frames < 0 || num_channels < 2 || num_channels > SGZ_MAX_CHANNELS)
         return ctx->fail(SGZ_E_ARG, "bad frames / channels");
     if (half_win < 1 || af_start < 0 || af_stop > num_frames || !num_out)
         return ctx->fail(SGZ_E_ARG, "bad window / span");
-    if (ctx->norm.enabled && ctx->numCh != num_channels)
-        return ctx->fail(SGZ_E_ARG, "norms were set for a different channel count");
+    const NormParams nrm = make_norm(norms, num_channels);
     const long long afLen = (long long)af_stop - af_start;
     // the reference loop runs once per frame after the first 2H have been read
     // (impl/FeatureSegmentationImpl.scala:101-129)
@@ -175,7 +189,7 @@ int sgz_segm_curve(sgz_context *ctx, const float *frames, int64_t num_frames, in
     SGZ_HIP(ctx, hipMemcpyAsync(raw.p, frames, elems * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     const int g1 = (int)std::min<size_t>((elems + 255) / 256, 16384);
     hipLaunchKernelGGL(planar_norm_kernel, dim3(g1), dim3(256), 0, ctx->stream, (const float *)raw.p,
-                       (long long)num_frames, num_channels, ctx->norm, (float *)planar.p);
+                       (long long)num_frames, num_channels, nrm, (float *)planar.p);
     SGZ_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(segm_kernel, dim3((unsigned)((numWin + 255) / 256)), dim3(256), 0, ctx->stream,
                        (const float *)planar.p, (long long)num_frames, num_channels, af_start, numWin, half_win,
@@ -187,7 +201,8 @@ int sgz_segm_curve(sgz_context *ctx, const float *frames, int64_t num_frames, in
 }
 
 int sgz_selfsim_run(sgz_context *ctx, const float *frames1, int64_t num_frames1, const float *frames2,
-                    int64_t num_frames2, int num_channels, int af_start, int half_win, int decim, int img_ext,
+                    int64_t num_frames2, int num_channels, const float *norms, int af_start, int half_win,
+                    int decim, int img_ext,
                     float temporal_weight, int colors, float color_warp, float color_ceil, int color_inv,
                     float *sim_out, int32_t *img_out)
 {
@@ -200,8 +215,7 @@ int sgz_selfsim_run(sgz_context *ctx, const float *frames1, int64_t num_frames1,
         return ctx->fail(SGZ_E_ARG, "only the gray colour scheme (0) is implemented");
     if (!(color_warp > 0) || !(color_ceil > 0))  // impl/SelfSimilarityImpl.scala:112-113
         return ctx->fail(SGZ_E_ARG, "color warp / ceil must be > 0");
-    if (ctx->norm.enabled && ctx->numCh != num_channels)
-        return ctx->fail(SGZ_E_ARG, "norms were set for a different channel count");
+    const NormParams nrm = make_norm(norms, num_channels);
     if (img_ext == 0) return SGZ_OK;
     const long long lastStart = (long long)af_start + (long long)(img_ext - 1) * decim;
     if (lastStart + half_win > num_frames1 || lastStart + half_win > num_frames2)
@@ -214,14 +228,14 @@ int sgz_selfsim_run(sgz_context *ctx, const float *frames1, int64_t num_frames1,
     SGZ_HIP(ctx, hipMalloc(&p1.p, e1 * sizeof(float)));
     SGZ_HIP(ctx, hipMemcpyAsync(raw.p, frames1, e1 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(planar_norm_kernel, dim3((unsigned)std::min<size_t>((e1 + 255) / 256, 16384)), dim3(256), 0,
-                       ctx->stream, (const float *)raw.p, (long long)num_frames1, num_channels, ctx->norm,
+                       ctx->stream, (const float *)raw.p, (long long)num_frames1, num_channels, nrm,
                        (float *)p1.p);
     SGZ_HIP(ctx, hipGetLastError());
     if (!same) {
         SGZ_HIP(ctx, hipMalloc(&p2.p, e2 * sizeof(float)));
         SGZ_HIP(ctx, hipMemcpyAsync(raw.p, frames2, e2 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
         hipLaunchKernelGGL(planar_norm_kernel, dim3((unsigned)std::min<size_t>((e2 + 255) / 256, 16384)), dim3(256),
-                           0, ctx->stream, (const float *)raw.p, (long long)num_frames2, num_channels, ctx->norm,
+                           0, ctx->stream, (const float *)raw.p, (long long)num_frames2, num_channels, nrm,
                            (float *)p2.p);
         SGZ_HIP(ctx, hipGetLastError());
     }

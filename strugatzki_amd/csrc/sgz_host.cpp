@@ -1,0 +1,481 @@
+// Host-side processors: what impl.FeatureCorrelationImpl / FeatureSegmentationImpl /
+// SelfSimilarityImpl do around their inner loops in the reference -- meta files,
+// database folder scan, norms, spans, result records -- driving the GPU through
+// the C ABI.  Also the string-based C wrappers that let any FFI run a whole
+// processor from its XML config.
+#include <zlib.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <filesystem>
+#include <fstream>
+
+#include "strugatzki_amd.hpp"
+
+namespace fs = std::filesystem;
+
+namespace strugatzki {
+namespace {
+
+void check(sgz_context *ctx, int rc)
+{
+    if (rc != SGZ_OK) throw Error(rc, sgz_last_error(ctx));
+}
+
+bool notify(const Observer &obs, double p)
+{
+    return !obs || obs(p);
+}
+void checkAborted(const Observer &obs, double p)
+{
+    if (!notify(obs, p)) throw Error(SGZ_E_STATE, "aborted");
+}
+
+// impl/FeatureCorrelationImpl.scala:38-39
+int fullToFeat(int64_t n, int stepSize) { return (int)((n + (stepSize >> 1)) / stepSize); }
+
+// feat_norms.aif: numCh channels x 2 frames, frame 0 = minima, frame 1 = maxima
+// (impl/FeatureCorrelationImpl.scala:61-71, Strugatzki.scala:417-426)
+std::vector<float> readNorms(const std::string &folder, int numCh)
+{
+    const AudioData a = readAudioFile((fs::path(folder) / kNormalizeName).string());
+    if (a.numChannels != numCh || a.numFrames != 2)
+        throw Error(SGZ_E_ARG, "requirement failed: norms file must have numCoeffs+1 channels and 2 frames");
+    std::vector<float> n(2 * (size_t)numCh);
+    for (int c = 0; c < numCh; c++) {
+        n[2 * c] = a.frames[c];
+        n[2 * c + 1] = a.frames[numCh + c];
+    }
+    return n;
+}
+
+struct Spans {
+    int afStart, afStop;
+};
+// impl/FeatureSegmentationImpl.scala:90-97, impl/SelfSimilarityImpl.scala:65-72
+Spans spanToFeat(const Span &s, int64_t numFrames, int step)
+{
+    Spans r;
+    r.afStart = s.start ? std::max(0, fullToFeat(*s.start, step)) : 0;
+    r.afStop = s.stop ? std::min((int)numFrames, fullToFeat(*s.stop, step)) : (int)numFrames;
+    return r;
+}
+
+void writePng(const std::string &path, const int32_t *rgb, int w, int h)
+{
+    // 8-bit RGB, filter 0 on every row, one zlib stream
+    std::vector<unsigned char> raw((size_t)h * (1 + 3 * (size_t)w));
+    for (int y = 0; y < h; y++) {
+        unsigned char *row = &raw[(size_t)y * (1 + 3 * (size_t)w)];
+        row[0] = 0;
+        for (int x = 0; x < w; x++) {
+            const int32_t p = rgb[(size_t)y * w + x];
+            row[1 + 3 * x] = (unsigned char)(p >> 16);
+            row[2 + 3 * x] = (unsigned char)(p >> 8);
+            row[3 + 3 * x] = (unsigned char)p;
+        }
+    }
+    uLongf zlen = compressBound((uLong)raw.size());
+    std::vector<unsigned char> z(zlen);
+    if (compress2(z.data(), &zlen, raw.data(), (uLong)raw.size(), 1) != Z_OK) throw Error(SGZ_E_IO, "PNG: deflate failed");
+    std::ofstream f(path, std::ios::binary | std::ios::trunc);
+    if (!f) throw Error(SGZ_E_IO, "cannot create " + path);
+    auto chunk = [&](const char *type, const unsigned char *data, size_t len) {
+        unsigned char hdr[8] = {(unsigned char)(len >> 24), (unsigned char)(len >> 16), (unsigned char)(len >> 8),
+                                (unsigned char)len, (unsigned char)type[0], (unsigned char)type[1],
+                                (unsigned char)type[2], (unsigned char)type[3]};
+        f.write(reinterpret_cast<const char *>(hdr), 8);
+        if (len) f.write(reinterpret_cast<const char *>(data), (std::streamsize)len);
+        uLong crc = crc32(0L, hdr + 4, 4);
+        if (len) crc = crc32(crc, data, (uInt)len);
+        const unsigned char c[4] = {(unsigned char)(crc >> 24), (unsigned char)(crc >> 16), (unsigned char)(crc >> 8),
+                                    (unsigned char)crc};
+        f.write(reinterpret_cast<const char *>(c), 4);
+    };
+    static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    f.write(reinterpret_cast<const char *>(sig), 8);
+    const unsigned char ihdr[13] = {(unsigned char)(w >> 24), (unsigned char)(w >> 16), (unsigned char)(w >> 8),
+                                    (unsigned char)w, (unsigned char)(h >> 24), (unsigned char)(h >> 16),
+                                    (unsigned char)(h >> 8), (unsigned char)h, 8, 2, 0, 0, 0};
+    chunk("IHDR", ihdr, 13);
+    // IDAT chunks of at most 1 GiB
+    for (size_t off = 0; off < zlen;) {
+        const size_t n = std::min<size_t>(zlen - off, (size_t)1 << 30);
+        chunk("IDAT", z.data() + off, n);
+        off += n;
+    }
+    chunk("IEND", nullptr, 0);
+    if (!f) throw Error(SGZ_E_IO, "cannot write " + path);
+}
+
+}  // namespace
+
+// -----------------------------------------------------------------------------
+// FeatureCorrelation: impl/FeatureCorrelationImpl.scala:32-246, 399-411
+// -----------------------------------------------------------------------------
+std::vector<Match> runFeatureCorrelation(sgz_context *ctx, const FeatureCorrelationConfig &cfg, const Observer &obs)
+{
+    if (!ctx) throw Error(SGZ_E_ARG, "null context");
+    if (cfg.punchOut) throw Error(SGZ_E_ARG, "punchOut (in/out pairing) is not implemented");
+    if (cfg.numMatches < 0 || cfg.numPerFile < 0) throw Error(SGZ_E_ARG, "numMatches / numPerFile must be >= 0");
+    const FeatureExtractionConfig extrIn = FeatureExtractionConfig::fromXMLFile(cfg.metaInput);  // :35
+    if (extrIn.fftOverlap < 1 || extrIn.fftSize < extrIn.fftOverlap) throw Error(SGZ_E_ARG, "bad fftSize / fftOverlap");
+    const int stepSize = extrIn.fftSize / extrIn.fftOverlap;  // :36
+    const int numCh = extrIn.numCoeffs + 1;
+
+    // :42 -- *_feat.xml in the folder, minus the input's own meta file; visited in name order
+    std::vector<std::string> metas;
+    std::error_code ec;
+    const fs::path inMeta = fs::path(cfg.metaInput).lexically_normal();
+    for (const auto &e : fs::directory_iterator(cfg.databaseFolder, ec)) {
+        const std::string name = e.path().filename().string();
+        if (name.size() < 9 || name.compare(name.size() - 9, 9, "_feat.xml") != 0) continue;
+        const fs::path p = (fs::path(cfg.databaseFolder) / name).lexically_normal();
+        if (p == inMeta) continue;
+        std::error_code ec2;
+        if (fs::exists(inMeta, ec2) && fs::equivalent(p, inMeta, ec2)) continue;
+        metas.push_back(p.string());
+    }
+    if (ec) throw Error(SGZ_E_IO, "cannot list database folder " + cfg.databaseFolder);
+    std::sort(metas.begin(), metas.end());
+    // :50-55 -- same number of coefficients and same step size
+    std::vector<FeatureExtractionConfig> extrDBs;
+    for (const auto &m : metas) {
+        const FeatureExtractionConfig e = FeatureExtractionConfig::fromXMLFile(m);
+        if (e.fftOverlap >= 1 && e.numCoeffs == extrIn.numCoeffs && e.fftSize / e.fftOverlap == stepSize) extrDBs.push_back(e);
+    }
+
+    std::vector<float> norms;
+    if (cfg.normalize) norms = readNorms(cfg.databaseFolder, numCh);  // :61-71
+
+    // readInBuffer, :83-98
+    const AudioData afIn = readAudioFile(extrIn.featureOutput);
+    if (afIn.numChannels != numCh) throw Error(SGZ_E_ARG, "input feature file has the wrong number of channels");
+    const int start = fullToFeat(cfg.punchIn.span.start.value_or(0), stepSize);
+    const int stop = fullToFeat(cfg.punchIn.span.stop.value_or(0), stepSize);
+    const int L = stop - start;
+    if (L < 1 || start < 0 || (int64_t)stop > afIn.numFrames)
+        throw Error(SGZ_E_IO, "punchIn span lies outside the input feature file");
+
+    check(ctx, sgz_db_reset(ctx, numCh));
+    std::vector<int> dbIndex;  // database entries that made it to the GPU
+    for (size_t i = 0; i < extrDBs.size(); i++) {
+        checkAborted(obs, 0.5 * (double)i / (double)std::max<size_t>(extrDBs.size(), 1));  // :164
+        const AudioData af = readAudioFile(extrDBs[i].featureOutput);  // :169
+        if (af.numChannels != numCh)
+            throw Error(SGZ_E_IO, "feature file " + extrDBs[i].featureOutput + " has the wrong number of channels");
+        check(ctx, sgz_db_add_file(ctx, af.frames.data(), af.numFrames));
+        dbIndex.push_back((int)i);
+    }
+    check(ctx, sgz_set_norms(ctx, cfg.normalize ? norms.data() : nullptr));
+    check(ctx, sgz_corr_set_target(ctx, afIn.frames.data() + (size_t)start * numCh, L, cfg.punchIn.temporalWeight,
+                                   cfg.maxBoost));
+
+    const int nf = (int)dbIndex.size();
+    sgz_selector *sel = sgz_sel_create(cfg.numMatches, cfg.numPerFile, cfg.minSpacing, stepSize, L);
+    if (!sel) throw Error(SGZ_E_ARG, "illegal selection parameters");
+    struct SelGuard {
+        sgz_selector *s;
+        ~SelGuard() { sgz_sel_destroy(s); }
+    } guard{sel};
+
+    // GPU: all similarities; host: replay of the match bookkeeping in file order
+    const int head = std::min(nf, std::max(cfg.numMatches, 1));
+    check(ctx, sgz_corr_run(ctx, 0, head));
+    if (head < nf) check(ctx, sgz_corr_run(ctx, head, nf));
+    std::vector<float> sim, boost;
+    auto feedDense = [&](int f0, int f1) {
+        int64_t total = 0;
+        for (int f = f0; f < f1; f++) total += sgz_corr_num_windows(ctx, f);
+        sim.resize((size_t)total);
+        boost.resize((size_t)total);
+        check(ctx, sgz_corr_read_dense_range(ctx, f0, f1, sim.data(), boost.data()));
+        size_t pos = 0;
+        for (int f = f0; f < f1; f++) {
+            const int64_t n = sgz_corr_num_windows(ctx, f);
+            if (sgz_sel_feed_file(sel, f, n, nullptr, sim.data() + pos, boost.data() + pos) != SGZ_OK)
+                throw Error(SGZ_E_ARG, "selector rejected its input");
+            pos += (size_t)n;
+        }
+    };
+    feedDense(0, head);
+    checkAborted(obs, 0.6);
+    int f = head;
+    while (f < nf && !sgz_sel_is_full(sel)) {
+        feedDense(f, f + 1);
+        f++;
+    }
+    if (f < nf) {
+        const int64_t cap = 1 << 16;
+        std::vector<sgz_candidate> cands((size_t)cap);
+        int64_t count = 0;
+        const int rc = sgz_corr_compact(ctx, f, nf, sgz_sel_threshold(sel), cands.data(), cap, &count);
+        if (rc == SGZ_E_OVERFLOW) {
+            for (int g = f; g < nf; g++) feedDense(g, g + 1);
+        } else {
+            check(ctx, rc);
+            std::vector<int32_t> off;
+            size_t i = 0;
+            while (i < (size_t)count) {
+                size_t j = i;
+                off.clear();
+                sim.clear();
+                boost.clear();
+                while (j < (size_t)count && cands[j].file == cands[i].file) {
+                    off.push_back(cands[j].offset);
+                    sim.push_back(cands[j].sim);
+                    boost.push_back(cands[j].boost);
+                    j++;
+                }
+                if (sgz_sel_feed_file(sel, cands[i].file, (int64_t)off.size(), off.data(), sim.data(), boost.data()) != SGZ_OK)
+                    throw Error(SGZ_E_ARG, "selector rejected its input");
+                i = j;
+            }
+        }
+    }
+    checkAborted(obs, 1.0);
+    std::vector<sgz_match> raw((size_t)std::max(cfg.numMatches, 1));
+    const int n = sgz_sel_result(sel, raw.data(), cfg.numMatches);
+    std::vector<Match> out;
+    for (int i = 0; i < n; i++) {
+        Match m;
+        m.sim = raw[i].sim;
+        m.file = extrDBs[(size_t)dbIndex[(size_t)raw[i].file]].audioInput;  // :237
+        m.punch = Span::of(raw[i].start, raw[i].stop);
+        m.boostIn = raw[i].boost_in;
+        m.boostOut = raw[i].boost_out;
+        out.push_back(m);
+    }
+    return out;
+}
+
+// -----------------------------------------------------------------------------
+// FeatureSegmentation: impl/FeatureSegmentationImpl.scala:31-142
+// -----------------------------------------------------------------------------
+std::vector<Break> runFeatureSegmentation(sgz_context *ctx, const FeatureSegmentationConfig &cfg, const Observer &obs)
+{
+    if (!ctx) throw Error(SGZ_E_ARG, "null context");
+    const FeatureExtractionConfig extr = FeatureExtractionConfig::fromXMLFile(cfg.metaInput);
+    if (extr.fftOverlap < 1 || extr.fftSize < extr.fftOverlap) throw Error(SGZ_E_ARG, "bad fftSize / fftOverlap");
+    const int stepSize = extr.fftSize / extr.fftOverlap;
+    const int numCh = extr.numCoeffs + 1;
+    std::vector<float> norms;
+    if (cfg.normalize) norms = readNorms(cfg.databaseFolder, numCh);
+    const int halfWinLen = fullToFeat(cfg.corrLen, stepSize);
+    if (halfWinLen < 1) throw Error(SGZ_E_ARG, "corrLen is shorter than one feature frame");
+    const AudioData af = readAudioFile(extr.featureOutput);
+    if (af.numChannels != numCh) throw Error(SGZ_E_IO, "feature file has the wrong number of channels");
+    const Spans sp = spanToFeat(cfg.span, af.numFrames, stepSize);
+    checkAborted(obs, 0.0);
+    std::vector<float> dense((size_t)std::max<int64_t>(1, af.numFrames));
+    int64_t numOut = 0;
+    if (sp.afStop > sp.afStart)
+        check(ctx, sgz_segm_curve(ctx, af.frames.data(), af.numFrames, numCh, cfg.normalize ? norms.data() : nullptr,
+                                  sp.afStart, sp.afStop, halfWinLen, cfg.temporalWeight, dense.data(), &numOut));
+    checkAborted(obs, 0.9);
+    std::vector<sgz_break> raw((size_t)std::max(cfg.numBreaks, 1));
+    const int n = sgz_segm_select(dense.data(), numOut, sp.afStart, halfWinLen, stepSize, cfg.numBreaks, cfg.minSpacing,
+                                  raw.data(), cfg.numBreaks);
+    if (n < 0) throw Error(n, "illegal break selection parameters");
+    std::vector<Break> out;
+    for (int i = 0; i < n; i++) out.push_back(Break{raw[i].sim, raw[i].pos});
+    notify(obs, 1.0);
+    return out;
+}
+
+// -----------------------------------------------------------------------------
+// SelfSimilarity: impl/SelfSimilarityImpl.scala:31-180
+// -----------------------------------------------------------------------------
+void runSelfSimilarity(sgz_context *ctx, const SelfSimilarityConfig &cfg, const Observer &obs)
+{
+    if (!ctx) throw Error(SGZ_E_ARG, "null context");
+    const FeatureExtractionConfig e1 = FeatureExtractionConfig::fromXMLFile(cfg.metaInput);
+    const FeatureExtractionConfig e2 = cfg.metaInput2 ? FeatureExtractionConfig::fromXMLFile(*cfg.metaInput2) : e1;
+    if (!(e1.fftSize == e2.fftSize && e1.fftOverlap == e2.fftOverlap && e1.numCoeffs == e2.numCoeffs))
+        throw Error(SGZ_E_ARG, "requirement failed: the two inputs differ in fftSize, fftOverlap or numCoeffs");  // :34-35
+    if (e1.fftOverlap < 1 || e1.fftSize < e1.fftOverlap) throw Error(SGZ_E_ARG, "bad fftSize / fftOverlap");
+    const int stepSize = e1.fftSize / e1.fftOverlap;
+    const int numCh = e1.numCoeffs + 1;
+    const int halfWinLen = fullToFeat(cfg.corrLen, stepSize);
+    const int winLen = halfWinLen * 2;
+    if (halfWinLen < 1) throw Error(SGZ_E_ARG, "corrLen is shorter than one feature frame");
+    if (cfg.colors != ColorScheme::GrayScale)
+        throw Error(SGZ_E_ARG, "only the 'gray' color scheme is implemented");
+    if (cfg.decimation < 1) throw Error(SGZ_E_ARG, "Illegal decimation setting of " + std::to_string(cfg.decimation));
+    if (!(cfg.colorWarp > 0)) throw Error(SGZ_E_ARG, "Illegal color warp setting. Must be > 0");
+    if (!(cfg.colorCeil > 0)) throw Error(SGZ_E_ARG, "Illegal color ceil setting. Must be > 0");
+    std::vector<float> norms;
+    if (cfg.normalize) norms = readNorms(cfg.databaseFolder, numCh);
+    const AudioData a1 = readAudioFile(e1.featureOutput);
+    const bool same = e1.featureOutput == e2.featureOutput;
+    AudioData a2own;
+    if (!same) a2own = readAudioFile(e2.featureOutput);
+    const AudioData &a2 = same ? a1 : a2own;
+    if (a1.numChannels != numCh || a2.numChannels != numCh)
+        throw Error(SGZ_E_IO, "feature file has the wrong number of channels");
+    const int64_t afNumFrames = std::min(a1.numFrames, a2.numFrames);  // :64
+    const Spans sp = spanToFeat(cfg.span, afNumFrames, stepSize);
+    const int afLen = sp.afStop - sp.afStart;
+    const int numCorrs = (int)std::max<int64_t>(0, (int64_t)afLen - winLen + 1);  // :75-80
+    int decim = cfg.decimation, imgExt = numCorrs / decim;                          // :81-91
+    if (imgExt > 0xB504) {
+        decim = (numCorrs + 0xB503) / 0xB504;
+        imgExt = numCorrs / decim;
+    }
+    checkAborted(obs, 0.0);
+    std::vector<int32_t> img((size_t)imgExt * (size_t)imgExt);
+    check(ctx, sgz_selfsim_run(ctx, a1.frames.data(), a1.numFrames, a2.frames.data(), a2.numFrames, numCh,
+                               cfg.normalize ? norms.data() : nullptr, sp.afStart, halfWinLen, decim, imgExt,
+                               cfg.temporalWeight, 0, cfg.colorWarp, cfg.colorCeil, cfg.colorInv ? 1 : 0, nullptr,
+                               img.data()));
+    checkAborted(obs, 0.9);
+    writePng(cfg.imageOutput, img.data(), imgExt, imgExt);  // :167
+    notify(obs, 1.0);
+}
+
+}  // namespace strugatzki
+
+// -----------------------------------------------------------------------------
+// C wrappers
+// -----------------------------------------------------------------------------
+namespace {
+char *dupString(const std::string &s)
+{
+    char *p = static_cast<char *>(std::malloc(s.size() + 1));
+    if (p) std::memcpy(p, s.c_str(), s.size() + 1);
+    return p;
+}
+thread_local std::string g_lastHostError;
+
+template <typename F>
+int guarded(F &&f)
+{
+    try {
+        f();
+        return SGZ_OK;
+    } catch (const strugatzki::Error &e) {
+        g_lastHostError = e.what();
+        return e.code();
+    } catch (const std::exception &e) {
+        g_lastHostError = e.what();
+        return SGZ_E_IO;
+    }
+}
+strugatzki::Observer makeObserver(sgz_progress_fn cb, void *user)
+{
+    if (!cb) return nullptr;
+    return [cb, user](double p) { return cb(p, user) != 0; };
+}
+}  // namespace
+
+extern "C" {
+
+const char *sgz_host_last_error(void) { return g_lastHostError.c_str(); }
+
+void sgz_free_string(char *s) { std::free(s); }
+
+int sgz_run_correlation_xml(sgz_context *ctx, const char *config_xml, sgz_progress_fn cb, void *user,
+                            char **result_xml)
+{
+    if (!config_xml || !result_xml) return SGZ_E_ARG;
+    *result_xml = nullptr;
+    return guarded([&] {
+        const auto cfg = strugatzki::FeatureCorrelationConfig::fromXML(config_xml);
+        const auto ms = strugatzki::runFeatureCorrelation(ctx, cfg, makeObserver(cb, user));
+        std::string o = "<matches>\n";
+        for (const auto &m : ms) o += m.toXML() + "\n";
+        o += "</matches>";
+        *result_xml = dupString(o);
+    });
+}
+
+int sgz_run_segmentation_xml(sgz_context *ctx, const char *config_xml, sgz_progress_fn cb, void *user,
+                             char **result_xml)
+{
+    if (!config_xml || !result_xml) return SGZ_E_ARG;
+    *result_xml = nullptr;
+    return guarded([&] {
+        const auto cfg = strugatzki::FeatureSegmentationConfig::fromXML(config_xml);
+        const auto bs = strugatzki::runFeatureSegmentation(ctx, cfg, makeObserver(cb, user));
+        std::string o = "<breaks>\n";
+        for (const auto &b : bs) o += b.toXML() + "\n";
+        o += "</breaks>";
+        *result_xml = dupString(o);
+    });
+}
+
+int sgz_run_selfsimilarity_xml(sgz_context *ctx, const char *config_xml, sgz_progress_fn cb, void *user)
+{
+    if (!config_xml) return SGZ_E_ARG;
+    return guarded([&] {
+        const auto cfg = strugatzki::SelfSimilarityConfig::fromXML(config_xml);
+        strugatzki::runSelfSimilarity(ctx, cfg, makeObserver(cb, user));
+    });
+}
+
+int sgz_config_roundtrip_xml(const char *kind, const char *xml, char **out_xml)
+{
+    if (!kind || !xml || !out_xml) return SGZ_E_ARG;
+    *out_xml = nullptr;
+    return guarded([&] {
+        const std::string k(kind);
+        std::string o;
+        if (k == "feature") o = strugatzki::FeatureExtractionConfig::fromXML(xml).toXML();
+        else if (k == "correlate") o = strugatzki::FeatureCorrelationConfig::fromXML(xml).toXML();
+        else if (k == "match") o = strugatzki::Match::fromXML(xml).toXML();
+        else if (k == "segmentation") o = strugatzki::FeatureSegmentationConfig::fromXML(xml).toXML();
+        else if (k == "break") o = strugatzki::Break::fromXML(xml).toXML();
+        else if (k == "selfsimilarity") o = strugatzki::SelfSimilarityConfig::fromXML(xml).toXML();
+        else throw strugatzki::Error(SGZ_E_ARG, "unknown config kind " + k);
+        *out_xml = dupString(o);
+    });
+}
+
+int sgz_default_config_xml(const char *kind, char **out_xml)
+{
+    if (!kind || !out_xml) return SGZ_E_ARG;
+    *out_xml = nullptr;
+    return guarded([&] {
+        const std::string k(kind);
+        std::string o;
+        if (k == "feature") o = strugatzki::FeatureExtractionConfig().toXML();
+        else if (k == "correlate") o = strugatzki::FeatureCorrelationConfig().toXML();
+        else if (k == "segmentation") o = strugatzki::FeatureSegmentationConfig().toXML();
+        else if (k == "selfsimilarity") o = strugatzki::SelfSimilarityConfig().toXML();
+        else throw strugatzki::Error(SGZ_E_ARG, "unknown config kind " + k);
+        *out_xml = dupString(o);
+    });
+}
+
+int sgz_write_float_aiff(const char *path, const float *frames, int64_t num_frames, int num_channels,
+                         double sample_rate)
+{
+    if (!path || num_frames < 0 || num_channels < 1 || (num_frames > 0 && !frames)) return SGZ_E_ARG;
+    return guarded([&] {
+        strugatzki::AudioData a;
+        a.numChannels = num_channels;
+        a.numFrames = num_frames;
+        a.sampleRate = sample_rate;
+        a.frames.assign(frames, frames + (size_t)num_frames * num_channels);
+        strugatzki::writeFloatAiff(path, a);
+    });
+}
+
+int sgz_read_audio_file(const char *path, float *frames_out, int64_t capacity_frames, int64_t *num_frames,
+                        int *num_channels, double *sample_rate)
+{
+    if (!path) return SGZ_E_ARG;
+    return guarded([&] {
+        const strugatzki::AudioData a = strugatzki::readAudioFile(path);
+        if (num_frames) *num_frames = a.numFrames;
+        if (num_channels) *num_channels = a.numChannels;
+        if (sample_rate) *sample_rate = a.sampleRate;
+        if (frames_out) {
+            if (capacity_frames < a.numFrames) throw strugatzki::Error(SGZ_E_OVERFLOW, "frame buffer too small");
+            std::memcpy(frames_out, a.frames.data(), a.frames.size() * sizeof(float));
+        }
+    });
+}
+
+}  // extern "C"

@@ -155,26 +155,29 @@ class Context:
         self._check(lib.sgz_synchronize(self._h))
 
     # ---- segmentation / self-similarity ----------------------------------
-    def segm_curve(self, frames: np.ndarray, af_start: int, af_stop: int, half_win: int,
+    def segm_curve(self, frames: np.ndarray, norms: np.ndarray | None, af_start: int, af_stop: int, half_win: int,
                    temporal_weight: float) -> np.ndarray:
         a = _as_frames(frames)
+        nrm = None if norms is None else np.ascontiguousarray(norms, dtype=np.float32)
         n = max(0, (af_stop - af_start) - 2 * half_win + 1)
         out = np.empty(max(n, 1), dtype=np.float32)
         cnt = C.c_int64(0)
-        self._check(lib.sgz_segm_curve(self._h, N.ptr(a), a.shape[0], a.shape[1], af_start, af_stop, half_win,
+        self._check(lib.sgz_segm_curve(self._h, N.ptr(a), a.shape[0], a.shape[1], N.ptr(nrm), af_start, af_stop, half_win,
                                        temporal_weight, N.ptr(out), C.byref(cnt)))
         return out[: cnt.value]
 
-    def selfsim(self, frames1: np.ndarray, frames2: np.ndarray | None, af_start: int, half_win: int, decim: int,
+    def selfsim(self, frames1: np.ndarray, frames2: np.ndarray | None, norms: np.ndarray | None, af_start: int,
+                half_win: int, decim: int,
                 img_ext: int, temporal_weight: float, colors: int = 0, color_warp: float = 1.0,
                 color_ceil: float = 1.0, color_inv: bool = False, want_sim: bool = True,
                 want_img: bool = True) -> tuple[np.ndarray | None, np.ndarray | None]:
         a1 = _as_frames(frames1)
         a2 = a1 if frames2 is None else _as_frames(frames2, a1.shape[1])
+        nrm = None if norms is None else np.ascontiguousarray(norms, dtype=np.float32)
         sim = np.zeros((img_ext, img_ext), dtype=np.float32) if want_sim else None
         img = np.zeros((img_ext, img_ext), dtype=np.int32) if want_img else None
         self._check(lib.sgz_selfsim_run(self._h, N.ptr(a1), a1.shape[0], N.ptr(a2), a2.shape[0], a1.shape[1],
-                                        af_start, half_win, decim, img_ext, temporal_weight, colors, color_warp,
+                                        N.ptr(nrm), af_start, half_win, decim, img_ext, temporal_weight, colors, color_warp,
                                         color_ceil, int(color_inv), N.ptr(sim), N.ptr(img)))
         return sim, img
 

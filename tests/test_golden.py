@@ -86,9 +86,7 @@ def test_gpu_reproduces_segmentation_golden(ctx):
     from strugatzki_amd.engine import segm_select
     g = _load("segmentation.npz")
     a0, a1, H, nb, ms = (int(v) for v in g["params"])
-    ctx.db_reset(NUM_CH)
-    ctx.set_norms(g["norms"])
-    dense = ctx.segm_curve(g["frames"], a0, a1, H, 0.5)
+    dense = ctx.segm_curve(g["frames"], g["norms"], a0, a1, H, 0.5)
     assert np.array_equal(dense, g["dense"])  # same summation order as the reference: bit-exact
     got = segm_select(dense, a0, H, STEP, nb, ms)
     assert np.array_equal(np.array([(b.sim, b.pos) for b in got], dtype=np.float64), g["breaks"])
@@ -98,9 +96,7 @@ def test_gpu_reproduces_segmentation_golden(ctx):
 def test_gpu_reproduces_selfsim_golden(ctx):
     g = _load("selfsim.npz")
     ext, decim, af_start, num_corrs, H = (int(v) for v in g["params"])
-    ctx.db_reset(NUM_CH)
-    ctx.set_norms(g["norms"])
-    sim, img = ctx.selfsim(g["frames"], None, af_start, H, decim, ext, 0.5, 0, 0.7, 0.9, False)
+    sim, img = ctx.selfsim(g["frames"], None, g["norms"], af_start, H, decim, ext, 0.5, 0, 0.7, 0.9, False)
     np.testing.assert_allclose(sim, g["sim"], rtol=0, atol=1e-5)
     # pixel values: allow one grey level where pow() rounds differently
     d = np.abs((img & 0xFF).astype(np.int64) - (g["img"] & 0xFF).astype(np.int64))

@@ -31,9 +31,7 @@ def test_segmentation_curve_and_breaks(ctx, span, corr_len, weight, normalize):
     H = O.full_to_feat(corr_len, STEP)
     a0 = max(0, O.full_to_feat(span[0], STEP)) if span[0] is not None else 0
     a1 = min(frames.shape[0], O.full_to_feat(span[1], STEP)) if span[1] is not None else frames.shape[0]
-    ctx.db_reset(NUM_CH)
-    ctx.set_norms(norms)
-    got = ctx.segm_curve(frames, a0, a1, H, weight)
+    got = ctx.segm_curve(frames, norms, a0, a1, H, weight)
     assert got.shape == dense.shape
     np.testing.assert_allclose(got, dense, rtol=0, atol=1e-5)
     assert np.array_equal(got, dense)  # the kernel keeps the reference's summation order
@@ -43,9 +41,7 @@ def test_segmentation_curve_and_breaks(ctx, span, corr_len, weight, normalize):
 
 def test_segmentation_window_longer_than_span_gives_nothing(ctx):
     frames = _frames(60)
-    ctx.db_reset(NUM_CH)
-    ctx.set_norms(norms_default())
-    assert ctx.segm_curve(frames, 0, 60, 43, 0.5).shape == (0,)
+    assert ctx.segm_curve(frames, norms_default(), 0, 60, 43, 0.5).shape == (0,)
 
 
 @pytest.mark.parametrize("decim,corr_len,warp,ceil,inv", [(1, 4 * STEP, 1.0, 1.0, False), (3, 8 * STEP, 0.5, 0.8, True),
@@ -56,10 +52,8 @@ def test_selfsim_matrix_and_image(ctx, decim, corr_len, warp, ceil, inv):
     cfg = O.SelfSimConfig(0, 0, 0, 0, corr_len, decim, 0.5, 0, warp, ceil, int(inv), 1, STEP, NUM_CH - 1)
     ext, d, af_start, _ = O.selfsim_geometry(cfg, frames.shape[0], frames.shape[0])
     want_sim, want_img = O.selfsim_run(cfg, frames, None, norms)
-    ctx.db_reset(NUM_CH)
-    ctx.set_norms(norms)
     H = O.full_to_feat(corr_len, STEP)
-    sim, img = ctx.selfsim(frames, None, af_start, H, d, ext, 0.5, 0, warp, ceil, inv)
+    sim, img = ctx.selfsim(frames, None, norms, af_start, H, d, ext, 0.5, 0, warp, ceil, inv)
     np.testing.assert_allclose(sim, want_sim, rtol=0, atol=1e-5)
     assert np.array_equal(sim, sim.T)
     dpx = np.abs((img & 0xFF).astype(np.int64) - (want_img & 0xFF).astype(np.int64))
@@ -74,9 +68,7 @@ def test_cross_file_similarity(ctx):
     cfg = O.SelfSimConfig(0, 0, 0, 0, 6 * STEP, 2, 0.5, 0, 1.0, 1.0, 0, 1, STEP, NUM_CH - 1)
     ext, d, af_start, _ = O.selfsim_geometry(cfg, 200, 180)
     want_sim, _ = O.selfsim_run(cfg, f1, f2, norms, want_img=False)
-    ctx.db_reset(NUM_CH)
-    ctx.set_norms(norms)
-    sim, _ = ctx.selfsim(f1, f2, af_start, 6, d, ext, 0.5, want_img=False)
+    sim, _ = ctx.selfsim(f1, f2, norms, af_start, 6, d, ext, 0.5, want_img=False)
     # the reference mirrors the upper triangle (left <= right) into the lower one
     np.testing.assert_allclose(sim, want_sim, rtol=0, atol=1e-5)
 
@@ -84,11 +76,9 @@ def test_cross_file_similarity(ctx):
 def test_selfsim_rejects_bad_arguments(ctx):
     import strugatzki_amd as S
     frames = _frames(100)
-    ctx.db_reset(NUM_CH)
-    ctx.set_norms(None)
     with pytest.raises(S.NativeError):
-        ctx.selfsim(frames, None, 0, 4, 1, 10, 0.5, color_warp=0.0)
+        ctx.selfsim(frames, None, None, 0, 4, 1, 10, 0.5, color_warp=0.0)
     with pytest.raises(S.NativeError):
-        ctx.selfsim(frames, None, 0, 4, 1, 200, 0.5)  # windows past the end
+        ctx.selfsim(frames, None, None, 0, 4, 1, 200, 0.5)  # windows past the end
     with pytest.raises(S.NativeError):
-        ctx.selfsim(frames, None, 0, 4, 1, 10, 0.5, colors=1)  # psycho-optical palette not implemented
+        ctx.selfsim(frames, None, None, 0, 4, 1, 10, 0.5, colors=1)  # psycho-optical palette not implemented

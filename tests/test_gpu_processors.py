@@ -1,0 +1,139 @@
+"""End-to-end runs of the processors from files on disk (feature AIFFs, *_feat.xml, feat_norms.aif),
+through the library's host side and the GPU, against the oracle fed with the same arrays."""
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from common import NUM_CH, SEED, STEP, O, corr_config, make_plants, norms_default, synth_db, synth_target
+from strugatzki_amd import processors as P
+from strugatzki_amd.processors import FeatureCorrelation, FeatureExtraction, FeatureSegmentation, SelfSimilarity, Span
+
+pytestmark = pytest.mark.gpu
+RATE = 44100.0 / STEP
+
+
+def _write_entry(folder, name, frames, audio_name=None, num_coeffs=NUM_CH - 1, fft=(1024, 2)):
+    feat = os.path.join(folder, f"{name}_feat.aif")
+    meta = os.path.join(folder, f"{name}_feat.xml")
+    P.write_float_aiff(feat, frames, RATE)
+    cfg = FeatureExtraction.Config(audio_name or os.path.join(folder, f"{name}.aif"), feat, meta, num_coeffs, fft[0],
+                                   fft[1], 0)
+    open(meta, "w").write(cfg.to_xml())
+    return meta
+
+
+def _write_norms(folder, norms):
+    P.write_float_aiff(os.path.join(folder, "feat_norms.aif"), np.ascontiguousarray(norms.T), RATE)
+
+
+def _make_db(tmp_path, nf=8, frames=700, L=64, ts=11, nplants=3):
+    db_dir = str(tmp_path / "db")
+    os.makedirs(db_dir)
+    plants = make_plants(nplants, L, nf, frames, ts)
+    db = synth_db(nf, frames, plants)
+    tgt = synth_target(ts, L)
+    for f, x in enumerate(db):
+        _write_entry(db_dir, f"snd{f:03d}", x)
+    # entries the folder scan must skip: other numCoeffs, other step size
+    _write_entry(db_dir, "zz_other_coeffs", O.synth_file(SEED, 90, 300, 11), num_coeffs=10)
+    _write_entry(db_dir, "zz_other_step", O.synth_file(SEED, 91, 300, NUM_CH), fft=(2048, 2))
+    in_meta = _write_entry(db_dir, "input", tgt)  # the input lives in the same folder and must be excluded
+    norms = norms_default()
+    _write_norms(db_dir, norms)
+    return db_dir, in_meta, db, tgt, norms, plants
+
+
+@pytest.mark.parametrize("num_matches,num_per_file,min_spacing", [(5, 1, 0), (6, 2, 30 * STEP)])
+def test_feature_correlation_from_files(ctx, tmp_path, num_matches, num_per_file, min_spacing):
+    L, ts = 64, 11
+    db_dir, in_meta, db, tgt, norms, plants = _make_db(tmp_path, L=L, ts=ts)
+    cfg = FeatureCorrelation.Config(db_dir, in_meta, FeatureCorrelation.Punch(Span(ts * STEP, (ts + L) * STEP), 0.5),
+                                    None, 22050, 88200, True, 8.0, num_matches, num_per_file, min_spacing)
+    seen = []
+    got = FeatureCorrelation.run(ctx, cfg, lambda p: seen.append(p) or True)
+    want, _, _ = O.correlation_run(corr_config(ts, L, num_matches=num_matches, num_per_file=num_per_file,
+                                               min_spacing=min_spacing), tgt, norms, db, dense=False)
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert g.file == os.path.join(db_dir, f"snd{w.file:03d}.aif")
+        assert (g.punch.start, g.punch.stop) == (w.start, w.stop)
+        assert abs(g.sim - w.sim) <= 1e-5 and g.boostOut == 1.0
+    assert seen and seen[-1] == 1.0 and seen == sorted(seen)
+
+
+def test_feature_correlation_errors(ctx, tmp_path):
+    L, ts = 64, 11
+    db_dir, in_meta, *_ = _make_db(tmp_path, nf=2, L=L, ts=ts)
+    base = FeatureCorrelation.Config(db_dir, in_meta, FeatureCorrelation.Punch(Span(ts * STEP, (ts + L) * STEP), 0.5))
+    os.remove(os.path.join(db_dir, "feat_norms.aif"))
+    with pytest.raises(P.N.NativeError) as e:
+        FeatureCorrelation.run(ctx, base)
+    assert e.value.code == P.N.SGZ_E_IO
+    base.normalize = False
+    assert len(FeatureCorrelation.run(ctx, base)) == 1
+    with pytest.raises(P.N.NativeError):  # span beyond the input feature file
+        FeatureCorrelation.run(ctx, FeatureCorrelation.Config(db_dir, in_meta, FeatureCorrelation.Punch(
+            Span(0, 10 ** 9), 0.5), normalize=False))
+    with pytest.raises(P.N.NativeError):  # punch-out pairing is not implemented
+        FeatureCorrelation.run(ctx, FeatureCorrelation.Config(db_dir, in_meta, base.punchIn, base.punchIn,
+                                                              normalize=False))
+    aborted = FeatureCorrelation.Config(db_dir, in_meta, base.punchIn, normalize=False)
+    with pytest.raises(P.N.NativeError) as e:
+        FeatureCorrelation.run(ctx, aborted, lambda p: False)
+    assert "aborted" in str(e.value)
+
+
+def test_feature_segmentation_from_files(ctx, tmp_path):
+    d = str(tmp_path)
+    frames = np.concatenate([O.synth_file(SEED, k, 300, NUM_CH) * np.float32(1.0 - 0.25 * (k % 2)) for k in range(4)])
+    meta = _write_entry(d, "piece", frames)
+    norms = norms_default()
+    _write_norms(d, norms)
+    cfg = FeatureSegmentation.Config(d, meta, Span(40 * STEP, 1100 * STEP), 22050, 0.5, True, 5, 22050)
+    got = FeatureSegmentation.run(ctx, cfg)
+    ocfg = O.SegmConfig(1, 1, 40 * STEP, 1100 * STEP, 22050, 0.5, 1, 5, 22050, STEP, NUM_CH - 1)
+    want, _ = O.segmentation_run(ocfg, frames, norms)
+    assert [(b.sim, b.pos) for b in got] == [(w.sim, w.pos) for w in want]
+
+
+def _read_png_rgb(path):
+    raw = open(path, "rb").read()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, w = 8, b"", None
+    while pos < len(raw):
+        n = int.from_bytes(raw[pos:pos + 4], "big")
+        typ = raw[pos + 4:pos + 8]
+        data = raw[pos + 8:pos + 8 + n]
+        assert zlib.crc32(typ + data) == int.from_bytes(raw[pos + 8 + n:pos + 12 + n], "big")
+        if typ == b"IHDR":
+            w, h = int.from_bytes(data[:4], "big"), int.from_bytes(data[4:8], "big")
+            assert data[8:10] == b"\x08\x02"
+        elif typ == b"IDAT":
+            idat += data
+        pos += 12 + n
+    px = np.frombuffer(zlib.decompress(idat), dtype=np.uint8).reshape(h, 1 + 3 * w)
+    assert np.all(px[:, 0] == 0)
+    return px[:, 1:].reshape(h, w, 3)
+
+
+def test_self_similarity_png(ctx, tmp_path):
+    d = str(tmp_path)
+    frames = O.synth_file(SEED, 5, 230, NUM_CH)
+    frames[120:160] = frames[30:70]
+    meta = _write_entry(d, "piece", frames)
+    norms = norms_default()
+    _write_norms(d, norms)
+    out = os.path.join(d, "sim.png")
+    cfg = SelfSimilarity.Config(d, meta, None, out, Span.all(), 8 * STEP, 2, 0.5, SelfSimilarity.GRAY, 1.0, 1.0, False,
+                                True)
+    SelfSimilarity.run(ctx, cfg)
+    ocfg = O.SelfSimConfig(0, 0, 0, 0, 8 * STEP, 2, 0.5, 0, 1.0, 1.0, 0, 1, STEP, NUM_CH - 1)
+    _, want = O.selfsim_run(ocfg, frames, None, norms)
+    rgb = _read_png_rgb(out)
+    assert rgb.shape == (want.shape[0], want.shape[1], 3)
+    dpx = np.abs(rgb[:, :, 2].astype(int) - (want & 0xFF))
+    assert dpx.max() <= 1 and (dpx > 0).mean() < 0.01
+    with pytest.raises(P.N.NativeError):
+        SelfSimilarity.run(ctx, SelfSimilarity.Config(d, meta, None, out, colors="psycho"))
