@@ -167,6 +167,9 @@ SGZ_API int sgz_corr_compact_device(sgz_context *ctx, int file_begin, int file_e
 /* Milliseconds the GPU spent in the last sgz_corr_run's correlation kernel
  * (HIP events on the context's stream); < 0 if none has completed. */
 SGZ_API float sgz_corr_last_kernel_ms(sgz_context *ctx);
+/* Same clock for whichever timed kernel ran last on the context (correlation or
+ * extraction). */
+SGZ_API float sgz_last_kernel_ms(sgz_context *ctx);
 /* Algorithmic work of the last sgz_corr_run: windows and floating point
  * operations (2 * numCh * L per window for the cross term). */
 SGZ_API int sgz_corr_last_work(const sgz_context *ctx, int64_t *windows, double *flops);
@@ -226,6 +229,26 @@ SGZ_API int sgz_selfsim_run(sgz_context *ctx, const float *frames1, int64_t num_
                     float temporal_weight, int colors, float color_warp, float color_ceil,
                     int color_inv, float *sim_out, int32_t *img_out);
 
+/* ---- FeatureExtraction --------------------------------------------------- */
+
+/* Feature frames an input of num_frames sample frames yields:
+ * ceil(num_frames / step) - 1 with step = fft_size / fft_overlap
+ * (impl/NonRealtimeProcessor.scala:93,107-108). */
+SGZ_API int64_t sgz_extract_num_frames(int64_t num_frames, int fft_size, int fft_overlap);
+
+/* Extracts [loudness / 32, mfcc 0 .. num_coeffs-1] per hop from interleaved PCM
+ * (host memory, num_frames x num_channels).  Takes the place of the scsynth
+ * non-realtime render of impl/FeatureExtractionImpl.scala:40-69 and
+ * impl/NonRealtimeProcessor.scala:57-160: same framing (mix-down per
+ * channels_behavior 0 = Mix / 1 = First / 2 = Last, Hann window, hop, channel
+ * order, frame count), own spectral model (42 mel bands, dB, DCT-II, A-weighted
+ * sones) since scsynth's is not part of the reference sources.  features_out
+ * receives *num_out frames of num_coeffs + 1 floats. */
+SGZ_API int sgz_extract(sgz_context *ctx, const float *pcm, int64_t num_frames, int num_channels,
+                        double sample_rate, int fft_size, int fft_overlap, int num_coeffs,
+                        int channels_behavior, float *features_out, int64_t capacity_frames,
+                        int64_t *num_out);
+
 /* ---- whole processors from their XML configs (host side) ------------------ */
 
 /* Progress observer: called with a value in [0, 1] between GPU launches; a
@@ -247,6 +270,10 @@ SGZ_API int sgz_run_segmentation_xml(sgz_context *ctx, const char *config_xml, s
 /* SelfSimilarity.run: <selfsimilarity> in (SelfSimilarity.scala:223-238); writes the
  * PNG named by <output>.  Replaces impl/SelfSimilarityImpl.body(). */
 SGZ_API int sgz_run_selfsimilarity_xml(sgz_context *ctx, const char *config_xml, sgz_progress_fn cb, void *user);
+/* FeatureExtraction.run: <feature> in (FeatureExtraction.scala:163-172); reads <input>,
+ * writes the feature AIFF <output> and, if <meta> is set, the config XML there.
+ * Replaces impl/FeatureExtractionImpl.body() (:31-78). */
+SGZ_API int sgz_run_extraction_xml(sgz_context *ctx, const char *config_xml, sgz_progress_fn cb, void *user);
 /* Text of the last failure of an sgz_run_* / sgz_*_xml / file call on this thread. */
 SGZ_API const char *sgz_host_last_error(void);
 SGZ_API void sgz_free_string(char *s);

@@ -144,6 +144,10 @@ def lib() -> C.CDLL:
         L.sgzo_synth_fill.argtypes = [C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.POINTER(Plant),
                                       C.c_int, fp]
         L.sgzo_synth_fill.restype = None
+        L.sgzo_extract_num_frames.argtypes = [C.c_int64, C.c_int]
+        L.sgzo_extract_num_frames.restype = C.c_int64
+        L.sgzo_extract.argtypes = [fp, C.c_int64, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, fp]
+        L.sgzo_extract.restype = C.c_int
         _lib = L
     return _lib
 
@@ -294,4 +298,19 @@ def synth_file_numpy(seed: int, file: int, num_frames: int, num_ch: int) -> np.n
     s = s * np.float32(0.125)
     out = s.copy()
     out[:, 0] = np.float32(0.05) + np.float32(1.45) * s[:, 0]
+    return out
+
+
+# ---- extraction (own spectral model; framing per the reference) ----------------
+def extract(pcm: np.ndarray, sample_rate: float, fft_size: int = 1024, fft_overlap: int = 2, num_coeffs: int = 13,
+            channels: int = 0) -> np.ndarray:
+    a = np.ascontiguousarray(pcm, dtype=np.float32)
+    if a.ndim == 1:
+        a = a[:, None]
+    n = lib().sgzo_extract_num_frames(a.shape[0], fft_size // fft_overlap)
+    out = np.zeros((n, num_coeffs + 1), dtype=np.float32)
+    rc = lib().sgzo_extract(_fp(a), a.shape[0], a.shape[1], sample_rate, fft_size, fft_overlap, num_coeffs, channels,
+                            _fp(out))
+    if rc != 0:
+        raise ValueError("oracle rejected the extraction arguments")
     return out

@@ -23,7 +23,12 @@
  *
  * Build: gcc -O2 -ffp-contract=off (no FMA contraction: the JVM does not fuse).
  */
+#define _USE_MATH_DEFINES
+#define _GNU_SOURCE
 #include <math.h>
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -752,4 +757,159 @@ SGZO_API void sgzo_synth_fill(uint64_t seed, int64_t file, int64_t frame0, int64
             out[(size_t)i * numCh + ch] = v;
         }
     }
+}
+
+/* ------------------------------------------------------------------------- */
+/* Feature extraction.                                                       */
+/*                                                                           */
+/* PARITY UNPINNED AND NOT A RESTATEMENT OF THE REFERENCE'S DSP: the         */
+/* reference delegates extraction to SuperCollider's scsynth (FFT, MFCC,     */
+/* Loudness UGens; impl/FeatureExtractionImpl.scala:40-55,                    */
+/* impl/NonRealtimeProcessor.scala:156-159), a third-party binary that is    */
+/* neither in the reference tree nor installed here, and whose filter tables */
+/* are not available offline.  What follows the reference is the FRAMING:    */
+/* channel mix-down (Mix = sum, First, Last; FeatureExtractionImpl:45-49),   */
+/* Hann window, hop = fftSize / fftOverlap, output channel order             */
+/* [loudness/32, mfcc 0..C-1] (:52-53), ceil(S/step) - 1 output frames of    */
+/* which the first is the empty analysis state (NonRealtimeProcessor:93,     */
+/* 107-108).  The spectral model itself (42 triangular mel bands, dB,        */
+/* DCT-II, A-weighted sones) is this build's own definition; this function   */
+/* is its fp64 statement, against which the fp32 GPU kernels are checked.    */
+/* ------------------------------------------------------------------------- */
+
+#define SGZO_NUM_BANDS 42
+
+static double mel_of_hz(double f) { return 2595.0 * log10(1.0 + f / 700.0); }
+static double hz_of_mel(double m) { return 700.0 * (pow(10.0, m / 2595.0) - 1.0); }
+
+/* Band edges in (fractional) FFT bins: NUM_BANDS + 2 points equally spaced in mel over 0 .. sr/2. */
+SGZO_API void sgzo_mel_edges(double sampleRate, int fftSize, double *edges /* [NUM_BANDS + 2] */)
+{
+    const double mHi = mel_of_hz(sampleRate * 0.5);
+    for (int j = 0; j < SGZO_NUM_BANDS + 2; j++) {
+        const double hz = hz_of_mel(mHi * j / (SGZO_NUM_BANDS + 1));
+        edges[j] = hz * fftSize / sampleRate;
+    }
+}
+
+/* A-weighting in dB at frequency f (IEC 61672 analytic form). */
+SGZO_API double sgzo_a_weight_db(double f)
+{
+    const double f2 = f * f;
+    const double num = 12194.0 * 12194.0 * f2 * f2;
+    const double den = (f2 + 20.6 * 20.6) * sqrt((f2 + 107.7 * 107.7) * (f2 + 737.9 * 737.9)) * (f2 + 12194.0 * 12194.0);
+    if (den == 0.0 || num == 0.0) return -100.0;
+    double a = 20.0 * log10(num / den) + 2.0;
+    if (a < -100.0) a = -100.0;
+    return a;
+}
+
+static void fft_inplace(double *re, double *im, int n)
+{
+    for (int i = 1, j = 0; i < n; i++) {
+        int bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) {
+            double t = re[i]; re[i] = re[j]; re[j] = t;
+            t = im[i]; im[i] = im[j]; im[j] = t;
+        }
+    }
+    for (int len = 2; len <= n; len <<= 1) {
+        const double ang = -2.0 * M_PI / len;
+        for (int i = 0; i < n; i += len) {
+            for (int k = 0; k < len / 2; k++) {
+                const double wr = cos(ang * k), wi = sin(ang * k);
+                const int a = i + k, b = i + k + len / 2;
+                const double xr = re[b] * wr - im[b] * wi, xi = re[b] * wi + im[b] * wr;
+                re[b] = re[a] - xr; im[b] = im[a] - xi;
+                re[a] += xr; im[a] += xi;
+            }
+        }
+    }
+}
+
+/* Number of feature frames for an input of numFrames sample frames (NonRealtimeProcessor.scala:93,107-108). */
+SGZO_API int64_t sgzo_extract_num_frames(int64_t numFrames, int stepSize)
+{
+    const int64_t outFrames = (numFrames + stepSize - 1) / stepSize;
+    return outFrames > 0 ? outFrames - 1 : 0;
+}
+
+/*
+ * pcm: interleaved [numFrames][numChannels]; out: [sgzo_extract_num_frames][numCoeffs + 1].
+ * Output frame i (stream index k = i + 1) shows the analysis of the most recent complete
+ * FFT frame at time k * step: the FFT frames end at fftSize + j * step, so that is frame
+ * j = k - fftOverlap, samples [(k - fftOverlap) * step, k * step); all zeros while
+ * k < fftOverlap (no FFT frame complete yet).  channels: 0 Mix (sum), 1 First, 2 Last.
+ */
+SGZO_API int sgzo_extract(const float *pcm, int64_t numFrames, int numChannels, double sampleRate,
+                          int fftSize, int fftOverlap, int numCoeffs, int channels, float *out)
+{
+    if (fftSize < 16 || (fftSize & (fftSize - 1)) || fftOverlap < 1 || fftSize % fftOverlap || numCoeffs < 1 ||
+        numCoeffs > SGZO_NUM_BANDS || numChannels < 1)
+        return -1;
+    const int step = fftSize / fftOverlap;
+    const int numCh = numCoeffs + 1;
+    const int64_t nOut = sgzo_extract_num_frames(numFrames, step);
+    double edges[SGZO_NUM_BANDS + 2];
+    sgzo_mel_edges(sampleRate, fftSize, edges);
+    double *re = (double *)malloc(sizeof(double) * fftSize);
+    double *im = (double *)malloc(sizeof(double) * fftSize);
+    double *pw = (double *)malloc(sizeof(double) * (fftSize / 2 + 1));
+    const double norm = 1.0 / ((double)fftSize * 0.25 * (double)fftSize * 0.25);  /* full-scale sine -> 1 */
+    double feat[SGZO_NUM_BANDS + 1];
+    memset(feat, 0, sizeof feat);
+    for (int64_t i = 0; i < nOut; i++) {
+        const int64_t k = i + 1;
+        const int64_t s0 = (k - fftOverlap) * step;
+        memset(feat, 0, sizeof feat);
+        if (k >= fftOverlap && s0 + fftSize <= numFrames) {
+            for (int n = 0; n < fftSize; n++) {
+                const float *fr = pcm + (size_t)(s0 + n) * numChannels;
+                double x;
+                if (channels == 1) x = fr[0];
+                else if (channels == 2) x = fr[numChannels - 1];
+                else {
+                    x = 0.0;
+                    for (int c = 0; c < numChannels; c++) x += fr[c];
+                }
+                const double w = 0.5 - 0.5 * cos(2.0 * M_PI * n / fftSize);
+                re[n] = x * w;
+                im[n] = 0.0;
+            }
+            fft_inplace(re, im, fftSize);
+            for (int b = 0; b <= fftSize / 2; b++) pw[b] = (re[b] * re[b] + im[b] * im[b]) * norm;
+            double db[SGZO_NUM_BANDS];
+            double loud = 0.0;
+            for (int j = 0; j < SGZO_NUM_BANDS; j++) {
+                const double e0 = edges[j], e1 = edges[j + 1], e2 = edges[j + 2];
+                int b0 = (int)ceil(e0), b1 = (int)floor(e2);
+                if (b1 > fftSize / 2) b1 = fftSize / 2;
+                double e = 0.0;
+                for (int b = b0; b <= b1; b++) {
+                    const double w = b <= e1 ? (e1 > e0 ? (b - e0) / (e1 - e0) : 1.0) : (e2 > e1 ? (e2 - b) / (e2 - e1) : 0.0);
+                    if (w > 0.0) e += w * pw[b];
+                }
+                double d = 100.0 + 10.0 * log10(e + 1e-10);
+                if (d < 0.0) d = 0.0;
+                db[j] = d;
+                const double fc = e1 * sampleRate / fftSize;
+                double phon = d + sgzo_a_weight_db(fc);
+                if (phon < 0.0) phon = 0.0;
+                loud += pow(2.0, (phon - 40.0) / 10.0);
+            }
+            feat[0] = loud / 32.0;
+            for (int c = 0; c < numCoeffs; c++) {
+                double s = 0.0;
+                for (int j = 0; j < SGZO_NUM_BANDS; j++) s += cos(M_PI / SGZO_NUM_BANDS * (j + 0.5) * c) * db[j];
+                feat[1 + c] = 0.5 + 0.5 * (s / SGZO_NUM_BANDS) / 100.0;
+            }
+        }
+        for (int c = 0; c < numCh; c++) out[(size_t)i * numCh + c] = (float)feat[c];
+    }
+    free(re);
+    free(im);
+    free(pw);
+    return 0;
 }

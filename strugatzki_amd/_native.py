@@ -82,6 +82,7 @@ SIGNATURES = {
     "sgz_corr_compact": (C.c_int, [_vp, C.c_int, C.c_int, C.c_float, _vp, C.c_int64, C.POINTER(C.c_int64)]),
     "sgz_corr_compact_device": (C.c_int, [_vp, C.c_int, C.c_int, C.c_float, _vp, C.c_int64, _vp]),
     "sgz_corr_last_kernel_ms": (C.c_float, [_vp]),
+    "sgz_last_kernel_ms": (C.c_float, [_vp]),
     "sgz_corr_last_work": (C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "sgz_sel_create": (_vp, [C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int]),
     "sgz_sel_destroy": (None, [_vp]),
@@ -102,6 +103,13 @@ SIGNATURES = {
         [_vp, _vp, C.c_int64, _vp, C.c_int64, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
          C.c_int, C.c_float, C.c_float, C.c_int, _vp, _vp],
     ),
+    "sgz_extract_num_frames": (C.c_int64, [C.c_int64, C.c_int, C.c_int]),
+    "sgz_extract": (
+        C.c_int,
+        [_vp, _vp, C.c_int64, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int64,
+         C.POINTER(C.c_int64)],
+    ),
+    "sgz_run_extraction_xml": (C.c_int, [_vp, C.c_char_p, _vp, _vp]),
     "sgz_run_correlation_xml": (C.c_int, [_vp, C.c_char_p, _vp, _vp, C.POINTER(_vp)]),
     "sgz_run_segmentation_xml": (C.c_int, [_vp, C.c_char_p, _vp, _vp, C.POINTER(_vp)]),
     "sgz_run_selfsimilarity_xml": (C.c_int, [_vp, C.c_char_p, _vp, _vp]),

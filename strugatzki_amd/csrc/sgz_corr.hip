@@ -991,6 +991,8 @@ float sgz_corr_last_kernel_ms(sgz_context *ctx)
     return ms;
 }
 
+float sgz_last_kernel_ms(sgz_context *ctx) { return sgz_corr_last_kernel_ms(ctx); }
+
 int sgz_corr_last_work(const sgz_context *ctx, int64_t *windows, double *flops)
 {
     if (!ctx) return SGZ_E_ARG;

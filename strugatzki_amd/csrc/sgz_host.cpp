@@ -334,6 +334,55 @@ void runSelfSimilarity(sgz_context *ctx, const SelfSimilarityConfig &cfg, const 
     notify(obs, 1.0);
 }
 
+// -----------------------------------------------------------------------------
+// FeatureExtraction: impl/FeatureExtractionImpl.scala:31-78, impl/NonRealtimeProcessor.scala:163-200
+// -----------------------------------------------------------------------------
+void runFeatureExtraction(sgz_context *ctx, const FeatureExtractionConfig &cfg, const Observer &obs)
+{
+    if (!ctx) throw Error(SGZ_E_ARG, "null context");
+    if (cfg.featureOutput.empty()) throw Error(SGZ_E_ARG, "featureOutput is not set");
+    if (cfg.fftOverlap < 1 || cfg.fftSize < cfg.fftOverlap) throw Error(SGZ_E_ARG, "bad fftSize / fftOverlap");
+    const AudioData in = readAudioFile(cfg.audioInput);  // :34
+    checkAborted(obs, 0.0);
+    const int stepSize = cfg.fftSize / cfg.fftOverlap;
+    const int numFeatures = cfg.numCoeffs + 1;
+    AudioData out;
+    out.numChannels = numFeatures;
+    out.sampleRate = in.sampleRate / stepSize;  // featRate, impl/NonRealtimeProcessor.scala:79,164
+    const int64_t n = sgz_extract_num_frames(in.numFrames, cfg.fftSize, cfg.fftOverlap);
+    if (n < 0) throw Error(SGZ_E_ARG, "bad fftSize / fftOverlap");
+    out.numFrames = n;
+    out.frames.resize((size_t)n * numFeatures);
+    int64_t got = 0;
+    check(ctx, sgz_extract(ctx, in.frames.data(), in.numFrames, in.numChannels, in.sampleRate, cfg.fftSize,
+                           cfg.fftOverlap, cfg.numCoeffs, (int)cfg.channelsBehavior, out.frames.data(), n, &got));
+    checkAborted(obs, 0.8);
+    // fixNaNs, impl/NonRealtimeProcessor.scala:178-190: NaN -> previous value of the channel, the memory
+    // starting at 0 in every 1024-frame chunk (the first chunk holds 1023 frames, :107-108)
+    int64_t pos = 0;
+    bool first = true;
+    while (pos < n) {
+        const int64_t len = std::min<int64_t>(n - pos, first ? 1023 : 1024);
+        for (int ch = 0; ch < numFeatures; ch++) {
+            float last = 0.0f;
+            for (int64_t i = pos; i < pos + len; i++) {
+                float &f = out.frames[(size_t)i * numFeatures + ch];
+                if (f != f) f = last; else last = f;
+            }
+        }
+        pos += len;
+        first = false;
+    }
+    writeFloatAiff(cfg.featureOutput, out);
+    if (cfg.metaOutput) {  // :72-77
+        std::ofstream f(*cfg.metaOutput, std::ios::trunc);
+        if (!f) throw Error(SGZ_E_IO, "cannot create " + *cfg.metaOutput);
+        f << "<?xml version='1.0' encoding='UTF-8'?>\n" << cfg.toXML() << "\n";
+        if (!f) throw Error(SGZ_E_IO, "cannot write " + *cfg.metaOutput);
+    }
+    notify(obs, 1.0);
+}
+
 }  // namespace strugatzki
 
 // -----------------------------------------------------------------------------
@@ -411,6 +460,15 @@ int sgz_run_selfsimilarity_xml(sgz_context *ctx, const char *config_xml, sgz_pro
     return guarded([&] {
         const auto cfg = strugatzki::SelfSimilarityConfig::fromXML(config_xml);
         strugatzki::runSelfSimilarity(ctx, cfg, makeObserver(cb, user));
+    });
+}
+
+int sgz_run_extraction_xml(sgz_context *ctx, const char *config_xml, sgz_progress_fn cb, void *user)
+{
+    if (!config_xml) return SGZ_E_ARG;
+    return guarded([&] {
+        const auto cfg = strugatzki::FeatureExtractionConfig::fromXML(config_xml);
+        strugatzki::runFeatureExtraction(ctx, cfg, makeObserver(cb, user));
     });
 }
 

@@ -182,6 +182,21 @@ class Context:
         return sim, img
 
 
+    # ---- extraction -----------------------------------------------------------
+    def extract(self, pcm: np.ndarray, sample_rate: float, fft_size: int = 1024, fft_overlap: int = 2,
+                num_coeffs: int = 13, channels_behavior: int = 0) -> np.ndarray:
+        """pcm: [frames][channels] (or 1-D mono) -> [featureFrames][num_coeffs + 1]."""
+        a = np.ascontiguousarray(pcm, dtype=np.float32)
+        if a.ndim == 1:
+            a = a[:, None]
+        n = max(0, lib.sgz_extract_num_frames(a.shape[0], fft_size, fft_overlap))
+        out = np.empty((max(n, 1), num_coeffs + 1), dtype=np.float32)
+        cnt = C.c_int64(0)
+        self._check(lib.sgz_extract(self._h, N.ptr(a), a.shape[0], a.shape[1], sample_rate, fft_size, fft_overlap,
+                                    num_coeffs, channels_behavior, N.ptr(out), out.shape[0], C.byref(cnt)))
+        return out[: cnt.value]
+
+
 class Selector:
     """Match bookkeeping of FeatureCorrelationImpl (host side, sgz_sel_*)."""
 
