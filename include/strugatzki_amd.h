@@ -141,6 +141,13 @@ SGZ_API int64_t sgz_corr_num_windows(const sgz_context *ctx, int file);
  * stream.  Replaces the sliding loop of impl/FeatureCorrelationImpl.scala:190-210
  * (calcBoost :75-78, correlate :414-421, MathUtil.stat/correlate/avg). */
 SGZ_API int sgz_corr_run(sgz_context *ctx, int file_begin, int file_end);
+/* Screening variant of sgz_corr_run: the cross terms are formed with fp32 products
+ * and fp32 partial sums (folded into fp64 after every channel block); window
+ * statistics, boost and the final division stay fp64.  Same outputs, similarities
+ * within a few 1e-7 of sgz_corr_run's; about twice the throughput.  Meant for
+ * the files of a search whose windows are afterwards filtered by a threshold and
+ * re-scored exactly (sgz_corr_rescore). */
+SGZ_API int sgz_corr_run_screen(sgz_context *ctx, int file_begin, int file_end);
 
 /* Copies sim / boost of all windows of one file to the host (either pointer
  * may be NULL).  Synchronises the stream. */
@@ -163,6 +170,17 @@ SGZ_API int sgz_corr_compact(sgz_context *ctx, int file_begin, int file_end, flo
 SGZ_API int sgz_corr_compact_device(sgz_context *ctx, int file_begin, int file_end, float threshold,
                             sgz_candidate *device_out, int64_t capacity,
                             unsigned long long *device_count);
+
+/* Re-evaluates the listed windows exactly (fp64, the reference's two-pass
+ * MathUtil.stat + MathUtil.correlate order of operations, straight from the raw
+ * frames) and overwrites their sim / boost.  `device_cands` / `device_count` are
+ * device memory as filled by sgz_corr_compact_device.  Asynchronous. */
+SGZ_API int sgz_corr_rescore_device(sgz_context *ctx, sgz_candidate *device_cands, int64_t capacity,
+                                    const unsigned long long *device_count);
+/* sgz_corr_compact followed by that exact re-scoring: the records returned carry
+ * exact similarities, selected by the (possibly screened) stored ones. */
+SGZ_API int sgz_corr_compact_rescored(sgz_context *ctx, int file_begin, int file_end, float threshold,
+                                      sgz_candidate *out, int64_t capacity, int64_t *count);
 
 /* Milliseconds the GPU spent in the last sgz_corr_run's correlation kernel
  * (HIP events on the context's stream); < 0 if none has completed. */

@@ -77,10 +77,13 @@ SIGNATURES = {
     "sgz_corr_set_target": (C.c_int, [_vp, _vp, C.c_int, C.c_float, C.c_float]),
     "sgz_corr_num_windows": (C.c_int64, [_vp, C.c_int]),
     "sgz_corr_run": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "sgz_corr_run_screen": (C.c_int, [_vp, C.c_int, C.c_int]),
     "sgz_corr_read_dense": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "sgz_corr_read_dense_range": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
     "sgz_corr_compact": (C.c_int, [_vp, C.c_int, C.c_int, C.c_float, _vp, C.c_int64, C.POINTER(C.c_int64)]),
     "sgz_corr_compact_device": (C.c_int, [_vp, C.c_int, C.c_int, C.c_float, _vp, C.c_int64, _vp]),
+    "sgz_corr_rescore_device": (C.c_int, [_vp, _vp, C.c_int64, _vp]),
+    "sgz_corr_compact_rescored": (C.c_int, [_vp, C.c_int, C.c_int, C.c_float, _vp, C.c_int64, C.POINTER(C.c_int64)]),
     "sgz_corr_last_kernel_ms": (C.c_float, [_vp]),
     "sgz_last_kernel_ms": (C.c_float, [_vp]),
     "sgz_corr_last_work": (C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),

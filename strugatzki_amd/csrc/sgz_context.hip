@@ -43,7 +43,7 @@ void sgz_destroy(sgz_context *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     for (auto &f : ctx->files)
         if (f.owned && f.d_raw) (void)hipFree(f.d_raw);
-    void *bufs[] = {ctx->d_aprime, ctx->d_files, ctx->d_tiles, ctx->d_ptiles, ctx->d_planar, ctx->d_prefix, ctx->d_tbase,
+    void *bufs[] = {ctx->d_aprime, ctx->d_aprime_f, ctx->d_tnorm, ctx->d_files, ctx->d_tiles, ctx->d_ptiles, ctx->d_planar, ctx->d_prefix, ctx->d_tbase,
                     ctx->d_sim,    ctx->d_boost, ctx->d_cand};
     for (void *b : bufs)
         if (b) (void)hipFree(b);

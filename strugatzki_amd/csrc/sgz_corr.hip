@@ -94,9 +94,10 @@ __global__ void synth_kernel(float *out, unsigned long long seed, long long file
 // so that both the frame-major fill and the chunk-major drain are (nearly)
 // conflict free.
 // ---------------------------------------------------------------------------
+template <typename T>
 __global__ __launch_bounds__(256) void prep_kernel(const FileDesc *__restrict__ files,
                                                    const PrepTile *__restrict__ ptiles,
-                                                   double *__restrict__ planar, double *__restrict__ prefix,
+                                                   T *__restrict__ planar, double *__restrict__ prefix,
                                                    double *__restrict__ tbase, NormParams nrm, int numCh, int cb,
                                                    double kT, double kS)
 {
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(256) void prep_kernel(const FileDesc *__restrict__ 
     __syncthreads();
 
     // phase 2: chunk-major planar fp64, centred; frames past the end are 0
-    double *dst = planar + fd.planar_off;
+    T *dst = planar + fd.planar_off;
     const int rows = numCh * kR;
     {
         // idx = tid + 256*k over [rows][cb]; cb is a power of two
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(256) void prep_kernel(const FileDesc *__restrict__ 
                 const long long fr = m * kR + j;
                 double v = 0.0;
                 if (fr < fd.frames) v = (double)xs[c * cstride + j * jstride + mm] - (c == 0 ? kT : kS);
-                dst[(long long)row * fd.M + m] = v;
+                dst[(long long)row * fd.M + m] = (T)v;
             }
         }
     }
@@ -272,18 +273,19 @@ __global__ __launch_bounds__(256) void tile_scan_kernel(const FileDesc *__restri
 // before and retired after the FMA work of the current phase.
 // Two workgroups per CU = 4 waves per SIMD: 2 x (64 KiB staging + 16 KiB sums).
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void load_chunk(double (&x)[kR], const double *p)
+template <typename T>
+__device__ __forceinline__ void load_chunk(T (&x)[kR], const T *p)
 {
 #pragma unroll
     for (int j = 0; j < kR; j++) x[j] = p[j * kMT];
 }
 
-__device__ __forceinline__ void fma_step(double (&acc)[kR], const double *__restrict__ a, const double (&x0)[kR],
-                                         const double (&x1)[kR])
+template <typename T>
+__device__ __forceinline__ void fma_step(T (&acc)[kR], const T *__restrict__ a, const T (&x0)[kR], const T (&x1)[kR])
 {
 #pragma unroll
     for (int q = 0; q < kR; q++) {
-        const double aq = a[q];
+        const T aq = a[q];
 #pragma unroll
         for (int r = 0; r < kR; r++) {
             const int k = q + r;
@@ -340,12 +342,15 @@ __device__ __forceinline__ void window_result(const CorrParams &cp, const Epilog
 }
 
 constexpr int kThreads = kWaves * 64;
-constexpr int kStageCols = 256;                           // columns one staging pass covers (>= kMT)
-constexpr int kStageIters = (kR * kStageCols) / (kThreads * 2);  // double2 copies per thread per block
-static_assert(kStageCols >= kMT && kMT % 2 == 0, "staging pass must cover a whole LDS row");
-constexpr int kStageDoubles = 2 * kR * kMT;               // two staging buffers
-constexpr int kRedDoubles = kR * 64;                      // one sum array (16 windows x 64 lanes)
-constexpr size_t kCorrLdsBytes = (size_t)(kStageDoubles + 2 * kRedDoubles) * sizeof(double);
+constexpr int kStageCols = 256;  // columns one staging pass covers (>= kMT)
+static_assert(kStageCols >= kMT && kMT % 4 == 0, "staging pass must cover a whole LDS row");
+constexpr int kRedDoubles = kR * 64;  // one sum array (16 windows x 64 lanes)
+
+template <typename T>
+constexpr size_t corr_lds_bytes()
+{
+    return (size_t)2 * kR * kMT * sizeof(T) + 2 * kRedDoubles * sizeof(double);
+}
 
 // Adds every wave's 16 partial sums into red[r][lane], wave 0 first.
 __device__ __forceinline__ void reduce_waves(double *red, const double (&acc)[kR], int wave, int lane)
@@ -362,37 +367,50 @@ __device__ __forceinline__ void reduce_waves(double *red, const double (&acc)[kR
     }
 }
 
+// T = double: the exact path.  T = float: the screening path -- fp32 products and
+// fp32 sums over one phase (<= 176 * 16 lags of one channel per wave), folded into
+// fp64 sums after every phase.
+template <typename T>
 __global__ __launch_bounds__(kThreads, 4) void corr_kernel(const FileDesc *__restrict__ files,
                                                            const TileDesc *__restrict__ tiles,
-                                                           const double *__restrict__ planar,
+                                                           const T *__restrict__ planar,
                                                            const double *__restrict__ prefix,
                                                            const double *__restrict__ tbase,
-                                                           const double *__restrict__ aprime, CorrParams cp,
+                                                           const T *__restrict__ aprime, CorrParams cp,
                                                            float *__restrict__ simOut,
                                                            float *__restrict__ boostOut)
 {
-    extern __shared__ __attribute__((aligned(16))) double lds[];  // 2 x [kR][kMT] + 2 x [kR][64]
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
+    T *lds = reinterpret_cast<T *>(ldsRaw);  // 2 x [kR][kMT] of T, then 2 x [kR][64] doubles
+    constexpr bool kExact = sizeof(T) == 8;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const TileDesc td = tiles[blockIdx.x];
     const FileDesc fd = files[td.file];
     const long long m0 = td.o0 / kR;
-    const double *fplanar = planar + fd.planar_off;
+    const T *fplanar = planar + fd.planar_off;
     const int Lpad = cp.S * kR;
     const int nPh = cp.numCh * cp.nb;
-    double *redS = lds + kStageDoubles;
+    double *redS = reinterpret_cast<double *>(ldsRaw + (size_t)2 * kR * kMT * sizeof(T));
     double *redT = redS + kRedDoubles;
 
-    double acc[kR];
+    T acc[kR];
+    double accD[kR];  // only used by the screening path
 #pragma unroll
-    for (int r = 0; r < kR; r++) acc[r] = 0.0;
+    for (int r = 0; r < kR; r++) {
+        acc[r] = (T)0;
+        accD[r] = 0.0;
+    }
 
-    // staging geometry: thread copies (row = it*rowsPerIt + tid/128, cols 2*(tid%128), +1)
-    constexpr int rowsPerIt = kThreads / (kStageCols / 2);
-    const int srow = tid / (kStageCols / 2);
-    const int scol = 2 * (tid % (kStageCols / 2));
-    double2 st[kStageIters];
+    // staging geometry: 16-byte vectors; thread copies row it*rowsPerIt + tid/vecPerRow, columns scol..scol+EV-1
+    constexpr int EV = 16 / sizeof(T);
+    constexpr int vecPerRow = kStageCols / EV;
+    constexpr int rowsPerIt = kThreads / vecPerRow;
+    constexpr int stageIters = kR / rowsPerIt;
+    const int srow = tid / vecPerRow;
+    const int scol = EV * (tid % vecPerRow);
+    float4 st[stageIters];
 
     auto stage_load = [&](int ph) {
         const int c = ph / cp.nb;
@@ -400,19 +418,19 @@ __global__ __launch_bounds__(kThreads, 4) void corr_kernel(const FileDesc *__res
         const int s0 = kb * cp.SB;
         const int scount = min(cp.SB, cp.S - s0);
         const int used = 64 + scount;  // chunks of this block that are read
-        const double *src = fplanar + ((long long)c * kR) * fd.M + m0 + s0 + scol;
+        const T *src = fplanar + ((long long)c * kR) * fd.M + m0 + s0 + scol;
 #pragma unroll
-        for (int it = 0; it < kStageIters; it++) {
+        for (int it = 0; it < stageIters; it++) {
             const int row = it * rowsPerIt + srow;
-            if (scol < used) st[it] = *reinterpret_cast<const double2 *>(src + (long long)row * fd.M);
+            if (scol < used) st[it] = *reinterpret_cast<const float4 *>(src + (long long)row * fd.M);
         }
     };
     auto stage_store = [&](int buf) {
-        double *dst = lds + buf * (kR * kMT) + scol;
+        T *dst = lds + buf * (kR * kMT) + scol;
 #pragma unroll
-        for (int it = 0; it < kStageIters; it++) {
+        for (int it = 0; it < stageIters; it++) {
             const int row = it * rowsPerIt + srow;
-            if (scol < kMT) *reinterpret_cast<double2 *>(dst + row * kMT) = st[it];
+            if (scol < kMT) *reinterpret_cast<float4 *>(dst + row * kMT) = st[it];
         }
     };
 
@@ -430,15 +448,15 @@ __global__ __launch_bounds__(kThreads, 4) void corr_kernel(const FileDesc *__res
         const int sb = (scount * wave) / kWaves;
         const int se = (scount * (wave + 1)) / kWaves;
         const int n = se - sb;
-        const double *a = aprime + (long long)c * Lpad + (long long)(s0 + sb) * kR;
-        const double *xp = lds + (ph & 1) * (kR * kMT) + lane + sb;
+        const T *a = aprime + (long long)c * Lpad + (long long)(s0 + sb) * kR;
+        const T *xp = lds + (ph & 1) * (kR * kMT) + lane + sb;
         // A second, opaque copy of the pointer keeps the compiler from pairing the
-        // loads of adjacent chunks into ds_read2_b64 (half the LDS rate of
-        // ds_read_b64, and its narrow offset field costs an address add per row).
-        const double *xq = xp + 1;
+        // loads of adjacent chunks into ds_read2 forms (half the LDS rate, and a
+        // narrow offset field that costs an address add per row).
+        const T *xq = xp + 1;
         asm volatile("" : "+v"(xq));
 
-        double xa[kR], xb[kR];
+        T xa[kR], xb[kR];
         load_chunk(xa, xp);
         int s = 0;
         for (; s + 2 <= n; s += 2) {
@@ -451,16 +469,40 @@ __global__ __launch_bounds__(kThreads, 4) void corr_kernel(const FileDesc *__res
             load_chunk(xb, xq + s);
             fma_step(acc, a + s * kR, xa, xb);
         }
+        if constexpr (!kExact) {
+#pragma unroll
+            for (int r = 0; r < kR; r++) {
+                accD[r] += (double)acc[r];
+                acc[r] = (T)0;
+            }
+        }
 
         if (ph + 1 < nPh) stage_store((ph + 1) & 1);
         __syncthreads();
         if (c == 0 && kb == cp.nb - 1) {  // loudness channel done: its sums go to redT
-            reduce_waves(redT, acc, wave, lane);
+            if constexpr (kExact) {
+                double tmp[kR];
 #pragma unroll
-            for (int r = 0; r < kR; r++) acc[r] = 0.0;
+                for (int r = 0; r < kR; r++) tmp[r] = (double)acc[r];
+                reduce_waves(redT, tmp, wave, lane);
+            } else {
+                reduce_waves(redT, accD, wave, lane);
+            }
+#pragma unroll
+            for (int r = 0; r < kR; r++) {
+                acc[r] = (T)0;
+                accD[r] = 0.0;
+            }
         }
     }
-    reduce_waves(redS, acc, wave, lane);
+    if constexpr (kExact) {
+        double tmp[kR];
+#pragma unroll
+        for (int r = 0; r < kR; r++) tmp[r] = (double)acc[r];
+        reduce_waves(redS, tmp, wave, lane);
+    } else {
+        reduce_waves(redS, accD, wave, lane);
+    }
 
     Epilogue ep;
     ep.pre = prefix + fd.prefix_off;
@@ -519,6 +561,90 @@ __global__ __launch_bounds__(256) void compact_kernel(const FileDesc *__restrict
     }
 }
 
+// ---------------------------------------------------------------------------
+// rescore_kernel: exact re-evaluation of listed windows, one workgroup per
+// window, straight from the raw frames with the reference's own two-pass
+// arithmetic (MathUtil.stat then MathUtil.correlate, impl/MathUtil.scala:29-62,
+// 177-196): fp32 normalise, fp64 mean, fp64 sums of (b - mean)^2 and of
+// (a - aMean)(b - bMean).  Sums are combined in a fixed tree order.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double block_sum_256(double v, double *scratch /* 4 doubles */)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    __syncthreads();  // scratch may still be read from the previous call
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
+}
+
+__global__ __launch_bounds__(256) void rescore_kernel(const FileDesc *__restrict__ files,
+                                                      const float *__restrict__ tnorm,  // [numCh][L] normalised target
+                                                      NormParams nrm, CorrParams cp, double aMeanT, double aMeanS,
+                                                      sgz_candidate *__restrict__ cands,
+                                                      const unsigned long long *__restrict__ count, long long capacity)
+{
+    __shared__ double scratch[4];
+    const long long n = min((long long)*count, capacity);
+    const int numCh = cp.numCh, L = cp.L;
+    for (long long ci = blockIdx.x; ci < n; ci += gridDim.x) {
+        const sgz_candidate cd = cands[ci];
+        const FileDesc fd = files[cd.file];
+        const float *raw = fd.raw + (long long)cd.offset * numCh;
+        // pass 1: sums
+        double sT = 0.0, sS = 0.0;
+        for (int i = threadIdx.x; i < L; i += 256) {
+            const float *fr = raw + (long long)i * numCh;
+            for (int c = 0; c < numCh; c++) {
+                float v = fr[c];
+                if (nrm.enabled) v = (v - nrm.mn[c]) / nrm.d[c];
+                if (c == 0) sT += (double)v; else sS += (double)v;
+            }
+        }
+        sT = block_sum_256(sT, scratch);
+        sS = block_sum_256(sS, scratch);
+        const double nT = (double)L, nS = (double)L * (double)(numCh - 1);
+        const double bMeanT = sT / nT, bMeanS = sS / nS;
+        // pass 2: squared deviations and cross terms
+        double qT = 0.0, qS = 0.0, xT = 0.0, xS = 0.0;
+        for (int i = threadIdx.x; i < L; i += 256) {
+            const float *fr = raw + (long long)i * numCh;
+            for (int c = 0; c < numCh; c++) {
+                float v = fr[c];
+                if (nrm.enabled) v = (v - nrm.mn[c]) / nrm.d[c];
+                const double a = (double)tnorm[(long long)c * L + i];
+                if (c == 0) {
+                    const double d = (double)v - bMeanT;
+                    qT += d * d;
+                    xT += (a - aMeanT) * d;
+                } else {
+                    const double d = (double)v - bMeanS;
+                    qS += d * d;
+                    xS += (a - aMeanS) * d;
+                }
+            }
+        }
+        qT = block_sum_256(qT, scratch);
+        qS = block_sum_256(qS, scratch);
+        xT = block_sum_256(xT, scratch);
+        xS = block_sum_256(xS, scratch);
+        if (threadIdx.x == 0) {
+            const float avgF = (float)bMeanT;
+            const double lnAvgB = log((double)avgF);
+            const float boost = (float)exp((cp.lnAvgIn - lnAvgB) / 0.6);
+            float sim = 0.0f;
+            if (boost <= cp.maxBoost) {
+                float temporal = 0.0f, spectral = 0.0f;
+                if (cp.w > 0.0f) temporal = (float)(xT / (cp.aStdT * sqrt(qT / nT) * nT));
+                if (cp.w < 1.0f) spectral = (float)(xS / (cp.aStdS * sqrt(qS / nS) * nS));
+                sim = temporal * cp.w + spectral * (1.0f - cp.w);
+            }
+            cands[ci].sim = sim;
+            cands[ci].boost = boost;
+        }
+    }
+}
+
 // Picks the chunks-per-tile of prep_kernel so that its LDS image stays <= 64 KiB.
 int pick_prep_cb(int numCh)
 {
@@ -550,10 +676,10 @@ int build_layout(sgz_context *ctx)
         fd.frames = ctx->files[f].frames;
         fd.num_windows = fd.frames >= L ? fd.frames - L + 1 : 0;
         const long long ntiles = (fd.num_windows + kTileW - 1) / kTileW;
-        long long M = ntiles * 64 + S + 2;
+        long long M = ntiles * 64 + S + 8;  // slack: staging copies whole 16-byte vectors
         const long long need = (fd.frames + kR - 1) / kR;
         if (M < need) M = need;
-        M = (M + 1) & ~1ll;
+        M = (M + 3) & ~3ll;
         fd.M = M;
         fd.planar_off = planar;
         fd.prefix_off = prefix;
@@ -776,7 +902,7 @@ int sgz_corr_set_target(sgz_context *ctx, const float *frames, int num_frames, f
     cp.S = S;
     cp.nb = (S + kSBMax - 1) / kSBMax;
     int SB = (S + cp.nb - 1) / cp.nb;
-    SB = (SB + 1) & ~1;
+    SB = (SB + 3) & ~3;  // staged blocks start on 16-byte boundaries for both element types
     cp.SB = SB;
     cp.kT = tMean;
     cp.kS = sMean;
@@ -803,6 +929,14 @@ int sgz_corr_set_target(sgz_context *ctx, const float *frames, int num_frames, f
     SGZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if ((rc = ensure(ctx, ctx->d_aprime, ctx->aprime_cap, ap.size()))) return rc;
     SGZ_HIP(ctx, hipMemcpy(ctx->d_aprime, ap.data(), sizeof(double) * ap.size(), hipMemcpyHostToDevice));
+    if ((rc = ensure(ctx, ctx->d_tnorm, ctx->tnorm_cap, tb.size()))) return rc;
+    SGZ_HIP(ctx, hipMemcpy(ctx->d_tnorm, tb.data(), sizeof(float) * tb.size(), hipMemcpyHostToDevice));
+    ctx->aMeanT = tMean;
+    ctx->aMeanS = sMean;
+    std::vector<float> apf(ap.size());
+    for (size_t i = 0; i < ap.size(); i++) apf[i] = (float)ap[i];
+    if ((rc = ensure(ctx, ctx->d_aprime_f, ctx->aprime_f_cap, apf.size()))) return rc;
+    SGZ_HIP(ctx, hipMemcpy(ctx->d_aprime_f, apf.data(), sizeof(float) * apf.size(), hipMemcpyHostToDevice));
     ctx->have_target = true;
     if (oldL != L) ctx->layout_dirty = true;
     return SGZ_OK;
@@ -815,7 +949,16 @@ int64_t sgz_corr_num_windows(const sgz_context *ctx, int file)
     return n >= ctx->cp.L ? n - ctx->cp.L + 1 : 0;
 }
 
-int sgz_corr_run(sgz_context *ctx, int file_begin, int file_end)
+static int corr_run_impl(sgz_context *ctx, int file_begin, int file_end, bool exact);
+
+int sgz_corr_run(sgz_context *ctx, int file_begin, int file_end) { return corr_run_impl(ctx, file_begin, file_end, true); }
+
+int sgz_corr_run_screen(sgz_context *ctx, int file_begin, int file_end)
+{
+    return corr_run_impl(ctx, file_begin, file_end, false);
+}
+
+static int corr_run_impl(sgz_context *ctx, int file_begin, int file_end, bool exact)
 {
     if (!ctx) return SGZ_E_ARG;
     if (!ctx->have_target) return ctx->fail(SGZ_E_STATE, "sgz_corr_set_target has not been called");
@@ -843,24 +986,29 @@ int sgz_corr_run(sgz_context *ctx, int file_begin, int file_end)
 
     const int cb = ctx->prep_cb;
     const size_t prepLds = (size_t)ctx->numCh * (kR * (cb + 1) + 1) * sizeof(float);
-    hipLaunchKernelGGL(prep_kernel, dim3(pt1 - pt0), dim3(256), prepLds, ctx->stream, ctx->d_files,
-                       ctx->d_ptiles + pt0, ctx->d_planar, ctx->d_prefix, ctx->d_tbase, ctx->norm, ctx->numCh, cb, ctx->cp.kT,
-                       ctx->cp.kS);
+    float *planarF = reinterpret_cast<float *>(ctx->d_planar);  // the screening path stores the planar image as fp32
+    if (exact)
+        hipLaunchKernelGGL(prep_kernel<double>, dim3(pt1 - pt0), dim3(256), prepLds, ctx->stream, ctx->d_files,
+                           ctx->d_ptiles + pt0, ctx->d_planar, ctx->d_prefix, ctx->d_tbase, ctx->norm, ctx->numCh, cb,
+                           ctx->cp.kT, ctx->cp.kS);
+    else
+        hipLaunchKernelGGL(prep_kernel<float>, dim3(pt1 - pt0), dim3(256), prepLds, ctx->stream, ctx->d_files,
+                           ctx->d_ptiles + pt0, planarF, ctx->d_prefix, ctx->d_tbase, ctx->norm, ctx->numCh, cb,
+                           ctx->cp.kT, ctx->cp.kS);
     SGZ_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(tile_scan_kernel, dim3(file_end - file_begin), dim3(256), 0, ctx->stream, ctx->d_files,
                        file_begin, ctx->d_tbase);
     SGZ_HIP(ctx, hipGetLastError());
-    const size_t corrLds = kCorrLdsBytes;
-    if (getenv("SGZ_DEBUG")) {
-        int nb = -1;
-        hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, corr_kernel, kThreads, corrLds);
-        fprintf(stderr, "[sgz] corr_kernel: %d tiles, lds %zu B, max active blocks/CU %d (%s)\n", t1 - t0, corrLds,
-                nb, hipGetErrorString(oe));
-    }
+    const size_t corrLds = exact ? corr_lds_bytes<double>() : corr_lds_bytes<float>();
     SGZ_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    hipLaunchKernelGGL(corr_kernel, dim3(t1 - t0), dim3(kThreads), corrLds, ctx->stream, ctx->d_files,
-                       ctx->d_tiles + t0, ctx->d_planar, ctx->d_prefix, ctx->d_tbase, ctx->d_aprime, ctx->cp, ctx->d_sim,
-                       ctx->d_boost);
+    if (exact)
+        hipLaunchKernelGGL(corr_kernel<double>, dim3(t1 - t0), dim3(kThreads), corrLds, ctx->stream, ctx->d_files,
+                           ctx->d_tiles + t0, ctx->d_planar, ctx->d_prefix, ctx->d_tbase, ctx->d_aprime, ctx->cp,
+                           ctx->d_sim, ctx->d_boost);
+    else
+        hipLaunchKernelGGL(corr_kernel<float>, dim3(t1 - t0), dim3(kThreads), corrLds, ctx->stream, ctx->d_files,
+                           ctx->d_tiles + t0, planarF, ctx->d_prefix, ctx->d_tbase, ctx->d_aprime_f, ctx->cp,
+                           ctx->d_sim, ctx->d_boost);
     SGZ_HIP(ctx, hipGetLastError());
     SGZ_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     ctx->ev_valid = true;
@@ -947,8 +1095,38 @@ int sgz_corr_compact_device(sgz_context *ctx, int file_begin, int file_end, floa
     return SGZ_OK;
 }
 
+int sgz_corr_rescore_device(sgz_context *ctx, sgz_candidate *device_cands, int64_t capacity,
+                            const unsigned long long *device_count)
+{
+    if (!ctx) return SGZ_E_ARG;
+    if (ctx->layout_dirty || !ctx->have_target) return ctx->fail(SGZ_E_STATE, "no correlation results");
+    if (!device_count || capacity < 0 || (capacity > 0 && !device_cands)) return ctx->fail(SGZ_E_ARG, "bad buffers");
+    if (capacity == 0) return SGZ_OK;
+    SGZ_HIP(ctx, hipSetDevice(ctx->device));
+    const int grid = (int)std::min<int64_t>(capacity, 4096);
+    hipLaunchKernelGGL(rescore_kernel, dim3(grid), dim3(256), 0, ctx->stream, ctx->d_files, ctx->d_tnorm, ctx->norm,
+                       ctx->cp, ctx->aMeanT, ctx->aMeanS, device_cands, device_count, (long long)capacity);
+    SGZ_HIP(ctx, hipGetLastError());
+    return SGZ_OK;
+}
+
+static int compact_host(sgz_context *ctx, int file_begin, int file_end, float threshold, bool rescore,
+                        sgz_candidate *out, int64_t capacity, int64_t *count);
+
+int sgz_corr_compact_rescored(sgz_context *ctx, int file_begin, int file_end, float threshold, sgz_candidate *out,
+                              int64_t capacity, int64_t *count)
+{
+    return compact_host(ctx, file_begin, file_end, threshold, true, out, capacity, count);
+}
+
 int sgz_corr_compact(sgz_context *ctx, int file_begin, int file_end, float threshold, sgz_candidate *out,
                      int64_t capacity, int64_t *count)
+{
+    return compact_host(ctx, file_begin, file_end, threshold, false, out, capacity, count);
+}
+
+static int compact_host(sgz_context *ctx, int file_begin, int file_end, float threshold, bool rescore,
+                        sgz_candidate *out, int64_t capacity, int64_t *count)
 {
     if (!ctx) return SGZ_E_ARG;
     if (!count || capacity < 0 || (capacity > 0 && !out)) return ctx->fail(SGZ_E_ARG, "bad output buffers");
@@ -959,6 +1137,7 @@ int sgz_corr_compact(sgz_context *ctx, int file_begin, int file_end, float thres
     unsigned long long *d_count = reinterpret_cast<unsigned long long *>(ctx->d_cand);
     if ((rc = sgz_corr_compact_device(ctx, file_begin, file_end, threshold, ctx->d_cand + 1, capacity, d_count)))
         return rc;
+    if (rescore && (rc = sgz_corr_rescore_device(ctx, ctx->d_cand + 1, capacity, d_count))) return rc;
     // first transfer: header + as many records as usually suffice
     const size_t first = (size_t)std::min<int64_t>(capacity, 1023);
     ctx->h_cand.resize(first + 1);

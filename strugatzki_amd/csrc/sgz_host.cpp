@@ -181,9 +181,13 @@ std::vector<Match> runFeatureCorrelation(sgz_context *ctx, const FeatureCorrelat
     } guard{sel};
 
     // GPU: all similarities; host: replay of the match bookkeeping in file order
+    // Head files: exact fp64 kernel, fed densely.  Tail files: screening kernel (fp32 products); the windows
+    // within `margin` of the bound are re-scored exactly on the GPU before they are fed.
     const int head = std::min(nf, std::max(cfg.numMatches, 1));
+    const float margin = 1e-5f;
+    bool screened = head < nf;
     check(ctx, sgz_corr_run(ctx, 0, head));
-    if (head < nf) check(ctx, sgz_corr_run(ctx, head, nf));
+    if (head < nf) check(ctx, sgz_corr_run_screen(ctx, head, nf));
     std::vector<float> sim, boost;
     auto feedDense = [&](int f0, int f1) {
         int64_t total = 0;
@@ -202,6 +206,10 @@ std::vector<Match> runFeatureCorrelation(sgz_context *ctx, const FeatureCorrelat
     feedDense(0, head);
     checkAborted(obs, 0.6);
     int f = head;
+    if (f < nf && !sgz_sel_is_full(sel) && screened) {  // dense feeding needs exact values
+        check(ctx, sgz_corr_run(ctx, f, nf));
+        screened = false;
+    }
     while (f < nf && !sgz_sel_is_full(sel)) {
         feedDense(f, f + 1);
         f++;
@@ -210,8 +218,11 @@ std::vector<Match> runFeatureCorrelation(sgz_context *ctx, const FeatureCorrelat
         const int64_t cap = 1 << 16;
         std::vector<sgz_candidate> cands((size_t)cap);
         int64_t count = 0;
-        const int rc = sgz_corr_compact(ctx, f, nf, sgz_sel_threshold(sel), cands.data(), cap, &count);
+        const int rc = screened ? sgz_corr_compact_rescored(ctx, f, nf, sgz_sel_threshold(sel) - margin, cands.data(),
+                                                            cap, &count)
+                                : sgz_corr_compact(ctx, f, nf, sgz_sel_threshold(sel), cands.data(), cap, &count);
         if (rc == SGZ_E_OVERFLOW) {
+            if (screened) check(ctx, sgz_corr_run(ctx, f, nf));
             for (int g = f; g < nf; g++) feedDense(g, g + 1);
         } else {
             check(ctx, rc);

@@ -85,6 +85,11 @@ struct sgz_context {
     sgz::CorrParams cp{};
     double *d_aprime = nullptr;  // [numCh][S * kR] centred target, fp64
     size_t aprime_cap = 0;
+    float *d_tnorm = nullptr;     // [numCh][L] normalised target, fp32 (exact re-scoring)
+    size_t tnorm_cap = 0;
+    double aMeanT = 0.0, aMeanS = 0.0;
+    float *d_aprime_f = nullptr;  // the same, rounded to fp32 (screening path)
+    size_t aprime_f_cap = 0;
 
     // layout (depends on db + target length)
     bool layout_dirty = true;

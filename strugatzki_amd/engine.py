@@ -109,6 +109,11 @@ class Context:
             file_end = self.num_files
         self._check(lib.sgz_corr_run(self._h, file_begin, file_end))
 
+    def corr_run_screen(self, file_begin: int = 0, file_end: int | None = None) -> None:
+        if file_end is None:
+            file_end = self.num_files
+        self._check(lib.sgz_corr_run_screen(self._h, file_begin, file_end))
+
     def corr_read_dense(self, file: int) -> tuple[np.ndarray, np.ndarray]:
         n = max(0, self.corr_num_windows(file))
         sim = np.empty(n, dtype=np.float32)
@@ -129,11 +134,14 @@ class Context:
             pos += n
         return out
 
-    def corr_compact(self, file_begin: int, file_end: int, threshold: float, capacity: int) -> np.ndarray:
-        """Candidates with sim > threshold, sorted by (file, offset); raises on overflow."""
+    def corr_compact(self, file_begin: int, file_end: int, threshold: float, capacity: int,
+                     rescore: bool = False) -> np.ndarray:
+        """Candidates with sim > threshold, sorted by (file, offset); raises on overflow.
+        rescore=True replaces their sim / boost by the exact fp64 re-evaluation."""
         out = np.empty(max(capacity, 1), dtype=N.CANDIDATE_DTYPE)
         cnt = C.c_int64(0)
-        rc = lib.sgz_corr_compact(self._h, file_begin, file_end, threshold, N.ptr(out), capacity, C.byref(cnt))
+        fn = lib.sgz_corr_compact_rescored if rescore else lib.sgz_corr_compact
+        rc = fn(self._h, file_begin, file_end, threshold, N.ptr(out), capacity, C.byref(cnt))
         self._check(rc)
         return out[: cnt.value]
 
@@ -141,6 +149,9 @@ class Context:
                             capacity: int, count_ptr: int) -> None:
         self._check(lib.sgz_corr_compact_device(self._h, file_begin, file_end, threshold,
                                                 C.c_void_p(out_ptr), capacity, C.c_void_p(count_ptr)))
+
+    def corr_rescore_device(self, cands_ptr: int, capacity: int, count_ptr: int) -> None:
+        self._check(lib.sgz_corr_rescore_device(self._h, C.c_void_p(cands_ptr), capacity, C.c_void_p(count_ptr)))
 
     def corr_last_kernel_ms(self) -> float:
         return float(lib.sgz_corr_last_kernel_ms(self._h))

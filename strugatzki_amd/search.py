@@ -10,7 +10,11 @@ replayed on the host in file order:
      entries.  From then on a window can only be offered if its sim exceeds
      the sim of the worst global entry, and that bound never falls.
   2. "tail": for all remaining files only windows above that bound are fetched
-     from the GPU (stream compaction) and fed in file / offset order.
+     from the GPU (stream compaction) and fed in file / offset order.  By default
+     the tail similarities come from the screening kernel (fp32 products, about
+     1e-7 off); windows within `margin` of the bound are re-scored exactly in
+     fp64 on the GPU before they are fed, so the result is the one the exact
+     kernel gives.
 
 Sharded over several GPUs (one process each), every rank holds the head files
 plus its own slice of the tail; the ranks exchange their tail candidates with
@@ -35,6 +39,8 @@ class SearchParams:
     min_spacing: int = 0      # sample frames
     step_size: int = 512      # fftSize / fftOverlap
     capacity: int = 1 << 16   # candidate records fetched per rank
+    screen: bool = True       # tail files: fp32-product screening kernel + exact re-scoring of the candidates
+    margin: float = 1e-5      # screening keeps windows with sim > T0 - margin (screen error is ~1e-7)
 
 
 def _feed_dense_head(ctx: Context, sel: Selector, files: Sequence[int], global_ids: Sequence[int]) -> int:
@@ -55,9 +61,13 @@ def search(ctx: Context, p: SearchParams) -> list[N.Match]:
     sel = Selector(p.num_matches, p.num_per_file, p.min_spacing, p.step_size, ctx.target_frames)
     head = min(nf, max(p.num_matches, 1))
     ctx.corr_run(0, head)
+    screened = p.screen and head < nf
     if head < nf:
-        ctx.corr_run(head, nf)
+        (ctx.corr_run_screen if screened else ctx.corr_run)(head, nf)
     f = _feed_dense_head(ctx, sel, range(head), range(head))
+    if f < nf and not sel.is_full and screened:  # dense feeding needs exact values
+        ctx.corr_run(f, nf)
+        screened = False
     # rare: equal sims collapsed entries, the set is not full yet -> keep feeding densely
     while f < nf and not sel.is_full:
         sim, boost = ctx.corr_read_dense(f)
@@ -65,12 +75,15 @@ def search(ctx: Context, p: SearchParams) -> list[N.Match]:
         f += 1
     if f < nf:
         try:
-            cands = ctx.corr_compact(f, nf, sel.threshold, p.capacity)
+            thr = sel.threshold - p.margin if screened else sel.threshold
+            cands = ctx.corr_compact(f, nf, thr, p.capacity, rescore=screened)
         except N.NativeError as e:
             if e.code != N.SGZ_E_OVERFLOW:
                 raise
             cands = None
         if cands is None:  # more candidates than the buffer holds: dense replay of the tail
+            if screened:
+                ctx.corr_run(f, nf)
             for g in range(f, nf):
                 sim, boost = ctx.corr_read_dense(g)
                 sel.feed_dense(g, sim, boost)
@@ -131,7 +144,7 @@ def search_sharded(ctx: Context, p: SearchParams, head_global: Sequence[int], ta
     sel = Selector(p.num_matches, p.num_per_file, p.min_spacing, p.step_size, ctx.target_frames)
     ctx.corr_run(0, nh)
     if nt:
-        ctx.corr_run(nh, nh + nt)
+        (ctx.corr_run_screen if p.screen else ctx.corr_run)(nh, nh + nt)
     _feed_dense_head(ctx, sel, range(nh), head_global)
     if not sel.is_full:  # every rank replayed the same head, so all ranks agree on this
         raise RuntimeError("head files did not fill the match set; enlarge the head (degenerate equal sims)")
@@ -140,7 +153,10 @@ def search_sharded(ctx: Context, p: SearchParams, head_global: Sequence[int], ta
     rec = torch.zeros((cap, 4), dtype=torch.int32, device=dev)
     cnt = torch.zeros(1, dtype=torch.int64, device=dev)
     torch.cuda.current_stream().synchronize()  # buffers are zeroed before the library's stream writes them
-    ctx.corr_compact_device(nh, nh + nt, sel.threshold, rec.data_ptr(), cap, cnt.data_ptr())
+    thr = sel.threshold - p.margin if p.screen else sel.threshold
+    ctx.corr_compact_device(nh, nh + nt, thr, rec.data_ptr(), cap, cnt.data_ptr())
+    if p.screen:
+        ctx.corr_rescore_device(rec.data_ptr(), cap, cnt.data_ptr())
     ctx.synchronize()
     n_local = min(int(cnt.item()), cap)
     if n_local:  # local file index -> global id

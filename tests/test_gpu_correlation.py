@@ -125,6 +125,49 @@ def test_search_matches_bit_exact(ctx, num_matches, num_per_file, min_spacing):
         assert g.boost_out == 1.0
 
 
+@pytest.mark.parametrize("L,frames", [(64, 400), (431, 2583), (3300, 5000)])
+def test_screening_kernel_and_exact_rescoring(ctx, L, frames):
+    """fp32-product screening stays within 1e-5 (in fact ~1e-7) of the oracle; re-scored candidates are exact."""
+    ts, nf = 20, 3
+    db = synth_db(nf, frames, make_plants(2, L, nf, frames, ts))
+    tgt = synth_target(ts, L)
+    norms = norms_default()
+    _, sims, boosts = O.correlation_run(corr_config(ts, L, num_matches=3), tgt, norms, db)
+    _load(ctx, db, norms)
+    ctx.corr_set_target(tgt[ts:ts + L], 0.5, 8.0)
+    ctx.corr_run_screen(0, nf)
+    for f in range(nf):
+        gs, gb = ctx.corr_read_dense(f)
+        np.testing.assert_allclose(gs, sims[f], rtol=0, atol=TOL)
+        assert float(np.max(np.abs(gs - sims[f]))) < 2e-6
+        np.testing.assert_allclose(gb, boosts[f], rtol=2e-6, atol=0)
+    thr = 0.2
+    cands = ctx.corr_compact(0, nf, thr, 1 << 16, rescore=True)
+    assert len(cands) > 0
+    for c in cands:
+        want = sims[c["file"]][c["offset"]]
+        assert abs(float(c["sim"]) - float(want)) <= 1.2e-7  # one fp32 ulp at most: same fp64 arithmetic as the oracle
+        assert c["boost"] == pytest.approx(boosts[c["file"]][c["offset"]], rel=2e-6)
+
+
+@pytest.mark.parametrize("screen", [False, True])
+def test_search_screened_equals_exact(ctx, screen):
+    import strugatzki_amd as S
+    L, ts, nf, frames = 96, 17, 24, 900
+    plants = make_plants(8, L, nf, frames, ts)
+    db = synth_db(nf, frames, plants)
+    tgt = synth_target(ts, L)
+    norms = norms_default()
+    cfg = corr_config(ts, L, num_matches=6, num_per_file=2, min_spacing=10 * STEP)
+    want, _, _ = O.correlation_run(cfg, tgt, norms, db, dense=False)
+    _load(ctx, db, norms)
+    ctx.corr_set_target(tgt[ts:ts + L], 0.5, 8.0)
+    got = S.search(ctx, S.SearchParams(6, 2, 10 * STEP, STEP, screen=screen))
+    assert [(g.file, g.start, g.stop) for g in got] == [(w.file, w.start, w.stop) for w in want]
+    for g, w in zip(got, want):
+        assert abs(g.sim - w.sim) <= 1.2e-7
+
+
 def test_search_falls_back_to_dense_on_candidate_overflow(ctx):
     import strugatzki_amd as S
     L, ts, nf, frames = 64, 4, 6, 500
