@@ -206,6 +206,10 @@ SGZ_API void sgz_sel_destroy(sgz_selector *sel);
  * order.  Leaving out windows is legal iff they could not pass the gate. */
 SGZ_API int sgz_sel_feed_file(sgz_selector *sel, int file, int64_t n, const int32_t *offsets,
                       const float *sims, const float *boosts);
+/* Feeds a whole candidate list, sorted by (file, offset): one sgz_sel_feed_file per
+ * file that occurs in it, in ascending file order (files without candidates
+ * need no call: nothing of theirs could pass the gate). */
+SGZ_API int sgz_sel_feed_candidates(sgz_selector *sel, const sgz_candidate *cands, int64_t n);
 /* 1 once allPrio holds num_matches entries: from then on only windows with
  * sim > sgz_sel_threshold() can still be offered. */
 SGZ_API int sgz_sel_is_full(const sgz_selector *sel);

@@ -27,7 +27,9 @@ int sgz_create(int device, void *hip_stream, sgz_context **out)
         }
         ctx->own_stream = true;
     }
-    if (hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->screen_stream, hipStreamNonBlocking) != hipSuccess) {
+        if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
         if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
         delete ctx;
         return SGZ_E_HIP;
@@ -41,15 +43,17 @@ void sgz_destroy(sgz_context *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->screen_stream) (void)hipStreamSynchronize(ctx->screen_stream);
     for (auto &f : ctx->files)
         if (f.owned && f.d_raw) (void)hipFree(f.d_raw);
-    void *bufs[] = {ctx->d_aprime, ctx->d_aprime_f, ctx->d_tnorm, ctx->d_files, ctx->d_tiles, ctx->d_ptiles, ctx->d_planar, ctx->d_prefix, ctx->d_tbase,
+    void *bufs[] = {ctx->d_planar_f, ctx->d_aprime, ctx->d_aprime_f, ctx->d_tnorm, ctx->d_files, ctx->d_tiles, ctx->d_ptiles, ctx->d_planar, ctx->d_prefix, ctx->d_tbase,
                     ctx->d_sim,    ctx->d_boost, ctx->d_cand};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     for (auto &r : ctx->runs) (void)hipEventDestroy(r.done);
     for (auto &e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    if (ctx->screen_stream) (void)hipStreamDestroy(ctx->screen_stream);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -63,6 +67,7 @@ int sgz_synchronize(sgz_context *ctx)
     if (!ctx) return SGZ_E_ARG;
     SGZ_HIP(ctx, hipSetDevice(ctx->device));
     SGZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SGZ_HIP(ctx, hipStreamSynchronize(ctx->screen_stream));
     return SGZ_OK;
 }
 

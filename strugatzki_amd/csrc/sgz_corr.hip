@@ -453,8 +453,10 @@ __global__ __launch_bounds__(kThreads, 4) void corr_kernel(const FileDesc *__res
         // A second, opaque copy of the pointer keeps the compiler from pairing the
         // loads of adjacent chunks into ds_read2 forms (half the LDS rate, and a
         // narrow offset field that costs an address add per row).
-        const T *xq = xp + 1;
-        asm volatile("" : "+v"(xq));
+        // (The offset, not the pointer, is made opaque: the pointer keeps its LDS address space.)
+        int one = 1;
+        asm volatile("" : "+v"(one));
+        const T *xq = xp + one;
 
         T xa[kR], xb[kR];
         load_chunk(xa, xp);
@@ -657,6 +659,8 @@ int pick_prep_cb(int numCh)
 
 int build_layout(sgz_context *ctx)
 {
+    SGZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SGZ_HIP(ctx, hipStreamSynchronize(ctx->screen_stream));
     const int L = ctx->cp.L;
     const int S = ctx->cp.S;
     const int nf = (int)ctx->files.size();
@@ -706,6 +710,7 @@ int build_layout(sgz_context *ctx)
     if ((rc = ensure(ctx, ctx->d_tiles, ctx->d_tiles_cap, ctx->h_tiles.size()))) return rc;
     if ((rc = ensure(ctx, ctx->d_ptiles, ctx->d_ptiles_cap, ctx->h_ptiles.size()))) return rc;
     if ((rc = ensure(ctx, ctx->d_planar, ctx->planar_cap, (size_t)planar))) return rc;
+    if ((rc = ensure(ctx, ctx->d_planar_f, ctx->planar_f_cap, (size_t)planar))) return rc;
     if ((rc = ensure(ctx, ctx->d_prefix, ctx->prefix_cap, (size_t)prefix))) return rc;
     if ((rc = ensure(ctx, ctx->d_tbase, ctx->tbase_cap, (size_t)tb))) return rc;
     if ((rc = ensure(ctx, ctx->d_sim, ctx->dense_cap, (size_t)wins))) return rc;
@@ -740,6 +745,7 @@ int sgz_db_reset(sgz_context *ctx, int num_channels)
         return ctx->fail(SGZ_E_ARG, "num_channels must be in [2, 64]");
     SGZ_HIP(ctx, hipSetDevice(ctx->device));
     SGZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SGZ_HIP(ctx, hipStreamSynchronize(ctx->screen_stream));
     for (auto &f : ctx->files)
         if (f.owned && f.d_raw) SGZ_HIP(ctx, hipFree(f.d_raw));
     ctx->files.clear();
@@ -927,6 +933,7 @@ int sgz_corr_set_target(sgz_context *ctx, const float *frames, int num_frames, f
     cp.sumAS = sumS;
     int rc;
     SGZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SGZ_HIP(ctx, hipStreamSynchronize(ctx->screen_stream));
     if ((rc = ensure(ctx, ctx->d_aprime, ctx->aprime_cap, ap.size()))) return rc;
     SGZ_HIP(ctx, hipMemcpy(ctx->d_aprime, ap.data(), sizeof(double) * ap.size(), hipMemcpyHostToDevice));
     if ((rc = ensure(ctx, ctx->d_tnorm, ctx->tnorm_cap, tb.size()))) return rc;
@@ -986,31 +993,37 @@ static int corr_run_impl(sgz_context *ctx, int file_begin, int file_end, bool ex
 
     const int cb = ctx->prep_cb;
     const size_t prepLds = (size_t)ctx->numCh * (kR * (cb + 1) + 1) * sizeof(float);
-    float *planarF = reinterpret_cast<float *>(ctx->d_planar);  // the screening path stores the planar image as fp32
+    // The screening path has its own planar image (fp32) and its own stream, so that a screening run
+    // over one file range overlaps with an exact run over another.
+    float *planarF = ctx->d_planar_f;
+    hipStream_t stream = exact ? ctx->stream : ctx->screen_stream;
+    // an earlier run over some of these files (possibly on the other stream) writes the same outputs
+    for (const auto &run : ctx->runs)
+        if (run.fb < file_end && run.fe > file_begin) SGZ_HIP(ctx, hipStreamWaitEvent(stream, run.done, 0));
     if (exact)
-        hipLaunchKernelGGL(prep_kernel<double>, dim3(pt1 - pt0), dim3(256), prepLds, ctx->stream, ctx->d_files,
+        hipLaunchKernelGGL(prep_kernel<double>, dim3(pt1 - pt0), dim3(256), prepLds, stream, ctx->d_files,
                            ctx->d_ptiles + pt0, ctx->d_planar, ctx->d_prefix, ctx->d_tbase, ctx->norm, ctx->numCh, cb,
                            ctx->cp.kT, ctx->cp.kS);
     else
-        hipLaunchKernelGGL(prep_kernel<float>, dim3(pt1 - pt0), dim3(256), prepLds, ctx->stream, ctx->d_files,
+        hipLaunchKernelGGL(prep_kernel<float>, dim3(pt1 - pt0), dim3(256), prepLds, stream, ctx->d_files,
                            ctx->d_ptiles + pt0, planarF, ctx->d_prefix, ctx->d_tbase, ctx->norm, ctx->numCh, cb,
                            ctx->cp.kT, ctx->cp.kS);
     SGZ_HIP(ctx, hipGetLastError());
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(file_end - file_begin), dim3(256), 0, ctx->stream, ctx->d_files,
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(file_end - file_begin), dim3(256), 0, stream, ctx->d_files,
                        file_begin, ctx->d_tbase);
     SGZ_HIP(ctx, hipGetLastError());
     const size_t corrLds = exact ? corr_lds_bytes<double>() : corr_lds_bytes<float>();
-    SGZ_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    SGZ_HIP(ctx, hipEventRecord(ctx->ev0, stream));
     if (exact)
-        hipLaunchKernelGGL(corr_kernel<double>, dim3(t1 - t0), dim3(kThreads), corrLds, ctx->stream, ctx->d_files,
+        hipLaunchKernelGGL(corr_kernel<double>, dim3(t1 - t0), dim3(kThreads), corrLds, stream, ctx->d_files,
                            ctx->d_tiles + t0, ctx->d_planar, ctx->d_prefix, ctx->d_tbase, ctx->d_aprime, ctx->cp,
                            ctx->d_sim, ctx->d_boost);
     else
-        hipLaunchKernelGGL(corr_kernel<float>, dim3(t1 - t0), dim3(kThreads), corrLds, ctx->stream, ctx->d_files,
+        hipLaunchKernelGGL(corr_kernel<float>, dim3(t1 - t0), dim3(kThreads), corrLds, stream, ctx->d_files,
                            ctx->d_tiles + t0, planarF, ctx->d_prefix, ctx->d_tbase, ctx->d_aprime_f, ctx->cp,
                            ctx->d_sim, ctx->d_boost);
     SGZ_HIP(ctx, hipGetLastError());
-    SGZ_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    SGZ_HIP(ctx, hipEventRecord(ctx->ev1, stream));
     ctx->ev_valid = true;
     // completion marker of this run, so that reading results of an earlier run
     // does not have to wait for later ones
@@ -1024,7 +1037,7 @@ static int corr_run_impl(sgz_context *ctx, int file_begin, int file_end, bool ex
         } else {
             SGZ_HIP(ctx, hipEventCreateWithFlags(&run.done, hipEventDisableTiming));
         }
-        SGZ_HIP(ctx, hipEventRecord(run.done, ctx->stream));
+        SGZ_HIP(ctx, hipEventRecord(run.done, stream));
         // a newer run over the same files supersedes older markers
         for (size_t i = 0; i < ctx->runs.size();) {
             if (ctx->runs[i].fb >= file_begin && ctx->runs[i].fe <= file_end) {
@@ -1084,6 +1097,8 @@ int sgz_corr_compact_device(sgz_context *ctx, int file_begin, int file_end, floa
     if (!device_count || capacity < 0 || (capacity > 0 && !device_out))
         return ctx->fail(SGZ_E_ARG, "bad output buffers");
     SGZ_HIP(ctx, hipSetDevice(ctx->device));
+    for (const auto &run : ctx->runs)
+        if (run.fb < file_end && run.fe > file_begin) SGZ_HIP(ctx, hipStreamWaitEvent(ctx->stream, run.done, 0));
     SGZ_HIP(ctx, hipMemsetAsync(device_count, 0, sizeof(unsigned long long), ctx->stream));
     const int t0 = ctx->tile_begin[file_begin], t1 = ctx->tile_begin[file_end];
     if (t1 > t0) {

@@ -226,23 +226,8 @@ std::vector<Match> runFeatureCorrelation(sgz_context *ctx, const FeatureCorrelat
             for (int g = f; g < nf; g++) feedDense(g, g + 1);
         } else {
             check(ctx, rc);
-            std::vector<int32_t> off;
-            size_t i = 0;
-            while (i < (size_t)count) {
-                size_t j = i;
-                off.clear();
-                sim.clear();
-                boost.clear();
-                while (j < (size_t)count && cands[j].file == cands[i].file) {
-                    off.push_back(cands[j].offset);
-                    sim.push_back(cands[j].sim);
-                    boost.push_back(cands[j].boost);
-                    j++;
-                }
-                if (sgz_sel_feed_file(sel, cands[i].file, (int64_t)off.size(), off.data(), sim.data(), boost.data()) != SGZ_OK)
-                    throw Error(SGZ_E_ARG, "selector rejected its input");
-                i = j;
-            }
+            if (sgz_sel_feed_candidates(sel, cands.data(), count) != SGZ_OK)
+                throw Error(SGZ_E_ARG, "selector rejected its input");
         }
     }
     checkAborted(obs, 1.0);

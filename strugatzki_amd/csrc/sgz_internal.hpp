@@ -107,6 +107,8 @@ struct sgz_context {
 
     double *d_planar = nullptr;
     size_t planar_cap = 0;
+    float *d_planar_f = nullptr;             // planar image of the screening path
+    size_t planar_f_cap = 0;
     double *d_prefix = nullptr;
     size_t prefix_cap = 0;
     double *d_tbase = nullptr;
@@ -127,6 +129,7 @@ struct sgz_context {
     std::vector<Run> runs;
     std::vector<hipEvent_t> event_pool;
     hipStream_t copy_stream = nullptr;       // device-to-host result copies
+    hipStream_t screen_stream = nullptr;     // screening runs (overlap with exact runs on `stream`)
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;

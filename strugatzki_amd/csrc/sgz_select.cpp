@@ -181,6 +181,32 @@ int sgz_sel_feed_file(sgz_selector *sel, int file, int64_t n, const int32_t *off
     return SGZ_OK;
 }
 
+int sgz_sel_feed_candidates(sgz_selector *sel, const sgz_candidate *cands, int64_t n)
+{
+    if (!sel || n < 0 || (n > 0 && !cands)) return SGZ_E_ARG;
+    std::vector<int32_t> off;
+    std::vector<float> sim, boost;
+    int64_t i = 0;
+    while (i < n) {
+        int64_t j = i;
+        off.clear();
+        sim.clear();
+        boost.clear();
+        while (j < n && cands[j].file == cands[i].file) {
+            if (j > i && cands[j].offset <= cands[j - 1].offset) return SGZ_E_ARG;  // must be sorted
+            off.push_back(cands[j].offset);
+            sim.push_back(cands[j].sim);
+            boost.push_back(cands[j].boost);
+            j++;
+        }
+        if (j < n && cands[j].file < cands[i].file) return SGZ_E_ARG;
+        const int rc = sgz_sel_feed_file(sel, cands[i].file, (int64_t)off.size(), off.data(), sim.data(), boost.data());
+        if (rc != SGZ_OK) return rc;
+        i = j;
+    }
+    return SGZ_OK;
+}
+
 int sgz_sel_is_full(const sgz_selector *sel)
 {
     return sel && (int)sel->all.size() >= sel->num_matches ? 1 : 0;

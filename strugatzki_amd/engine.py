@@ -243,6 +243,13 @@ class Selector:
         if rc != N.SGZ_OK:
             raise N.NativeError(rc, "sgz_sel_feed_file")
 
+    def feed_candidate_list(self, cands: np.ndarray) -> None:
+        """All files of a (file, offset)-sorted candidate array in one call."""
+        c = np.ascontiguousarray(cands, dtype=N.CANDIDATE_DTYPE)
+        rc = lib.sgz_sel_feed_candidates(self._h, N.ptr(c), c.shape[0])
+        if rc != N.SGZ_OK:
+            raise N.NativeError(rc, "sgz_sel_feed_candidates (candidates not sorted by file, offset?)")
+
     @property
     def is_full(self) -> bool:
         return bool(lib.sgz_sel_is_full(self._h))

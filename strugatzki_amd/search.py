@@ -88,8 +88,7 @@ def search(ctx: Context, p: SearchParams) -> list[N.Match]:
                 sim, boost = ctx.corr_read_dense(g)
                 sel.feed_dense(g, sim, boost)
         else:
-            for g, part in iter_files(cands):
-                sel.feed_candidates(g, part["offset"], part["sim"], part["boost"])
+            sel.feed_candidate_list(cands)
     out = sel.result()
     sel.close()
     return out
@@ -127,8 +126,7 @@ def exchange_candidates(rec, cnt, capacity: int, group=None) -> np.ndarray:
 
 def finish_selection(sel: Selector, cands: np.ndarray) -> list[N.Match]:
     """Tail replay over (file, offset)-sorted candidates, then the result list."""
-    for g, part in iter_files(cands):
-        sel.feed_candidates(g, part["offset"], part["sim"], part["boost"])
+    sel.feed_candidate_list(cands)
     return sel.result()
 
 

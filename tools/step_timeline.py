@@ -26,12 +26,12 @@ for it in range(4):
     t = [time.perf_counter()]
     sel = Selector(10, 1, 0, 512, L)
     ctx.corr_run(0, 10); t.append(time.perf_counter())
-    ctx.corr_run(10, NF); t.append(time.perf_counter())
+    ctx.corr_run_screen(10, NF); t.append(time.perf_counter())
     dense = ctx.corr_read_dense_range(0, 10); t.append(time.perf_counter())
     for g, (s, b) in enumerate(dense):
         sel.feed_dense(g, s, b)
     t.append(time.perf_counter())
-    cands = ctx.corr_compact(10, NF, sel.threshold, 1 << 16); t.append(time.perf_counter())
+    cands = ctx.corr_compact(10, NF, sel.threshold - 1e-5, 1 << 16, rescore=True); t.append(time.perf_counter())
     for g, part in iter_files(cands):
         sel.feed_candidates(g, part["offset"], part["sim"], part["boost"])
     res = sel.result(); t.append(time.perf_counter())
