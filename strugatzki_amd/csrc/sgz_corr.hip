@@ -570,52 +570,83 @@ __global__ __launch_bounds__(256) void compact_kernel(const FileDesc *__restrict
 // 177-196): fp32 normalise, fp64 mean, fp64 sums of (b - mean)^2 and of
 // (a - aMean)(b - bMean).  Sums are combined in a fixed tree order.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ double block_sum_256(double v, double *scratch /* 4 doubles */)
+constexpr int kRescoreThreads = 1024;
+constexpr int kRescoreWaves = kRescoreThreads / 64;
+
+__device__ __forceinline__ double block_sum(double v, double *scratch /* kRescoreWaves doubles */)
 {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
     __syncthreads();  // scratch may still be read from the previous call
     if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
     __syncthreads();
-    return (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
+    double p[kRescoreWaves];
+#pragma unroll
+    for (int k = 0; k < kRescoreWaves; k++) p[k] = scratch[k];
+#pragma unroll
+    for (int w = kRescoreWaves / 2; w >= 1; w >>= 1)
+#pragma unroll
+        for (int k = 0; k < w; k++) p[k] += p[k + w];
+    return p[0];
 }
 
-__global__ __launch_bounds__(256) void rescore_kernel(const FileDesc *__restrict__ files,
-                                                      const float *__restrict__ tnorm,  // [numCh][L] normalised target
-                                                      NormParams nrm, CorrParams cp, double aMeanT, double aMeanS,
-                                                      sgz_candidate *__restrict__ cands,
-                                                      const unsigned long long *__restrict__ count, long long capacity)
+__global__ __launch_bounds__(kRescoreThreads) void rescore_kernel(
+    const FileDesc *__restrict__ files, const float *__restrict__ tnorm,  // [numCh][L] normalised target
+    NormParams nrm, CorrParams cp, double aMeanT, double aMeanS, sgz_candidate *__restrict__ cands,
+    const unsigned long long *__restrict__ count, long long capacity)
 {
-    __shared__ double scratch[4];
+    constexpr int NT = kRescoreThreads, U = 4;
+    __shared__ double scratch[kRescoreWaves];
     const long long n = min((long long)*count, capacity);
     const int numCh = cp.numCh, L = cp.L;
+    // Elements are walked in memory order (e = i * numCh + c), NT at a time and U loads in flight per thread:
+    // coalesced reads of the raw frames; (i, c) of a thread's next element advance by a fixed (di, dc).
+    const int total = L * numCh;
+    const int di = NT / numCh, dc = NT - di * numCh;
+    const int i0 = (int)threadIdx.x / numCh, c0 = (int)threadIdx.x - i0 * numCh;
     for (long long ci = blockIdx.x; ci < n; ci += gridDim.x) {
         const sgz_candidate cd = cands[ci];
         const FileDesc fd = files[cd.file];
         const float *raw = fd.raw + (long long)cd.offset * numCh;
         // pass 1: sums
         double sT = 0.0, sS = 0.0;
-        for (int i = threadIdx.x; i < L; i += 256) {
-            const float *fr = raw + (long long)i * numCh;
-            for (int c = 0; c < numCh; c++) {
-                float v = fr[c];
+        {
+            int c = c0, e = threadIdx.x;
+            auto add = [&](float v) {
                 if (nrm.enabled) v = (v - nrm.mn[c]) / nrm.d[c];
                 if (c == 0) sT += (double)v; else sS += (double)v;
+                c += dc;
+                if (c >= numCh) c -= numCh;
+            };
+            for (; e + (U - 1) * NT < total; e += U * NT) {
+                float v[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) v[u] = raw[e + u * NT];
+#pragma unroll
+                for (int u = 0; u < U; u++) add(v[u]);
             }
+            for (; e < total; e += NT) add(raw[e]);
         }
-        sT = block_sum_256(sT, scratch);
-        sS = block_sum_256(sS, scratch);
+        sT = block_sum(sT, scratch);
+        sS = block_sum(sS, scratch);
         const double nT = (double)L, nS = (double)L * (double)(numCh - 1);
         const double bMeanT = sT / nT, bMeanS = sS / nS;
         // pass 2: squared deviations and cross terms
         double qT = 0.0, qS = 0.0, xT = 0.0, xS = 0.0;
-        for (int i = threadIdx.x; i < L; i += 256) {
-            const float *fr = raw + (long long)i * numCh;
-            for (int c = 0; c < numCh; c++) {
-                float v = fr[c];
-                if (nrm.enabled) v = (v - nrm.mn[c]) / nrm.d[c];
-                const double a = (double)tnorm[(long long)c * L + i];
-                if (c == 0) {
+        {
+            int i = i0, c = c0, e = threadIdx.x;
+            auto next = [&](int &ii, int &cc) {
+                ii += di;
+                cc += dc;
+                if (cc >= numCh) {
+                    cc -= numCh;
+                    ii += 1;
+                }
+            };
+            auto add = [&](float v, float af, int cc) {
+                if (nrm.enabled) v = (v - nrm.mn[cc]) / nrm.d[cc];
+                const double a = (double)af;
+                if (cc == 0) {
                     const double d = (double)v - bMeanT;
                     qT += d * d;
                     xT += (a - aMeanT) * d;
@@ -624,12 +655,29 @@ __global__ __launch_bounds__(256) void rescore_kernel(const FileDesc *__restrict
                     qS += d * d;
                     xS += (a - aMeanS) * d;
                 }
+            };
+            for (; e + (U - 1) * NT < total; e += U * NT) {
+                float v[U], af[U];
+                int cs[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    v[u] = raw[e + u * NT];
+                    af[u] = tnorm[(long long)c * L + i];
+                    cs[u] = c;
+                    next(i, c);
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) add(v[u], af[u], cs[u]);
+            }
+            for (; e < total; e += NT) {
+                add(raw[e], tnorm[(long long)c * L + i], c);
+                next(i, c);
             }
         }
-        qT = block_sum_256(qT, scratch);
-        qS = block_sum_256(qS, scratch);
-        xT = block_sum_256(xT, scratch);
-        xS = block_sum_256(xS, scratch);
+        qT = block_sum(qT, scratch);
+        qS = block_sum(qS, scratch);
+        xT = block_sum(xT, scratch);
+        xS = block_sum(xS, scratch);
         if (threadIdx.x == 0) {
             const float avgF = (float)bMeanT;
             const double lnAvgB = log((double)avgF);
@@ -647,12 +695,13 @@ __global__ __launch_bounds__(256) void rescore_kernel(const FileDesc *__restrict
     }
 }
 
-// Picks the chunks-per-tile of prep_kernel so that its LDS image stays <= 64 KiB.
+// Picks the chunks-per-tile of prep_kernel so that its LDS image stays <= 32 KiB
+// (the kernel is bandwidth bound: several workgroups per CU matter more than tile size).
 int pick_prep_cb(int numCh)
 {
     for (int cb = 64; cb >= 2; cb >>= 1) {
         const size_t bytes = (size_t)numCh * (kR * (cb + 1) + 1) * sizeof(float);
-        if (bytes <= 64 * 1024) return cb;
+        if (bytes <= 32 * 1024) return cb;
     }
     return 1;
 }
@@ -1119,7 +1168,7 @@ int sgz_corr_rescore_device(sgz_context *ctx, sgz_candidate *device_cands, int64
     if (capacity == 0) return SGZ_OK;
     SGZ_HIP(ctx, hipSetDevice(ctx->device));
     const int grid = (int)std::min<int64_t>(capacity, 4096);
-    hipLaunchKernelGGL(rescore_kernel, dim3(grid), dim3(256), 0, ctx->stream, ctx->d_files, ctx->d_tnorm, ctx->norm,
+    hipLaunchKernelGGL(rescore_kernel, dim3(grid), dim3(kRescoreThreads), 0, ctx->stream, ctx->d_files, ctx->d_tnorm, ctx->norm,
                        ctx->cp, ctx->aMeanT, ctx->aMeanS, device_cands, device_count, (long long)capacity);
     SGZ_HIP(ctx, hipGetLastError());
     return SGZ_OK;
