@@ -148,6 +148,21 @@ SGZ_API int sgz_corr_run(sgz_context *ctx, int file_begin, int file_end);
  * the files of a search whose windows are afterwards filtered by a threshold and
  * re-scored exactly (sgz_corr_rescore). */
 SGZ_API int sgz_corr_run_screen(sgz_context *ctx, int file_begin, int file_end);
+/* Second screening variant: the cross terms (the same sums of
+ * impl/MathUtil.scala:177-196) are formed on the matrix cores from half-precision
+ * copies of target and database (fp32 sums); window statistics, boost and the
+ * final division stay fp64.  The similarity written for a window is an UPPER
+ * BOUND of sgz_corr_run's value: the half-precision result plus the largest
+ * error the operand roundings can cause for that window (about 1e-3 * sqrt(1 +
+ * (mean offset / std-dev)^2); observed errors are near 1e-5), so that a
+ * threshold test never loses a window; boosts are the exact ones.  Several times
+ * the throughput of sgz_corr_run_screen.  Only for normalised features
+ * (sgz_set_norms with norms) and targets whose staged channel fits LDS:
+ * sgz_corr_screen_f16_available tells (1 / 0), and the run fails with
+ * SGZ_E_STATE otherwise.  A file whose normalised values leave the
+ * half-precision range makes sgz_corr_compact* over it report SGZ_E_OVERFLOW. */
+SGZ_API int sgz_corr_run_screen_f16(sgz_context *ctx, int file_begin, int file_end);
+SGZ_API int sgz_corr_screen_f16_available(const sgz_context *ctx);
 
 /* Copies sim / boost of all windows of one file to the host (either pointer
  * may be NULL).  Synchronises the stream. */

@@ -78,6 +78,8 @@ SIGNATURES = {
     "sgz_corr_num_windows": (C.c_int64, [_vp, C.c_int]),
     "sgz_corr_run": (C.c_int, [_vp, C.c_int, C.c_int]),
     "sgz_corr_run_screen": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "sgz_corr_run_screen_f16": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "sgz_corr_screen_f16_available": (C.c_int, [_vp]),
     "sgz_corr_read_dense": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "sgz_corr_read_dense_range": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
     "sgz_corr_compact": (C.c_int, [_vp, C.c_int, C.c_int, C.c_float, _vp, C.c_int64, C.POINTER(C.c_int64)]),

@@ -24,6 +24,9 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <type_traits>
+
+#include "sgz_corr_dev.hpp"
 #include "sgz_internal.hpp"
 
 using namespace sgz;
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(256) void prep_kernel(const FileDesc *__restrict__ 
                                                    const PrepTile *__restrict__ ptiles,
                                                    T *__restrict__ planar, double *__restrict__ prefix,
                                                    double *__restrict__ tbase, NormParams nrm, int numCh, int cb,
-                                                   double kT, double kS)
+                                                   double kT, double kS, int *__restrict__ hflags)
 {
     extern __shared__ __attribute__((aligned(16))) float xs[];
     __shared__ double wtot[4][4];
@@ -136,10 +139,34 @@ __global__ __launch_bounds__(256) void prep_kernel(const FileDesc *__restrict__ 
     }
     __syncthreads();
 
-    // phase 2: chunk-major planar fp64, centred; frames past the end are 0
+    // phase 2: planar image, centred; frames past the end are 0
     T *dst = planar + fd.planar_off;
     const int rows = numCh * kR;
-    {
+    if constexpr (std::is_same<T, _Float16>::value) {
+        // half precision: natural frame order [numCh][16 M], 8 frames (16 bytes) per thread
+        using half8 = __attribute__((ext_vector_type(8))) _Float16;
+        const long long rowLen = fd.M * kR;
+        const int vecPerRow = tileFrames / 8;
+        bool outOfRange = false;
+        for (int idx = tid; idx < numCh * vecPerRow; idx += 256) {
+            const int c = idx / vecPerRow, v = idx - c * vecPerRow;
+            const long long fr0 = f0 + 8 * v;
+            if (fr0 < rowLen) {
+                const float k = (float)(c == 0 ? kT : kS);
+                half8 out;
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const int fr = 8 * v + e;
+                    float val = 0.0f;
+                    if (f0 + fr < fd.frames) val = xs[c * cstride + (fr & (kR - 1)) * jstride + (fr >> 4)] - k;
+                    outOfRange |= !(fabsf(val) <= 60000.0f) && val == val;  // NaN stays NaN, as in the exact path
+                    out[e] = (_Float16)val;
+                }
+                *reinterpret_cast<half8 *>(dst + (long long)c * rowLen + fr0) = out;
+            }
+        }
+        if (outOfRange) hflags[pt.file] = 1;
+    } else {
         // idx = tid + 256*k over [rows][cb]; cb is a power of two
         const int cbShift = 31 - __clz(cb);
         for (int idx = tid; idx < rows * cb; idx += 256) {
@@ -292,53 +319,6 @@ __device__ __forceinline__ void fma_step(T (&acc)[kR], const T *__restrict__ a, 
             acc[r] = fma(aq, k < kR ? x0[k] : x1[k - kR], acc[r]);
         }
     }
-}
-
-// Prefix sums of the per-frame moments: P(q, i) = sum over frames < i.
-struct Epilogue {
-    const double *pre;    // 4 arrays of `frames` in-tile inclusive sums
-    const double *tbase;  // 4 arrays of `nptiles` tile bases
-    long long frames, nptiles;
-    int tileShift;        // log2(frames per prep tile)
-    __device__ __forceinline__ double P(int q, long long i) const
-    {
-        if (i == 0) return 0.0;
-        return pre[q * frames + (i - 1)] + tbase[q * nptiles + ((i - 1) >> tileShift)];
-    }
-};
-
-__device__ __forceinline__ void window_result(const CorrParams &cp, const Epilogue &ep, long long o,
-                                              double crossT, double crossS, float &simOut, float &boostOut)
-{
-    const double nT = (double)cp.L;
-    const double nS = (double)cp.L * (double)(cp.numCh - 1);
-    const double dmT = (ep.P(0, o + cp.L) - ep.P(0, o)) / nT;  // window mean - kT
-    const double avgD = cp.kT + dmT;
-    const float avgF = (float)avgD;  // MathUtil.avg returns Float
-    const double lnAvgB = log((double)avgF);
-    const float boost = (float)exp((cp.lnAvgIn - lnAvgB) / 0.6);
-    float sim = 0.0f;
-    if (boost <= cp.maxBoost) {
-        float temporal = 0.0f, spectral = 0.0f;
-        if (cp.w > 0.0f) {
-            double var = (ep.P(1, o + cp.L) - ep.P(1, o)) / nT - dmT * dmT;
-            if (var < 0.0) var = 0.0;
-            const double bStd = sqrt(var);
-            const double cross = crossT - dmT * cp.sumAT;
-            temporal = (float)(cross / (cp.aStdT * bStd * nT));
-        }
-        if (cp.w < 1.0f) {
-            const double dmS = (ep.P(2, o + cp.L) - ep.P(2, o)) / nS;
-            double var = (ep.P(3, o + cp.L) - ep.P(3, o)) / nS - dmS * dmS;
-            if (var < 0.0) var = 0.0;
-            const double bStd = sqrt(var);
-            const double cross = crossS - dmS * cp.sumAS;
-            spectral = (float)(cross / (cp.aStdS * bStd * nS));
-        }
-        sim = temporal * cp.w + spectral * (1.0f - cp.w);  // fp32, no contraction (-ffp-contract=off)
-    }
-    simOut = sim;
-    boostOut = boost;
 }
 
 constexpr int kThreads = kWaves * 64;
@@ -539,10 +519,14 @@ __global__ __launch_bounds__(256) void compact_kernel(const FileDesc *__restrict
                                                       const float *__restrict__ sim,
                                                       const float *__restrict__ boost, float threshold,
                                                       sgz_candidate *__restrict__ out, long long capacity,
-                                                      unsigned long long *__restrict__ count)
+                                                      unsigned long long *__restrict__ count,
+                                                      const int *__restrict__ hflags)
 {
     const TileDesc td = tiles[blockIdx.x];
     const FileDesc fd = files[td.file];
+    // A file whose half-precision image overflowed has no usable screening values: report it as a
+    // candidate overflow, which sends the caller to the exact dense path.
+    if (hflags[td.file] && td.o0 == 0 && threadIdx.x == 0) atomicAdd(count, (unsigned long long)capacity + 1ull);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const long long o = (long long)td.o0 + k * 256 + threadIdx.x;
@@ -716,6 +700,9 @@ int build_layout(sgz_context *ctx)
     ctx->h_files.assign(nf, FileDesc{});
     ctx->h_tiles.clear();
     ctx->h_ptiles.clear();
+    ctx->h_tiles_h.clear();
+    ctx->tile_h_begin.assign(nf + 1, 0);
+    const bool halfOk = ctx->hg.S2 > 0;
     ctx->tile_begin.assign(nf + 1, 0);
     ctx->ptile_begin.assign(nf + 1, 0);
     ctx->prep_cb = pick_prep_cb(ctx->numCh);
@@ -732,6 +719,11 @@ int build_layout(sgz_context *ctx)
         long long M = ntiles * 64 + S + 8;  // slack: staging copies whole 16-byte vectors
         const long long need = (fd.frames + kR - 1) / kR;
         if (M < need) M = need;
+        const long long ntilesH = (fd.num_windows + kHTileW - 1) / kHTileW;
+        if (halfOk) {  // the half-precision kernel stages 8 * XU frames from the first window of a tile
+            const long long needH = (ntilesH * kHTileW + 8ll * ctx->hg.XU + kR - 1) / kR;
+            if (M < needH) M = needH;
+        }
         M = (M + 3) & ~3ll;
         fd.M = M;
         fd.planar_off = planar;
@@ -745,6 +737,9 @@ int build_layout(sgz_context *ctx)
         wins += fd.num_windows;
         ctx->tile_begin[f] = (int)ctx->h_tiles.size();
         for (long long t = 0; t < ntiles; t++) ctx->h_tiles.push_back(TileDesc{f, (int)(t * kTileW)});
+        ctx->tile_h_begin[f] = (int)ctx->h_tiles_h.size();
+        if (halfOk)
+            for (long long t = 0; t < ntilesH; t++) ctx->h_tiles_h.push_back(TileDesc{f, (int)(t * kHTileW)});
         ctx->ptile_begin[f] = (int)ctx->h_ptiles.size();
         if (fd.num_windows > 0) {
             for (long long c0 = 0; c0 < M; c0 += ctx->prep_cb) ctx->h_ptiles.push_back(PrepTile{f, (int)c0});
@@ -752,6 +747,7 @@ int build_layout(sgz_context *ctx)
     }
     ctx->tile_begin[nf] = (int)ctx->h_tiles.size();
     ctx->ptile_begin[nf] = (int)ctx->h_ptiles.size();
+    ctx->tile_h_begin[nf] = (int)ctx->h_tiles_h.size();
     ctx->total_windows = wins;
 
     int rc;
@@ -760,6 +756,12 @@ int build_layout(sgz_context *ctx)
     if ((rc = ensure(ctx, ctx->d_ptiles, ctx->d_ptiles_cap, ctx->h_ptiles.size()))) return rc;
     if ((rc = ensure(ctx, ctx->d_planar, ctx->planar_cap, (size_t)planar))) return rc;
     if ((rc = ensure(ctx, ctx->d_planar_f, ctx->planar_f_cap, (size_t)planar))) return rc;
+    if (halfOk) {
+        if ((rc = ensure(ctx, ctx->d_planar_h, ctx->planar_h_cap, (size_t)planar))) return rc;
+        if ((rc = ensure(ctx, ctx->d_tiles_h, ctx->d_tiles_h_cap, ctx->h_tiles_h.size()))) return rc;
+    }
+    if ((rc = ensure(ctx, ctx->d_hflags, ctx->hflags_cap, (size_t)nf))) return rc;
+    if (nf) SGZ_HIP(ctx, hipMemsetAsync(ctx->d_hflags, 0, sizeof(int) * nf, ctx->stream));
     if ((rc = ensure(ctx, ctx->d_prefix, ctx->prefix_cap, (size_t)prefix))) return rc;
     if ((rc = ensure(ctx, ctx->d_tbase, ctx->tbase_cap, (size_t)tb))) return rc;
     if ((rc = ensure(ctx, ctx->d_sim, ctx->dense_cap, (size_t)wins))) return rc;
@@ -769,6 +771,9 @@ int build_layout(sgz_context *ctx)
                                         hipMemcpyHostToDevice, ctx->stream));
     if (!ctx->h_tiles.empty())
         SGZ_HIP(ctx, hipMemcpyAsync(ctx->d_tiles, ctx->h_tiles.data(), sizeof(TileDesc) * ctx->h_tiles.size(),
+                                    hipMemcpyHostToDevice, ctx->stream));
+    if (!ctx->h_tiles_h.empty())
+        SGZ_HIP(ctx, hipMemcpyAsync(ctx->d_tiles_h, ctx->h_tiles_h.data(), sizeof(TileDesc) * ctx->h_tiles_h.size(),
                                     hipMemcpyHostToDevice, ctx->stream));
     if (!ctx->h_ptiles.empty())
         SGZ_HIP(ctx, hipMemcpyAsync(ctx->d_ptiles, ctx->h_ptiles.data(), sizeof(PrepTile) * ctx->h_ptiles.size(),
@@ -994,7 +999,10 @@ int sgz_corr_set_target(sgz_context *ctx, const float *frames, int num_frames, f
     if ((rc = ensure(ctx, ctx->d_aprime_f, ctx->aprime_f_cap, apf.size()))) return rc;
     SGZ_HIP(ctx, hipMemcpy(ctx->d_aprime_f, apf.data(), sizeof(float) * apf.size(), hipMemcpyHostToDevice));
     ctx->have_target = true;
-    if (oldL != L) ctx->layout_dirty = true;
+    // half-precision target image of the matrix-core screening kernel (none when the geometry does not fit)
+    const bool hadHalf = ctx->hg.S2 > 0;
+    if ((rc = half_screen_set_target(ctx, ap, Lpad))) return rc;
+    if (oldL != L || hadHalf != (ctx->hg.S2 > 0)) ctx->layout_dirty = true;
     return SGZ_OK;
 }
 
@@ -1005,17 +1013,33 @@ int64_t sgz_corr_num_windows(const sgz_context *ctx, int file)
     return n >= ctx->cp.L ? n - ctx->cp.L + 1 : 0;
 }
 
-static int corr_run_impl(sgz_context *ctx, int file_begin, int file_end, bool exact);
+enum RunMode { kRunExact = 0, kRunScreenF32 = 1, kRunScreenF16 = 2 };
 
-int sgz_corr_run(sgz_context *ctx, int file_begin, int file_end) { return corr_run_impl(ctx, file_begin, file_end, true); }
+static int corr_run_impl(sgz_context *ctx, int file_begin, int file_end, int mode);
+
+int sgz_corr_run(sgz_context *ctx, int file_begin, int file_end)
+{
+    return corr_run_impl(ctx, file_begin, file_end, kRunExact);
+}
 
 int sgz_corr_run_screen(sgz_context *ctx, int file_begin, int file_end)
 {
-    return corr_run_impl(ctx, file_begin, file_end, false);
+    return corr_run_impl(ctx, file_begin, file_end, kRunScreenF32);
 }
 
-static int corr_run_impl(sgz_context *ctx, int file_begin, int file_end, bool exact)
+int sgz_corr_screen_f16_available(const sgz_context *ctx) { return ctx && half_screen_fits(ctx) ? 1 : 0; }
+
+int sgz_corr_run_screen_f16(sgz_context *ctx, int file_begin, int file_end)
 {
+    if (!ctx) return SGZ_E_ARG;
+    if (ctx->have_target && !half_screen_fits(ctx))
+        return ctx->fail(SGZ_E_STATE, "half-precision screening needs normalised features and a target that fits LDS");
+    return corr_run_impl(ctx, file_begin, file_end, kRunScreenF16);
+}
+
+static int corr_run_impl(sgz_context *ctx, int file_begin, int file_end, int mode)
+{
+    const bool exact = mode == kRunExact;
     if (!ctx) return SGZ_E_ARG;
     if (!ctx->have_target) return ctx->fail(SGZ_E_STATE, "sgz_corr_set_target has not been called");
     const int nf = (int)ctx->files.size();
@@ -1033,7 +1057,9 @@ static int corr_run_impl(sgz_context *ctx, int file_begin, int file_end, bool ex
     if (file_begin == file_end) return SGZ_OK;
 
     const int pt0 = ctx->ptile_begin[file_begin], pt1 = ctx->ptile_begin[file_end];
-    const int t0 = ctx->tile_begin[file_begin], t1 = ctx->tile_begin[file_end];
+    const bool half = mode == kRunScreenF16;
+    const int t0 = half ? ctx->tile_h_begin[file_begin] : ctx->tile_begin[file_begin];
+    const int t1 = half ? ctx->tile_h_begin[file_end] : ctx->tile_begin[file_end];
     long long wins = 0;
     for (int f = file_begin; f < file_end; f++) wins += ctx->h_files[f].num_windows;
     ctx->last_windows = wins;
@@ -1049,21 +1075,29 @@ static int corr_run_impl(sgz_context *ctx, int file_begin, int file_end, bool ex
     // an earlier run over some of these files (possibly on the other stream) writes the same outputs
     for (const auto &run : ctx->runs)
         if (run.fb < file_end && run.fe > file_begin) SGZ_HIP(ctx, hipStreamWaitEvent(stream, run.done, 0));
+    // range flags of these files: only a half-precision prep sets them
+    SGZ_HIP(ctx, hipMemsetAsync(ctx->d_hflags + file_begin, 0, sizeof(int) * (file_end - file_begin), stream));
     if (exact)
         hipLaunchKernelGGL(prep_kernel<double>, dim3(pt1 - pt0), dim3(256), prepLds, stream, ctx->d_files,
                            ctx->d_ptiles + pt0, ctx->d_planar, ctx->d_prefix, ctx->d_tbase, ctx->norm, ctx->numCh, cb,
-                           ctx->cp.kT, ctx->cp.kS);
+                           ctx->cp.kT, ctx->cp.kS, ctx->d_hflags);
+    else if (half)
+        hipLaunchKernelGGL(prep_kernel<_Float16>, dim3(pt1 - pt0), dim3(256), prepLds, stream, ctx->d_files,
+                           ctx->d_ptiles + pt0, reinterpret_cast<_Float16 *>(ctx->d_planar_h), ctx->d_prefix,
+                           ctx->d_tbase, ctx->norm, ctx->numCh, cb, ctx->cp.kT, ctx->cp.kS, ctx->d_hflags);
     else
         hipLaunchKernelGGL(prep_kernel<float>, dim3(pt1 - pt0), dim3(256), prepLds, stream, ctx->d_files,
                            ctx->d_ptiles + pt0, planarF, ctx->d_prefix, ctx->d_tbase, ctx->norm, ctx->numCh, cb,
-                           ctx->cp.kT, ctx->cp.kS);
+                           ctx->cp.kT, ctx->cp.kS, ctx->d_hflags);
     SGZ_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(tile_scan_kernel, dim3(file_end - file_begin), dim3(256), 0, stream, ctx->d_files,
                        file_begin, ctx->d_tbase);
     SGZ_HIP(ctx, hipGetLastError());
     const size_t corrLds = exact ? corr_lds_bytes<double>() : corr_lds_bytes<float>();
     SGZ_HIP(ctx, hipEventRecord(ctx->ev0, stream));
-    if (exact)
+    if (half) {
+        if ((rc = half_screen_launch(ctx, t0, t1, stream))) return rc;
+    } else if (exact)
         hipLaunchKernelGGL(corr_kernel<double>, dim3(t1 - t0), dim3(kThreads), corrLds, stream, ctx->d_files,
                            ctx->d_tiles + t0, ctx->d_planar, ctx->d_prefix, ctx->d_tbase, ctx->d_aprime, ctx->cp,
                            ctx->d_sim, ctx->d_boost);
@@ -1153,7 +1187,7 @@ int sgz_corr_compact_device(sgz_context *ctx, int file_begin, int file_end, floa
     if (t1 > t0) {
         hipLaunchKernelGGL(compact_kernel, dim3(t1 - t0), dim3(256), 0, ctx->stream, ctx->d_files,
                            ctx->d_tiles + t0, ctx->d_sim, ctx->d_boost, threshold, device_out,
-                           (long long)capacity, device_count);
+                           (long long)capacity, device_count, ctx->d_hflags);
         SGZ_HIP(ctx, hipGetLastError());
     }
     return SGZ_OK;

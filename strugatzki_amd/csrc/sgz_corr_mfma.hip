@@ -1,0 +1,292 @@
+// Half-precision matrix-core screening of the sliding cross term
+// (impl/FeatureCorrelationImpl.scala:193-232 evaluates, per window o,
+//  sum_i a'[c][i] * b[c][o + i] through MathUtil.correlate, impl/MathUtil.scala:177-196).
+//
+// With o = 16 m + r and kk = i + r the sum over lags becomes a dense matrix product
+//
+//     out[r][m] = sum_kk  A[r][kk] * X[kk][m],   A[r][kk] = a'[kk - r],   X[kk][m] = b[16 m + kk]
+//
+// (A is the target in 16 shifted copies, zero outside [0, L); X is the file read
+// at chunk stride 16).  v_mfma_f32_16x16x32_f16 multiplies a 16 x 32 slice of A
+// (one "step" s: kk = 32 s .. 32 s + 31) with the 32 x 16 slice of X of one
+// column tile (16 chunks).  The operand of tile t at step s is the operand of
+// tile t + 1 at step s - 8, so wave q of a workgroup takes the steps
+// s = q, q + 8, q + 16, ... and keeps a sliding window of kHNB operands in
+// registers: every step costs one 16-byte LDS read of database frames and one
+// target operand for kHNB matrix instructions.
+//
+// The products are half precision (11 significant bits), the sums fp32; window
+// means and std-devs still come from the fp64 prefix sums.  The result is a
+// screening value: callers re-score every window that comes within a margin of
+// their bound with the exact kernel (rescore_kernel) before using it.  What the
+// kernel stores is an upper bound of the similarity (window_result<true>): the
+// half-precision value plus the largest error the roundings can cause for that
+// window, so a threshold test on it never loses a window.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "sgz_corr_dev.hpp"
+#include "sgz_internal.hpp"
+
+using namespace sgz;
+
+namespace {
+
+using half8 = __attribute__((ext_vector_type(8))) _Float16;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int kHThreads = kHWaves * 64;
+// Two half-precision roundings (target and database value, 2^-11 each) per product, with some room for the
+// fp32 summation.
+constexpr float kHalfRelErr = 1.0e-3f;
+
+__host__ __device__ constexpr size_t half_buf_bytes(int XU, int LAd) { return (size_t)XU * 16 + (size_t)LAd * 8; }
+
+size_t half_lds_bytes(const HalfGeom &hg) { return 2 * half_buf_bytes(hg.XU, hg.LAd) + 2 * kHTileW * sizeof(float); }
+
+// Workgroup = 8 waves, one tile of kHTileW consecutive windows of one file.
+// Per channel the workgroup stages (double buffered) the frames
+// [o0, o0 + 8 XU) of the file in natural order and the two dword-aligned
+// copies of the target channel (even shifts read copy 0, odd shifts copy 1,
+// which is stored one element further left).
+template <int NSTAGE>
+__global__ __launch_bounds__(kHThreads, 4) void corr_mfma_kernel(
+    const FileDesc *__restrict__ files, const TileDesc *__restrict__ tiles, const _Float16 *__restrict__ planarH,
+    const double *__restrict__ prefix, const double *__restrict__ tbase, const uint32_t *__restrict__ aimg,
+    CorrParams cp, HalfGeom hg, float *__restrict__ simOut, float *__restrict__ boostOut)
+{
+    constexpr int NB = kHNB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const TileDesc td = tiles[blockIdx.x];
+    const FileDesc fd = files[td.file];
+    const size_t bufBytes = half_buf_bytes(hg.XU, hg.LAd);
+    const int nV = hg.XU + hg.LAd / 2;  // 16-byte vectors per staged channel
+    const long long rowLen = fd.M * kR;
+    const _Float16 *fplanar = planarH + fd.planar_off + td.o0;
+
+    uint4 st[NSTAGE];
+    auto stage_load = [&](int c) {
+        const uint4 *xsrc = reinterpret_cast<const uint4 *>(fplanar + (long long)c * rowLen);
+        const uint4 *asrc = reinterpret_cast<const uint4 *>(aimg + (size_t)c * 2 * hg.LAd);
+#pragma unroll
+        for (int it = 0; it < NSTAGE; it++) {
+            const int v = min(tid + it * kHThreads, nV - 1);  // surplus threads re-read the last vector
+            const uint4 *src = v < hg.XU ? xsrc + v : asrc + (v - hg.XU);
+            st[it] = *src;
+        }
+    };
+    auto stage_store = [&](int buf) {
+        uint4 *dst = reinterpret_cast<uint4 *>(lds + buf * bufBytes);
+#pragma unroll
+        for (int it = 0; it < NSTAGE; it++) {
+            const int v = tid + it * kHThreads;
+            if (v < nV) dst[v] = st[it];
+        }
+    };
+
+    const int m = lane & 15, g = lane >> 4;
+    const int hBase = 2 * m + g + 4 * q;                                              // 16-byte units
+    const int aBase = (m & 1) * hg.LAd + 4 * g + 8 - ((m + 1) >> 1) + 16 * q;          // dwords
+    const int P = (hg.S2 - q + 7) >> 3;                                               // steps of this wave
+
+    float4 *redS4 = reinterpret_cast<float4 *>(lds + 2 * bufBytes);
+    float4 *redT4 = redS4 + kHTileW / 4;
+    auto reduce = [&](float4 *red, const f32x4 (&acc)[NB]) {
+        for (int wv = 0; wv < kHWaves; wv++) {
+            if (q == wv) {
+#pragma unroll
+                for (int t = 0; t < NB; t++) {
+                    const int idx = 64 * t + 4 * m + g;  // window 256 t + 16 m + 4 g + reg
+                    float4 v = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+                    if (wv) {
+                        const float4 pv = red[idx];
+                        v.x += pv.x;
+                        v.y += pv.y;
+                        v.z += pv.z;
+                        v.w += pv.w;
+                    }
+                    red[idx] = v;
+                }
+            }
+            __syncthreads();
+        }
+    };
+
+    f32x4 acc[NB];
+#pragma unroll
+    for (int t = 0; t < NB; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // phase order: the MFCC channels 1 .. numCh-1 first (one sum), the loudness channel last
+    const int numCh = cp.numCh;
+    auto channel_of = [&](int ph) { return ph + 1 < numCh ? ph + 1 : 0; };
+
+    stage_load(channel_of(0));
+    stage_store(0);
+    __syncthreads();
+
+    for (int ph = 0; ph < numCh; ph++) {
+        if (ph + 1 < numCh) stage_load(channel_of(ph + 1));
+        const uint4 *Xu = reinterpret_cast<const uint4 *>(lds + (ph & 1) * bufBytes) + hBase;
+        const uint32_t *Ad = reinterpret_cast<const uint32_t *>(lds + (ph & 1) * bufBytes + (size_t)hg.XU * 16) + aBase;
+
+        half8 h[NB];
+#pragma unroll
+        for (int t = 0; t < NB; t++) h[t] = __builtin_bit_cast(half8, Xu[32 * t]);
+        auto load_a = [&](int p) {
+            const uint32_t *ap = Ad + 128 * p;
+            uint4 av;
+            av.x = ap[0];
+            av.y = ap[1];
+            av.z = ap[2];
+            av.w = ap[3];
+            return __builtin_bit_cast(half8, av);
+        };
+        half8 aNext = load_a(0);  // in range for any P: the image has room for one step
+        for (int pb = 0; pb < P; pb += NB) {
+#pragma unroll
+            for (int u = 0; u < NB; u++) {
+                const int p = pb + u;
+                if (p < P) {
+                    const half8 a = aNext;
+                    if (p + 1 < P) aNext = load_a(p + 1);
+#pragma unroll
+                    for (int t = 0; t < NB; t++)
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, h[(u + t) % NB], acc[t], 0, 0, 0);
+                    if (p + 1 < P) h[u] = __builtin_bit_cast(half8, Xu[32 * (p + NB)]);
+                }
+            }
+        }
+
+        if (ph + 1 < numCh) stage_store((ph + 1) & 1);
+        __syncthreads();
+        if (ph == numCh - 2) {  // all MFCC channels done
+            reduce(redS4, acc);
+#pragma unroll
+            for (int t = 0; t < NB; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    reduce(redT4, acc);
+
+    Epilogue ep;
+    ep.pre = prefix + fd.prefix_off;
+    ep.tbase = tbase + fd.tbase_off;
+    ep.frames = fd.frames;
+    ep.nptiles = fd.nptiles;
+    ep.tileShift = cp.prepTileShift;
+    CorrParams cph = cp;
+    cph.sumAT = hg.sumAT;
+    cph.sumAS = hg.sumAS;
+    const float *redS = reinterpret_cast<const float *>(redS4);
+    const float *redT = reinterpret_cast<const float *>(redT4);
+#pragma unroll
+    for (int k = 0; k < kHTileW / kHThreads; k++) {
+        const int wdw = tid + k * kHThreads;
+        const long long o = (long long)td.o0 + wdw;
+        if (o < fd.num_windows) {
+            float sim, boost;
+            window_result<true>(cph, ep, o, (double)redT[wdw], (double)redS[wdw], sim, boost, kHalfRelErr);
+            simOut[fd.win_off + o] = sim;
+            boostOut[fd.win_off + o] = boost;
+        }
+    }
+}
+
+}  // namespace
+
+namespace sgz {
+
+// Geometry for a target of L frames; false when one staged channel does not fit
+// the kernel's registers / LDS (the caller then screens with the fp32 kernel).
+static bool half_geom(int L, HalfGeom &hg)
+{
+    const int S2 = (L + 15 + 31) / 32;
+    int LAd = 16 * S2 + 16;
+    if ((LAd & 31) != 16) LAd += 16;
+    const int Pmax = (S2 + 7) / 8;
+    const int XU = 32 * (Pmax + kHNB);
+    hg.S2 = S2;
+    hg.LAd = LAd;
+    hg.XU = XU;
+    const int nV = XU + LAd / 2;
+    if (nV > kHStageV * kHThreads) return false;
+    if (half_lds_bytes(hg) > 160 * 1024) return false;
+    return true;
+}
+
+bool half_screen_fits(const sgz_context *ctx)
+{
+    HalfGeom hg{};
+    // Half precision needs a bounded value range: only normalised features qualify.
+    return ctx->have_target && ctx->norm.enabled && half_geom(ctx->cp.L, hg);
+}
+
+// Builds the two shifted half-precision copies of every target channel.
+// Copy k (k = 0, 1), halfword position p holds a'[p - 16 + k].
+int half_screen_set_target(sgz_context *ctx, const std::vector<double> &aprime, size_t Lpad)
+{
+    HalfGeom hg{};
+    const int L = ctx->cp.L, numCh = ctx->cp.numCh;
+    if (!half_geom(L, hg)) {
+        ctx->hg = HalfGeom{};
+        return SGZ_OK;
+    }
+    const size_t perCopy = (size_t)2 * hg.LAd;  // halfwords
+    std::vector<uint16_t> img((size_t)numCh * 2 * perCopy, 0);
+    double sumT = 0.0, sumS = 0.0;
+    for (int c = 0; c < numCh; c++) {
+        for (int i = 0; i < L; i++) {
+            const _Float16 hv = (_Float16)aprime[(size_t)c * Lpad + i];
+            uint16_t bits;
+            std::memcpy(&bits, &hv, 2);
+            if (c == 0) sumT += (double)hv; else sumS += (double)hv;
+            for (int k = 0; k < 2; k++) {
+                const long long p = (long long)i + 16 - k;
+                if (p >= 0 && p < (long long)perCopy) img[((size_t)c * 2 + k) * perCopy + (size_t)p] = bits;
+            }
+        }
+    }
+    hg.sumAT = sumT;
+    hg.sumAS = sumS;
+    int rc;
+    if ((rc = ensure(ctx, ctx->d_aimg_h, ctx->aimg_h_cap, img.size()))) return rc;
+    SGZ_HIP(ctx, hipMemcpy(ctx->d_aimg_h, img.data(), img.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    ctx->hg = hg;
+    return SGZ_OK;
+}
+
+int half_screen_launch(sgz_context *ctx, int tile_begin, int tile_end, hipStream_t stream)
+{
+    const HalfGeom &hg = ctx->hg;
+    if (hg.S2 <= 0) return ctx->fail(SGZ_E_STATE, "half-precision screening is not available for this target");
+    const size_t ldsBytes = half_lds_bytes(hg);
+    const int nV = hg.XU + hg.LAd / 2;
+    const _Float16 *planarH = reinterpret_cast<const _Float16 *>(ctx->d_planar_h);
+    const uint32_t *aimg = reinterpret_cast<const uint32_t *>(ctx->d_aimg_h);
+    if (nV <= 3 * kHThreads) {
+        auto kern = corr_mfma_kernel<3>;
+        if (ldsBytes > 64 * 1024)
+            SGZ_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
+        hipLaunchKernelGGL(kern, dim3(tile_end - tile_begin), dim3(kHThreads), ldsBytes, stream, ctx->d_files,
+                           ctx->d_tiles_h + tile_begin, planarH, ctx->d_prefix, ctx->d_tbase, aimg, ctx->cp, hg,
+                           ctx->d_sim, ctx->d_boost);
+    } else {
+        auto kern = corr_mfma_kernel<kHStageV>;
+        if (ldsBytes > 64 * 1024)
+            SGZ_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
+        hipLaunchKernelGGL(kern, dim3(tile_end - tile_begin), dim3(kHThreads), ldsBytes, stream, ctx->d_files,
+                           ctx->d_tiles_h + tile_begin, planarH, ctx->d_prefix, ctx->d_tbase, aimg, ctx->cp, hg,
+                           ctx->d_sim, ctx->d_boost);
+    }
+    SGZ_HIP(ctx, hipGetLastError());
+    return SGZ_OK;
+}
+
+}  // namespace sgz

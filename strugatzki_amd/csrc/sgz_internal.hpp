@@ -62,6 +62,19 @@ struct CorrParams {
     float maxBoost;
 };
 
+// ---- geometry of the half-precision matrix-core screening kernel ----------------
+constexpr int kHNB = 8;                 // 16x16 output tiles per wave (columns of 16 chunks each)
+constexpr int kHTileW = kHNB * 256;     // windows per workgroup tile
+constexpr int kHWaves = 8;              // waves per workgroup; wave q takes the 32-lag steps s = q, q + 8, ...
+constexpr int kHStageV = 6;             // 16-byte vectors one thread stages per channel, at most
+
+struct HalfGeom {
+    int S2;    // 32-lag steps: 32 * S2 >= L + 15
+    int LAd;   // dwords per shifted copy of one target channel (LAd % 32 == 16)
+    int XU;    // 16-byte units of one staged channel block of database frames
+    double sumAT, sumAS;  // sums of the half-precision target values
+};
+
 struct DbFile {
     float *d_raw = nullptr;
     long long frames = 0;
@@ -90,6 +103,9 @@ struct sgz_context {
     double aMeanT = 0.0, aMeanS = 0.0;
     float *d_aprime_f = nullptr;  // the same, rounded to fp32 (screening path)
     size_t aprime_f_cap = 0;
+    uint16_t *d_aimg_h = nullptr; // half-precision target image [numCh][2 shifts][2 * LAd] (matrix-core screening)
+    size_t aimg_h_cap = 0;
+    sgz::HalfGeom hg{};
 
     // layout (depends on db + target length)
     bool layout_dirty = true;
@@ -98,6 +114,10 @@ struct sgz_context {
     std::vector<int> tile_begin;             // first tile of each file (+ sentinel)
     std::vector<sgz::PrepTile> h_ptiles;
     std::vector<int> ptile_begin;
+    std::vector<sgz::TileDesc> h_tiles_h;    // tiles of the matrix-core screening kernel
+    std::vector<int> tile_h_begin;
+    sgz::TileDesc *d_tiles_h = nullptr;
+    size_t d_tiles_h_cap = 0;
     int prep_cb = 64;                        // chunks per prep tile
     sgz::FileDesc *d_files = nullptr;
     sgz::TileDesc *d_tiles = nullptr;
@@ -109,6 +129,10 @@ struct sgz_context {
     size_t planar_cap = 0;
     float *d_planar_f = nullptr;             // planar image of the screening path
     size_t planar_f_cap = 0;
+    uint16_t *d_planar_h = nullptr;          // half-precision image [numCh][16 * M], frames in natural order
+    size_t planar_h_cap = 0;
+    int *d_hflags = nullptr;                 // per file: 1 = a value left the half-precision range
+    size_t hflags_cap = 0;
     double *d_prefix = nullptr;
     size_t prefix_cap = 0;
     double *d_tbase = nullptr;
@@ -151,6 +175,11 @@ struct sgz_context {
     } while (0)
 
 namespace sgz {
+// sgz_corr_mfma.hip
+bool half_screen_fits(const sgz_context *ctx);
+int half_screen_set_target(sgz_context *ctx, const std::vector<double> &aprime, size_t Lpad);
+int half_screen_launch(sgz_context *ctx, int tile_begin, int tile_end, hipStream_t stream);
+
 // Grows a device buffer to at least `count` elements (contents are not kept).
 template <typename T>
 int ensure(const sgz_context *ctx, T *&ptr, size_t &cap, size_t count)

@@ -114,6 +114,15 @@ class Context:
             file_end = self.num_files
         self._check(lib.sgz_corr_run_screen(self._h, file_begin, file_end))
 
+    def corr_run_screen_f16(self, file_begin: int = 0, file_end: int | None = None) -> None:
+        if file_end is None:
+            file_end = self.num_files
+        self._check(lib.sgz_corr_run_screen_f16(self._h, file_begin, file_end))
+
+    @property
+    def screen_f16_available(self) -> bool:
+        return bool(lib.sgz_corr_screen_f16_available(self._h))
+
     def corr_read_dense(self, file: int) -> tuple[np.ndarray, np.ndarray]:
         n = max(0, self.corr_num_windows(file))
         sim = np.empty(n, dtype=np.float32)

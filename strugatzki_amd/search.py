@@ -39,8 +39,28 @@ class SearchParams:
     min_spacing: int = 0      # sample frames
     step_size: int = 512      # fftSize / fftOverlap
     capacity: int = 1 << 16   # candidate records fetched per rank
-    screen: bool = True       # tail files: fp32-product screening kernel + exact re-scoring of the candidates
-    margin: float = 1e-5      # screening keeps windows with sim > T0 - margin (screen error is ~1e-7)
+    screen: bool = True       # tail files: screening kernel + exact re-scoring of the candidates
+    screen_mode: str = "auto"  # "f16": half-precision matrix-core kernel, "f32": fp32-product kernel,
+                               # "auto": f16 where available (normalised features, target fits LDS), else f32
+    margin: float | None = None  # screening keeps windows with sim > T0 - margin; None: per mode (MARGIN)
+
+
+# Default margins.  f32: many times the largest screening error observed against the exact kernel
+# (1.2e-7).  f16: that kernel already writes an upper bound of the similarity, the margin only covers the
+# rounding of that sum.
+MARGIN = {"f32": 1e-5, "f16": 1e-6}
+
+
+def _screen_mode(ctx: Context, p: SearchParams) -> str:
+    if p.screen_mode == "auto":
+        return "f16" if ctx.screen_f16_available else "f32"
+    if p.screen_mode not in MARGIN:
+        raise ValueError(f"unknown screen_mode {p.screen_mode!r}")
+    return p.screen_mode
+
+
+def _run_screen(ctx: Context, mode: str, fb: int, fe: int) -> None:
+    (ctx.corr_run_screen_f16 if mode == "f16" else ctx.corr_run_screen)(fb, fe)
 
 
 def _feed_dense_head(ctx: Context, sel: Selector, files: Sequence[int], global_ids: Sequence[int]) -> int:
@@ -62,8 +82,13 @@ def search(ctx: Context, p: SearchParams) -> list[N.Match]:
     head = min(nf, max(p.num_matches, 1))
     ctx.corr_run(0, head)
     screened = p.screen and head < nf
+    mode = _screen_mode(ctx, p) if screened else None
+    margin = p.margin if p.margin is not None or not screened else MARGIN[mode]
     if head < nf:
-        (ctx.corr_run_screen if screened else ctx.corr_run)(head, nf)
+        if screened:
+            _run_screen(ctx, mode, head, nf)
+        else:
+            ctx.corr_run(head, nf)
     f = _feed_dense_head(ctx, sel, range(head), range(head))
     if f < nf and not sel.is_full and screened:  # dense feeding needs exact values
         ctx.corr_run(f, nf)
@@ -75,7 +100,7 @@ def search(ctx: Context, p: SearchParams) -> list[N.Match]:
         f += 1
     if f < nf:
         try:
-            thr = sel.threshold - p.margin if screened else sel.threshold
+            thr = sel.threshold - margin if screened else sel.threshold
             cands = ctx.corr_compact(f, nf, thr, p.capacity, rescore=screened)
         except N.NativeError as e:
             if e.code != N.SGZ_E_OVERFLOW:
@@ -141,8 +166,13 @@ def search_sharded(ctx: Context, p: SearchParams, head_global: Sequence[int], ta
     assert ctx.num_files == nh + nt
     sel = Selector(p.num_matches, p.num_per_file, p.min_spacing, p.step_size, ctx.target_frames)
     ctx.corr_run(0, nh)
+    mode = _screen_mode(ctx, p) if p.screen else None
+    margin = p.margin if p.margin is not None or not p.screen else MARGIN[mode]
     if nt:
-        (ctx.corr_run_screen if p.screen else ctx.corr_run)(nh, nh + nt)
+        if p.screen:
+            _run_screen(ctx, mode, nh, nh + nt)
+        else:
+            ctx.corr_run(nh, nh + nt)
     _feed_dense_head(ctx, sel, range(nh), head_global)
     if not sel.is_full:  # every rank replayed the same head, so all ranks agree on this
         raise RuntimeError("head files did not fill the match set; enlarge the head (degenerate equal sims)")
@@ -151,7 +181,7 @@ def search_sharded(ctx: Context, p: SearchParams, head_global: Sequence[int], ta
     rec = torch.zeros((cap, 4), dtype=torch.int32, device=dev)
     cnt = torch.zeros(1, dtype=torch.int64, device=dev)
     torch.cuda.current_stream().synchronize()  # buffers are zeroed before the library's stream writes them
-    thr = sel.threshold - p.margin if p.screen else sel.threshold
+    thr = sel.threshold - margin if p.screen else sel.threshold
     ctx.corr_compact_device(nh, nh + nt, thr, rec.data_ptr(), cap, cnt.data_ptr())
     if p.screen:
         ctx.corr_rescore_device(rec.data_ptr(), cap, cnt.data_ptr())

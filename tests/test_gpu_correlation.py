@@ -150,7 +150,45 @@ def test_screening_kernel_and_exact_rescoring(ctx, L, frames):
         assert c["boost"] == pytest.approx(boosts[c["file"]][c["offset"]], rel=2e-6)
 
 
-@pytest.mark.parametrize("screen", [False, True])
+@pytest.mark.parametrize("L,frames", [(64, 400), (431, 2583), (3300, 5000), (16, 100), (33, 33), (100, 4500)])
+def test_screening_f16_is_an_upper_bound(ctx, L, frames):
+    """The matrix-core screening kernel writes sim + its error bound: never below the oracle, and close to it."""
+    ts, nf = 20, 3
+    db = synth_db(nf, frames, make_plants(2, L, nf, frames, ts))
+    tgt = synth_target(ts, L)
+    norms = norms_default()
+    _, sims, boosts = O.correlation_run(corr_config(ts, L, num_matches=3), tgt, norms, db)
+    _load(ctx, db, norms)
+    ctx.corr_set_target(tgt[ts:ts + L], 0.5, 8.0)
+    assert ctx.screen_f16_available
+    ctx.corr_run_screen_f16(0, nf)
+    for f in range(nf):
+        gs, gb = ctx.corr_read_dense(f)
+        open_ = boosts[f] <= 8.0 * (1 - 1e-4)  # away from the boost gate
+        d = gs.astype(np.float64) - sims[f]
+        assert np.all(d[open_] >= 0.0)
+        assert np.all(d[open_] <= 2e-2)
+        np.testing.assert_allclose(gb, boosts[f], rtol=2e-6, atol=0)
+    cands = ctx.corr_compact(0, nf, 0.2, 1 << 16, rescore=True)
+    assert len(cands) > 0
+    for c in cands:
+        assert abs(float(c["sim"]) - float(sims[c["file"]][c["offset"]])) <= 1.2e-7
+
+
+def test_screening_f16_needs_norms(ctx):
+    import strugatzki_amd as S
+    from strugatzki_amd import _native as N
+    db = synth_db(1, 300)
+    _load(ctx, db, None)
+    ctx.corr_set_target(synth_target(3, 50)[3:53], 0.5, 8.0)
+    assert not ctx.screen_f16_available
+    with pytest.raises(N.NativeError):
+        ctx.corr_run_screen_f16(0, 1)
+    got = S.search(ctx, S.SearchParams(1, 1, 0, STEP))  # "auto" falls back to the fp32 screening kernel
+    assert len(got) == 1
+
+
+@pytest.mark.parametrize("screen", [False, "f32", "f16"])
 def test_search_screened_equals_exact(ctx, screen):
     import strugatzki_amd as S
     L, ts, nf, frames = 96, 17, 24, 900
@@ -162,7 +200,7 @@ def test_search_screened_equals_exact(ctx, screen):
     want, _, _ = O.correlation_run(cfg, tgt, norms, db, dense=False)
     _load(ctx, db, norms)
     ctx.corr_set_target(tgt[ts:ts + L], 0.5, 8.0)
-    got = S.search(ctx, S.SearchParams(6, 2, 10 * STEP, STEP, screen=screen))
+    got = S.search(ctx, S.SearchParams(6, 2, 10 * STEP, STEP, screen=bool(screen), screen_mode=screen or "auto"))
     assert [(g.file, g.start, g.stop) for g in got] == [(w.file, w.start, w.stop) for w in want]
     for g, w in zip(got, want):
         assert abs(g.sim - w.sim) <= 1.2e-7
