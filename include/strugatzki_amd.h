@@ -197,6 +197,26 @@ SGZ_API int sgz_corr_rescore_device(sgz_context *ctx, sgz_candidate *device_cand
 SGZ_API int sgz_corr_compact_rescored(sgz_context *ctx, int file_begin, int file_end, float threshold,
                                       sgz_candidate *out, int64_t capacity, int64_t *count);
 
+/* Search over the bounds of one sgz_corr_run_screen_f16 run that covers files
+ * [0, max(file_end, head_end)), for numPerFile = 1.  A head file (index <
+ * head_end) can only contribute its largest similarity, first occurrence (the
+ * running strict maximum kept by impl/FeatureCorrelationImpl.scala:234-239 with
+ * entryHasSpace :124-128 and addMatch :136-150), so only windows whose upper
+ * bound reaches the file's largest lower bound are collected from it; from the
+ * other files, windows whose upper bound exceeds the smallest of those head
+ * bounds, below which the worst entry of a full match set cannot lie.  The
+ * device variant appends to `device_out` / `*device_count` as
+ * sgz_corr_compact_device does; sgz_corr_compact_bounded re-scores the
+ * candidates exactly and returns them sorted by (file, offset).  Head files
+ * that hold a NaN similarity or no window, and files outside the
+ * half-precision range, make the count exceed the capacity (SGZ_E_OVERFLOW):
+ * the caller then takes the exact path. */
+SGZ_API int sgz_corr_compact_bounded_device(sgz_context *ctx, int file_begin, int file_end, int head_end,
+                                            sgz_candidate *device_out, int64_t capacity,
+                                            unsigned long long *device_count);
+SGZ_API int sgz_corr_compact_bounded(sgz_context *ctx, int file_begin, int file_end, int head_end,
+                                     sgz_candidate *out, int64_t capacity, int64_t *count);
+
 /* Milliseconds the GPU spent in the last sgz_corr_run's correlation kernel
  * (HIP events on the context's stream); < 0 if none has completed. */
 SGZ_API float sgz_corr_last_kernel_ms(sgz_context *ctx);
@@ -225,6 +245,16 @@ SGZ_API int sgz_sel_feed_file(sgz_selector *sel, int file, int64_t n, const int3
  * file that occurs in it, in ascending file order (files without candidates
  * need no call: nothing of theirs could pass the gate). */
 SGZ_API int sgz_sel_feed_candidates(sgz_selector *sel, const sgz_candidate *cands, int64_t n);
+/* Feeds the exactly re-scored candidates of sgz_corr_compact_bounded (sorted by
+ * (file, offset), files 0 .. num_files-1, the first head_files of them head
+ * files): per head file its largest similarity, first occurrence, then the
+ * rest through sgz_sel_feed_candidates.  Needs numPerFile = 1.  Returns
+ * SGZ_E_STATE when the shortcut does not apply (a head file without candidate,
+ * a NaN similarity, equal similarities that leave the set short of numMatches
+ * before the tail): the selector is then partly fed and must be discarded, and
+ * the caller takes the exact path. */
+SGZ_API int sgz_sel_feed_screened(sgz_selector *sel, const sgz_candidate *cands, int64_t n, int head_files,
+                                  int num_files);
 /* 1 once allPrio holds num_matches entries: from then on only windows with
  * sim > sgz_sel_threshold() can still be offered. */
 SGZ_API int sgz_sel_is_full(const sgz_selector *sel);

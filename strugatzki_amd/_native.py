@@ -86,6 +86,8 @@ SIGNATURES = {
     "sgz_corr_compact_device": (C.c_int, [_vp, C.c_int, C.c_int, C.c_float, _vp, C.c_int64, _vp]),
     "sgz_corr_rescore_device": (C.c_int, [_vp, _vp, C.c_int64, _vp]),
     "sgz_corr_compact_rescored": (C.c_int, [_vp, C.c_int, C.c_int, C.c_float, _vp, C.c_int64, C.POINTER(C.c_int64)]),
+    "sgz_corr_compact_bounded": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int64, C.POINTER(C.c_int64)]),
+    "sgz_corr_compact_bounded_device": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int64, _vp]),
     "sgz_corr_last_kernel_ms": (C.c_float, [_vp]),
     "sgz_last_kernel_ms": (C.c_float, [_vp]),
     "sgz_corr_last_work": (C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
@@ -93,6 +95,7 @@ SIGNATURES = {
     "sgz_sel_destroy": (None, [_vp]),
     "sgz_sel_feed_file": (C.c_int, [_vp, C.c_int, C.c_int64, _vp, _vp, _vp]),
     "sgz_sel_feed_candidates": (C.c_int, [_vp, _vp, C.c_int64]),
+    "sgz_sel_feed_screened": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int]),
     "sgz_sel_is_full": (C.c_int, [_vp]),
     "sgz_sel_threshold": (C.c_float, [_vp]),
     "sgz_sel_result": (C.c_int, [_vp, C.POINTER(Match), C.c_int]),

@@ -548,6 +548,97 @@ __global__ __launch_bounds__(256) void compact_kernel(const FileDesc *__restrict
 }
 
 // ---------------------------------------------------------------------------
+// Search over bounds (half-precision screening run): with numPerFile = 1 a head
+// file contributes its largest similarity, first occurrence (the sliding loop of
+// impl/FeatureCorrelationImpl.scala:234-239 keeps a running strict maximum).
+// file_bound_kernel finds, per head file, the largest lower bound: every window
+// whose upper bound reaches it may hold the maximum.  bound_min_kernel takes the
+// minimum of those over the head files: no match set that the head files fill
+// can end with a smaller worst entry, so tail windows whose upper bound does not
+// exceed it cannot be offered.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void file_bound_kernel(const FileDesc *__restrict__ files,
+                                                          const float *__restrict__ up,
+                                                          const float *__restrict__ lo, float *__restrict__ thr,
+                                                          int *__restrict__ hflags)
+{
+    __shared__ float wmax[16];
+    __shared__ int wbad[16];
+    const FileDesc fd = files[blockIdx.x];
+    float best = -INFINITY;
+    int bad = 0;
+    for (long long o = threadIdx.x; o < fd.num_windows; o += 1024) {
+        const float l = lo[fd.win_off + o], u = up[fd.win_off + o];
+        bad |= (l != l) || (u != u);
+        best = fmaxf(best, l);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        best = fmaxf(best, __shfl_xor(best, off, 64));
+        bad |= __shfl_xor(bad, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        wmax[threadIdx.x >> 6] = best;
+        wbad[threadIdx.x >> 6] = bad;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 16; k++) {
+            best = fmaxf(best, wmax[k]);
+            bad |= wbad[k];
+        }
+        thr[blockIdx.x] = best;
+        // a NaN similarity changes what the reference's loop keeps: leave such files to the exact path
+        if (bad || fd.num_windows == 0) hflags[blockIdx.x] = hflags[blockIdx.x] | 2;
+    }
+}
+
+__global__ __launch_bounds__(64) void bound_min_kernel(float *__restrict__ thr, int n)
+{
+    float v = INFINITY;
+    for (int k = threadIdx.x; k < n; k += 64) v = fminf(v, thr[k]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
+    if (threadIdx.x == 0) thr[n] = v;
+}
+
+// Windows of head files (file < headEnd) whose upper bound reaches the file's own bound, windows of the
+// other files whose upper bound exceeds the minimum of the head bounds (thr[headEnd]).
+__global__ __launch_bounds__(256) void compact_bounded_kernel(const FileDesc *__restrict__ files,
+                                                              const TileDesc *__restrict__ tiles,
+                                                              const float *__restrict__ up,
+                                                              const float *__restrict__ boost,
+                                                              const float *__restrict__ thr, int headEnd,
+                                                              sgz_candidate *__restrict__ out, long long capacity,
+                                                              unsigned long long *__restrict__ count,
+                                                              const int *__restrict__ hflags)
+{
+    const TileDesc td = tiles[blockIdx.x];
+    const FileDesc fd = files[td.file];
+    if (hflags[td.file] && td.o0 == 0 && threadIdx.x == 0) atomicAdd(count, (unsigned long long)capacity + 1ull);
+    const bool headFile = td.file < headEnd;
+    const float t = headFile ? thr[td.file] : thr[headEnd];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const long long o = (long long)td.o0 + k * 256 + threadIdx.x;
+        if (o < fd.num_windows) {
+            const float s = up[fd.win_off + o];
+            if (headFile ? s >= t : s > t) {
+                const unsigned long long slot = atomicAdd(count, 1ull);
+                if ((long long)slot < capacity) {
+                    sgz_candidate c;
+                    c.file = td.file;
+                    c.offset = (int)o;
+                    c.sim = s;
+                    c.boost = boost[fd.win_off + o];
+                    out[slot] = c;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // rescore_kernel: exact re-evaluation of listed windows, one workgroup per
 // window, straight from the raw frames with the reference's own two-pass
 // arithmetic (MathUtil.stat then MathUtil.correlate, impl/MathUtil.scala:29-62,
@@ -766,6 +857,8 @@ int build_layout(sgz_context *ctx)
     if ((rc = ensure(ctx, ctx->d_tbase, ctx->tbase_cap, (size_t)tb))) return rc;
     if ((rc = ensure(ctx, ctx->d_sim, ctx->dense_cap, (size_t)wins))) return rc;
     if ((rc = ensure(ctx, ctx->d_boost, ctx->boost_cap, (size_t)wins))) return rc;
+    if (halfOk && (rc = ensure(ctx, ctx->d_lo, ctx->lo_cap, (size_t)wins))) return rc;
+    ctx->lo_begin = ctx->lo_end = 0;
     // the three tables are consumed by kernels queued later on ctx->stream
     if (nf) SGZ_HIP(ctx, hipMemcpyAsync(ctx->d_files, ctx->h_files.data(), sizeof(FileDesc) * nf,
                                         hipMemcpyHostToDevice, ctx->stream));
@@ -1108,6 +1201,12 @@ static int corr_run_impl(sgz_context *ctx, int file_begin, int file_end, int mod
     SGZ_HIP(ctx, hipGetLastError());
     SGZ_HIP(ctx, hipEventRecord(ctx->ev1, stream));
     ctx->ev_valid = true;
+    if (half) {
+        ctx->lo_begin = file_begin;
+        ctx->lo_end = file_end;
+    } else if (file_begin < ctx->lo_end && file_end > ctx->lo_begin) {
+        ctx->lo_begin = ctx->lo_end = 0;  // these files no longer hold bounds
+    }
     // completion marker of this run, so that reading results of an earlier run
     // does not have to wait for later ones
     {
@@ -1193,6 +1292,40 @@ int sgz_corr_compact_device(sgz_context *ctx, int file_begin, int file_end, floa
     return SGZ_OK;
 }
 
+int sgz_corr_compact_bounded_device(sgz_context *ctx, int file_begin, int file_end, int head_end,
+                                    sgz_candidate *device_out, int64_t capacity, unsigned long long *device_count)
+{
+    if (!ctx) return SGZ_E_ARG;
+    if (ctx->layout_dirty || !ctx->have_target) return ctx->fail(SGZ_E_STATE, "no correlation results");
+    const int nf = (int)ctx->files.size();
+    if (file_begin < 0 || file_end > nf || file_begin > file_end) return ctx->fail(SGZ_E_ARG, "bad file range");
+    if (head_end < 1 || head_end > nf) return ctx->fail(SGZ_E_ARG, "bad head_end");
+    if (!device_count || capacity < 0 || (capacity > 0 && !device_out))
+        return ctx->fail(SGZ_E_ARG, "bad output buffers");
+    const int need_end = std::max(file_end, head_end);
+    if (ctx->lo_begin != 0 || ctx->lo_end < need_end)
+        return ctx->fail(SGZ_E_STATE, "files are not covered by one sgz_corr_run_screen_f16 run starting at file 0");
+    SGZ_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = ensure(ctx, ctx->d_thr, ctx->thr_cap, (size_t)nf + 1))) return rc;
+    for (const auto &run : ctx->runs)
+        if (run.fb < need_end) SGZ_HIP(ctx, hipStreamWaitEvent(ctx->stream, run.done, 0));
+    SGZ_HIP(ctx, hipMemsetAsync(device_count, 0, sizeof(unsigned long long), ctx->stream));
+    hipLaunchKernelGGL(file_bound_kernel, dim3(head_end), dim3(1024), 0, ctx->stream, ctx->d_files, ctx->d_sim,
+                       ctx->d_lo, ctx->d_thr, ctx->d_hflags);
+    SGZ_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(bound_min_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->d_thr, head_end);
+    SGZ_HIP(ctx, hipGetLastError());
+    const int t0 = ctx->tile_begin[file_begin], t1 = ctx->tile_begin[file_end];
+    if (t1 > t0) {
+        hipLaunchKernelGGL(compact_bounded_kernel, dim3(t1 - t0), dim3(256), 0, ctx->stream, ctx->d_files,
+                           ctx->d_tiles + t0, ctx->d_sim, ctx->d_boost, ctx->d_thr, head_end, device_out,
+                           (long long)capacity, device_count, ctx->d_hflags);
+        SGZ_HIP(ctx, hipGetLastError());
+    }
+    return SGZ_OK;
+}
+
 int sgz_corr_rescore_device(sgz_context *ctx, sgz_candidate *device_cands, int64_t capacity,
                             const unsigned long long *device_count)
 {
@@ -1209,7 +1342,15 @@ int sgz_corr_rescore_device(sgz_context *ctx, sgz_candidate *device_cands, int64
 }
 
 static int compact_host(sgz_context *ctx, int file_begin, int file_end, float threshold, bool rescore,
-                        sgz_candidate *out, int64_t capacity, int64_t *count);
+                        sgz_candidate *out, int64_t capacity, int64_t *count, int head_end = 0);
+
+int sgz_corr_compact_bounded(sgz_context *ctx, int file_begin, int file_end, int head_end, sgz_candidate *out,
+                             int64_t capacity, int64_t *count)
+{
+    if (!ctx) return SGZ_E_ARG;
+    if (head_end < 1) return ctx->fail(SGZ_E_ARG, "bad head_end");
+    return compact_host(ctx, file_begin, file_end, 0.0f, true, out, capacity, count, head_end);
+}
 
 int sgz_corr_compact_rescored(sgz_context *ctx, int file_begin, int file_end, float threshold, sgz_candidate *out,
                               int64_t capacity, int64_t *count)
@@ -1224,7 +1365,7 @@ int sgz_corr_compact(sgz_context *ctx, int file_begin, int file_end, float thres
 }
 
 static int compact_host(sgz_context *ctx, int file_begin, int file_end, float threshold, bool rescore,
-                        sgz_candidate *out, int64_t capacity, int64_t *count)
+                        sgz_candidate *out, int64_t capacity, int64_t *count, int head_end)
 {
     if (!ctx) return SGZ_E_ARG;
     if (!count || capacity < 0 || (capacity > 0 && !out)) return ctx->fail(SGZ_E_ARG, "bad output buffers");
@@ -1233,21 +1374,24 @@ static int compact_host(sgz_context *ctx, int file_begin, int file_end, float th
     // device buffer = [one record-sized header holding the count][capacity records]
     if ((rc = ensure(ctx, ctx->d_cand, ctx->cand_cap, (size_t)capacity + 1))) return rc;
     unsigned long long *d_count = reinterpret_cast<unsigned long long *>(ctx->d_cand);
-    if ((rc = sgz_corr_compact_device(ctx, file_begin, file_end, threshold, ctx->d_cand + 1, capacity, d_count)))
-        return rc;
+    if (head_end > 0)
+        rc = sgz_corr_compact_bounded_device(ctx, file_begin, file_end, head_end, ctx->d_cand + 1, capacity, d_count);
+    else
+        rc = sgz_corr_compact_device(ctx, file_begin, file_end, threshold, ctx->d_cand + 1, capacity, d_count);
+    if (rc) return rc;
     if (rescore && (rc = sgz_corr_rescore_device(ctx, ctx->d_cand + 1, capacity, d_count))) return rc;
     // first transfer: header + as many records as usually suffice
     const size_t first = (size_t)std::min<int64_t>(capacity, 1023);
-    ctx->h_cand.resize(first + 1);
-    SGZ_HIP(ctx, hipMemcpyAsync(ctx->h_cand.data(), ctx->d_cand, sizeof(sgz_candidate) * (first + 1),
+    if (!ctx->h_pinned) SGZ_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_pinned), sizeof(sgz_candidate) * 1024));
+    SGZ_HIP(ctx, hipMemcpyAsync(ctx->h_pinned, ctx->d_cand, sizeof(sgz_candidate) * (first + 1),
                                 hipMemcpyDeviceToHost, ctx->stream));
     SGZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     unsigned long long n = 0;
-    std::memcpy(&n, ctx->h_cand.data(), sizeof n);
+    std::memcpy(&n, ctx->h_pinned, sizeof n);
     *count = (int64_t)n;
     const size_t got = (size_t)std::min<unsigned long long>(n, (unsigned long long)capacity);
     const size_t inFirst = std::min(got, first);
-    if (inFirst) std::memcpy(out, ctx->h_cand.data() + 1, sizeof(sgz_candidate) * inFirst);
+    if (inFirst) std::memcpy(out, ctx->h_pinned + 1, sizeof(sgz_candidate) * inFirst);
     if (got > first)
         SGZ_HIP(ctx, hipMemcpy(out + first, ctx->d_cand + 1 + first, sizeof(sgz_candidate) * (got - first),
                                hipMemcpyDeviceToHost));

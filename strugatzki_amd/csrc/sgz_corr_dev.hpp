@@ -20,14 +20,15 @@ struct Epilogue {
 };
 
 // kUpper = false: the similarity as the reference computes it.
-// kUpper = true (screening with reduced-precision products of relative error <= relErr): an upper bound of
-// it.  By Cauchy-Schwarz the error of a normalised cross term is at most relErr * sqrt(1 + (dm / sd)^2), dm
-// the offset of the window mean from the centring constant, sd the window std-dev; a window without spread
-// gets +inf (always re-scored), and the boost gate is taken with a small slack.
+// kUpper = true (screening with reduced-precision products of relative error <= relErr): simOut is an upper
+// bound of it and *loOut (if given) a lower bound.  By Cauchy-Schwarz the error of a normalised cross term
+// is at most relErr * sqrt(1 + (dm / sd)^2), dm the offset of the window mean from the centring constant,
+// sd the window std-dev.  A window without spread gets (-inf, +inf); a boost within 1e-5 of the gate makes
+// the bounds include 0, the value of a gated window.
 template <bool kUpper = false>
 __device__ __forceinline__ void window_result(const CorrParams &cp, const Epilogue &ep, long long o,
                                               double crossT, double crossS, float &simOut, float &boostOut,
-                                              float relErr = 0.0f)
+                                              float relErr = 0.0f, float *loOut = nullptr)
 {
     const double nT = (double)cp.L;
     const double nS = (double)cp.L * (double)(cp.numCh - 1);
@@ -36,7 +37,7 @@ __device__ __forceinline__ void window_result(const CorrParams &cp, const Epilog
     const float avgF = (float)avgD;  // MathUtil.avg returns Float
     const double lnAvgB = log((double)avgF);
     const float boost = (float)exp((cp.lnAvgIn - lnAvgB) / 0.6);
-    float sim = 0.0f;
+    float sim = 0.0f, lo = 0.0f;
     const bool open = kUpper ? boost <= cp.maxBoost * 1.00001f : boost <= cp.maxBoost;
     if (open) {
         float temporal = 0.0f, spectral = 0.0f, errT = 0.0f, errS = 0.0f;
@@ -60,11 +61,23 @@ __device__ __forceinline__ void window_result(const CorrParams &cp, const Epilog
         sim = temporal * cp.w + spectral * (1.0f - cp.w);  // fp32, no contraction (-ffp-contract=off)
         if (kUpper) {
             const float e = errT * cp.w + errS * (1.0f - cp.w) + 1e-5f;
-            sim = e < INFINITY && sim == sim ? sim + e : INFINITY;
+            const bool finite = e < INFINITY && fabsf(sim) < INFINITY;  // false for NaN as well
+            const bool isNan = sim != sim && e < INFINITY;               // NaN data: stays NaN, as in the exact path
+            if (!isNan) {
+                lo = finite ? sim - e : -INFINITY;
+                sim = finite ? sim + e : INFINITY;
+            } else {
+                lo = sim;
+            }
+            if (boost > cp.maxBoost * 0.99999f) {  // the exact path may gate this window
+                sim = fmaxf(sim, 0.0f);
+                lo = fminf(lo, 0.0f);
+            }
         }
     }
     simOut = sim;
     boostOut = boost;
+    if (kUpper && loOut) *loOut = lo;
 }
 
 }  // namespace sgz

@@ -56,7 +56,7 @@ template <int NSTAGE>
 __global__ __launch_bounds__(kHThreads, 4) void corr_mfma_kernel(
     const FileDesc *__restrict__ files, const TileDesc *__restrict__ tiles, const _Float16 *__restrict__ planarH,
     const double *__restrict__ prefix, const double *__restrict__ tbase, const uint32_t *__restrict__ aimg,
-    CorrParams cp, HalfGeom hg, float *__restrict__ simOut, float *__restrict__ boostOut)
+    CorrParams cp, HalfGeom hg, float *__restrict__ simOut, float *__restrict__ boostOut, float *__restrict__ loOut)
 {
     constexpr int NB = kHNB;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -190,9 +190,11 @@ __global__ __launch_bounds__(kHThreads, 4) void corr_mfma_kernel(
         const long long o = (long long)td.o0 + wdw;
         if (o < fd.num_windows) {
             float sim, boost;
-            window_result<true>(cph, ep, o, (double)redT[wdw], (double)redS[wdw], sim, boost, kHalfRelErr);
+            float lo;
+            window_result<true>(cph, ep, o, (double)redT[wdw], (double)redS[wdw], sim, boost, kHalfRelErr, &lo);
             simOut[fd.win_off + o] = sim;
             boostOut[fd.win_off + o] = boost;
+            loOut[fd.win_off + o] = lo;
         }
     }
 }
@@ -275,7 +277,7 @@ int half_screen_launch(sgz_context *ctx, int tile_begin, int tile_end, hipStream
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
         hipLaunchKernelGGL(kern, dim3(tile_end - tile_begin), dim3(kHThreads), ldsBytes, stream, ctx->d_files,
                            ctx->d_tiles_h + tile_begin, planarH, ctx->d_prefix, ctx->d_tbase, aimg, ctx->cp, hg,
-                           ctx->d_sim, ctx->d_boost);
+                           ctx->d_sim, ctx->d_boost, ctx->d_lo);
     } else {
         auto kern = corr_mfma_kernel<kHStageV>;
         if (ldsBytes > 64 * 1024)
@@ -283,7 +285,7 @@ int half_screen_launch(sgz_context *ctx, int tile_begin, int tile_end, hipStream
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
         hipLaunchKernelGGL(kern, dim3(tile_end - tile_begin), dim3(kHThreads), ldsBytes, stream, ctx->d_files,
                            ctx->d_tiles_h + tile_begin, planarH, ctx->d_prefix, ctx->d_tbase, aimg, ctx->cp, hg,
-                           ctx->d_sim, ctx->d_boost);
+                           ctx->d_sim, ctx->d_boost, ctx->d_lo);
     }
     SGZ_HIP(ctx, hipGetLastError());
     return SGZ_OK;

@@ -140,6 +140,12 @@ struct sgz_context {
     float *d_sim = nullptr;
     float *d_boost = nullptr;
     size_t dense_cap = 0, boost_cap = 0;
+    float *d_lo = nullptr;                   // lower bounds of the half-precision screening run
+    size_t lo_cap = 0;
+    int lo_begin = 0, lo_end = 0;            // files whose d_sim / d_lo hold bounds of the latest such run
+    float *d_thr = nullptr;                  // per head file: largest lower bound; then their minimum
+    size_t thr_cap = 0;
+    sgz_candidate *h_pinned = nullptr;       // pinned staging of the first candidate transfer
 
     sgz_candidate *d_cand = nullptr;         // [count header][records]
     size_t cand_cap = 0;

@@ -207,6 +207,27 @@ int sgz_sel_feed_candidates(sgz_selector *sel, const sgz_candidate *cands, int64
     return SGZ_OK;
 }
 
+int sgz_sel_feed_screened(sgz_selector *sel, const sgz_candidate *cands, int64_t n, int head_files, int num_files)
+{
+    if (!sel || n < 0 || (n > 0 && !cands) || head_files < 0 || num_files < head_files) return SGZ_E_ARG;
+    if (sel->num_per_file != 1) return SGZ_E_STATE;
+    int64_t i = 0;
+    for (int f = 0; f < head_files; f++) {
+        if (i >= n || cands[i].file != f) return SGZ_E_STATE;  // a head file without windows
+        int64_t best = i, j = i;
+        for (; j < n && cands[j].file == f; j++) {
+            if (j > i && cands[j].offset <= cands[j - 1].offset) return SGZ_E_ARG;  // must be sorted
+            if (cands[j].sim != cands[j].sim) return SGZ_E_STATE;                   // NaN: order matters
+            if (cands[j].sim > cands[best].sim) best = j;                            // strict: first occurrence
+        }
+        const int rc = sgz_sel_feed_file(sel, f, 1, &cands[best].offset, &cands[best].sim, &cands[best].boost);
+        if (rc != SGZ_OK) return rc;
+        i = j;
+    }
+    if (head_files < num_files && !sgz_sel_is_full(sel)) return SGZ_E_STATE;  // the loop would go on densely
+    return sgz_sel_feed_candidates(sel, cands + i, n - i);
+}
+
 int sgz_sel_is_full(const sgz_selector *sel)
 {
     return sel && (int)sel->all.size() >= sel->num_matches ? 1 : 0;

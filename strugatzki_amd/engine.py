@@ -154,6 +154,21 @@ class Context:
         self._check(rc)
         return out[: cnt.value]
 
+    def corr_compact_bounded(self, file_begin: int, file_end: int, head_end: int, capacity: int) -> np.ndarray:
+        """Exactly re-scored candidates of a search over the bounds of a corr_run_screen_f16 run
+        (numPerFile = 1), sorted by (file, offset); raises NativeError(SGZ_E_OVERFLOW) when the exact path
+        has to be taken."""
+        out = np.empty(max(capacity, 1), dtype=N.CANDIDATE_DTYPE)
+        cnt = C.c_int64(0)
+        self._check(lib.sgz_corr_compact_bounded(self._h, file_begin, file_end, head_end, N.ptr(out), capacity,
+                                                 C.byref(cnt)))
+        return out[: cnt.value]
+
+    def corr_compact_bounded_device(self, file_begin: int, file_end: int, head_end: int, out_ptr: int,
+                                    capacity: int, count_ptr: int) -> None:
+        self._check(lib.sgz_corr_compact_bounded_device(self._h, file_begin, file_end, head_end,
+                                                        C.c_void_p(out_ptr), capacity, C.c_void_p(count_ptr)))
+
     def corr_compact_device(self, file_begin: int, file_end: int, threshold: float, out_ptr: int,
                             capacity: int, count_ptr: int) -> None:
         self._check(lib.sgz_corr_compact_device(self._h, file_begin, file_end, threshold,
@@ -258,6 +273,17 @@ class Selector:
         rc = lib.sgz_sel_feed_candidates(self._h, N.ptr(c), c.shape[0])
         if rc != N.SGZ_OK:
             raise N.NativeError(rc, "sgz_sel_feed_candidates (candidates not sorted by file, offset?)")
+
+    def feed_screened(self, cands: np.ndarray, head_files: int, num_files: int) -> bool:
+        """Feeds the re-scored candidates of Context.corr_compact_bounded.  False: the shortcut does not
+        apply, this selector must be discarded and the exact path taken."""
+        c = np.ascontiguousarray(cands, dtype=N.CANDIDATE_DTYPE)
+        rc = lib.sgz_sel_feed_screened(self._h, N.ptr(c), c.shape[0], head_files, num_files)
+        if rc == N.SGZ_E_STATE:
+            return False
+        if rc != N.SGZ_OK:
+            raise N.NativeError(rc, "sgz_sel_feed_screened")
+        return True
 
     @property
     def is_full(self) -> bool:

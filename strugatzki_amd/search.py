@@ -43,6 +43,7 @@ class SearchParams:
     screen_mode: str = "auto"  # "f16": half-precision matrix-core kernel, "f32": fp32-product kernel,
                                # "auto": f16 where available (normalised features, target fits LDS), else f32
     margin: float | None = None  # screening keeps windows with sim > T0 - margin; None: per mode (MARGIN)
+    screen_head: bool = True   # numPerFile == 1 and f16 screening: the head files are screened as well
 
 
 # Default margins.  f32: many times the largest screening error observed against the exact kernel
@@ -75,9 +76,32 @@ def _feed_dense_head(ctx: Context, sel: Selector, files: Sequence[int], global_i
     return len(files)
 
 
+def _search_over_bounds(ctx: Context, p: SearchParams, head: int) -> list[N.Match] | None:
+    """All files through the half-precision kernel; the bounds it writes pick the windows that are re-scored
+    exactly (Context.corr_compact_bounded).  None: the shortcut does not apply (see sgz_sel_feed_screened)."""
+    nf = ctx.num_files
+    ctx.corr_run_screen_f16(0, nf)
+    try:
+        cands = ctx.corr_compact_bounded(0, nf, head, p.capacity)
+    except N.NativeError as e:
+        if e.code != N.SGZ_E_OVERFLOW:
+            raise
+        return None
+    sel = Selector(p.num_matches, p.num_per_file, p.min_spacing, p.step_size, ctx.target_frames)
+    try:
+        return sel.result() if sel.feed_screened(cands, head, nf) else None
+    finally:
+        sel.close()
+
+
 def search(ctx: Context, p: SearchParams) -> list[N.Match]:
     """Single-GPU search over all files of the context, in their index order."""
     nf = ctx.num_files
+    if (p.screen and p.screen_head and p.num_per_file == 1 and p.num_matches >= 1 and nf > 0
+            and _screen_mode(ctx, p) == "f16"):
+        out = _search_over_bounds(ctx, p, min(nf, p.num_matches))
+        if out is not None:
+            return out
     sel = Selector(p.num_matches, p.num_per_file, p.min_spacing, p.step_size, ctx.target_frames)
     head = min(nf, max(p.num_matches, 1))
     ctx.corr_run(0, head)

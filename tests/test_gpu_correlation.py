@@ -206,6 +206,39 @@ def test_search_screened_equals_exact(ctx, screen):
         assert abs(g.sim - w.sim) <= 1.2e-7
 
 
+@pytest.mark.parametrize("case", ["duplicate_head_files", "short_head_file", "single_file", "fewer_files_than_matches"])
+def test_search_over_bounds_and_its_fallbacks(ctx, case):
+    """numPerFile = 1 with f16 screening searches over bounds; cases it cannot decide go to the exact path."""
+    import strugatzki_amd as S
+    L, ts, nf, frames = 96, 17, 12, 900
+    fr = [frames] * nf
+    num_matches = 5
+    if case == "short_head_file":
+        fr[2] = L - 1
+    if case == "single_file":
+        nf, fr = 1, [frames]
+    if case == "fewer_files_than_matches":
+        nf, fr = 3, [frames] * 3
+    db = synth_db(nf, fr, make_plants(4, L, nf, frames, ts))
+    if case == "duplicate_head_files":
+        db[1] = db[0].copy()  # equal best sims collapse in the reference's sorted set
+    tgt = synth_target(ts, L)
+    norms = norms_default()
+    cfg = corr_config(ts, L, num_matches=num_matches, num_per_file=1)
+    _load(ctx, db, norms)
+    ctx.corr_set_target(tgt[ts:ts + L], 0.5, 8.0)
+    if case == "short_head_file":
+        # the reference's stale-ring window for files shorter than the target is not reproduced by either
+        # GPU path: compare with the exact GPU search instead of the oracle
+        want = S.search(ctx, S.SearchParams(num_matches, 1, 0, STEP, screen=False))
+    else:
+        want, _, _ = O.correlation_run(cfg, tgt, norms, db, dense=False)
+    got = S.search(ctx, S.SearchParams(num_matches, 1, 0, STEP))
+    assert [(g.file, g.start, g.stop) for g in got] == [(w.file, w.start, w.stop) for w in want]
+    for g, w in zip(got, want):
+        assert abs(g.sim - w.sim) <= 1.2e-7
+
+
 def test_search_falls_back_to_dense_on_candidate_overflow(ctx):
     import strugatzki_amd as S
     L, ts, nf, frames = 64, 4, 6, 500
