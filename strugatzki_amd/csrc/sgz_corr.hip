@@ -655,14 +655,11 @@ __device__ __forceinline__ double block_sum(double v, double *scratch /* kRescor
     __syncthreads();  // scratch may still be read from the previous call
     if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
     __syncthreads();
-    double p[kRescoreWaves];
+    static_assert(kRescoreWaves == 16, "the cross-wave step folds 16 partial sums");
+    double p = scratch[threadIdx.x & 15];
 #pragma unroll
-    for (int k = 0; k < kRescoreWaves; k++) p[k] = scratch[k];
-#pragma unroll
-    for (int w = kRescoreWaves / 2; w >= 1; w >>= 1)
-#pragma unroll
-        for (int k = 0; k < w; k++) p[k] += p[k + w];
-    return p[0];
+    for (int off = 8; off >= 1; off >>= 1) p += __shfl_xor(p, off, 64);
+    return p;
 }
 
 __global__ __launch_bounds__(kRescoreThreads) void rescore_kernel(
@@ -754,6 +751,121 @@ __global__ __launch_bounds__(kRescoreThreads) void rescore_kernel(
         xT = block_sum(xT, scratch);
         xS = block_sum(xS, scratch);
         if (threadIdx.x == 0) {
+            const float avgF = (float)bMeanT;
+            const double lnAvgB = log((double)avgF);
+            const float boost = (float)exp((cp.lnAvgIn - lnAvgB) / 0.6);
+            float sim = 0.0f;
+            if (boost <= cp.maxBoost) {
+                float temporal = 0.0f, spectral = 0.0f;
+                if (cp.w > 0.0f) temporal = (float)(xT / (cp.aStdT * sqrt(qT / nT) * nT));
+                if (cp.w < 1.0f) spectral = (float)(xS / (cp.aStdS * sqrt(qS / nS) * nS));
+                sim = temporal * cp.w + spectral * (1.0f - cp.w);
+            }
+            cands[ci].sim = sim;
+            cands[ci].boost = boost;
+        }
+    }
+}
+
+// LDS-resident variant for windows of at most 36 K values: the normalised values of the window are kept in
+// LDS between the two passes (one read of the raw frames, one fp32 division per value), eight loads in
+// flight per thread.
+__global__ __launch_bounds__(kRescoreThreads) void rescore_lds_kernel(
+    const FileDesc *__restrict__ files, const float *__restrict__ tnorm, NormParams nrm, CorrParams cp,
+    double aMeanT, double aMeanS, sgz_candidate *__restrict__ cands, const unsigned long long *__restrict__ count,
+    long long capacity)
+{
+    constexpr int NT = kRescoreThreads, U = 8;
+    extern __shared__ __attribute__((aligned(16))) float vals[];
+    __shared__ double scratch[kRescoreWaves];
+    __shared__ float smn[SGZ_MAX_CHANNELS], sdv[SGZ_MAX_CHANNELS];
+    const long long n = min((long long)*count, capacity);
+    if ((long long)blockIdx.x >= n) return;
+    const int numCh = cp.numCh, L = cp.L;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int c = 0; c < SGZ_MAX_CHANNELS; c++) {  // static indices: the parameter block stays in scalar registers
+        if (tid == c) {
+            smn[c] = nrm.mn[c];
+            sdv[c] = nrm.d[c];
+        }
+    }
+    const int total = L * numCh;
+    const int di = NT / numCh, dc = NT - di * numCh;
+    const int i0 = tid / numCh, c0 = tid - i0 * numCh;
+    const double nT = (double)L, nS = (double)L * (double)(numCh - 1);
+    for (long long ci = blockIdx.x; ci < n; ci += gridDim.x) {
+        __syncthreads();  // smn / sdv written; vals of the previous window no longer read
+        const sgz_candidate cd = cands[ci];
+        const FileDesc fd = files[cd.file];
+        const float *raw = fd.raw + (long long)cd.offset * numCh;
+        double sT = 0.0, sS = 0.0;
+        {
+            int c = c0, e = tid;
+            auto add = [&](float v, int ee) {
+                if (nrm.enabled) v = (v - smn[c]) / sdv[c];
+                vals[ee] = v;
+                if (c == 0) sT += (double)v; else sS += (double)v;
+                c += dc;
+                if (c >= numCh) c -= numCh;
+            };
+            for (; e + (U - 1) * NT < total; e += U * NT) {
+                float v[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) v[u] = raw[e + u * NT];
+#pragma unroll
+                for (int u = 0; u < U; u++) add(v[u], e + u * NT);
+            }
+            for (; e < total; e += NT) add(raw[e], e);
+        }
+        sT = block_sum(sT, scratch);
+        sS = block_sum(sS, scratch);
+        const double bMeanT = sT / nT, bMeanS = sS / nS;
+        double qT = 0.0, qS = 0.0, xT = 0.0, xS = 0.0;
+        {
+            int i = i0, c = c0, e = tid;
+            auto next = [&](int &ii, int &cc) {
+                ii += di;
+                cc += dc;
+                if (cc >= numCh) {
+                    cc -= numCh;
+                    ii += 1;
+                }
+            };
+            auto add = [&](float v, float af, int cc) {
+                const double a = (double)af;
+                if (cc == 0) {
+                    const double d = (double)v - bMeanT;
+                    qT += d * d;
+                    xT += (a - aMeanT) * d;
+                } else {
+                    const double d = (double)v - bMeanS;
+                    qS += d * d;
+                    xS += (a - aMeanS) * d;
+                }
+            };
+            for (; e + (U - 1) * NT < total; e += U * NT) {
+                float af[U];
+                int cs[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    af[u] = tnorm[(long long)c * L + i];
+                    cs[u] = c;
+                    next(i, c);
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) add(vals[e + u * NT], af[u], cs[u]);
+            }
+            for (; e < total; e += NT) {
+                add(vals[e], tnorm[(long long)c * L + i], c);
+                next(i, c);
+            }
+        }
+        qT = block_sum(qT, scratch);
+        qS = block_sum(qS, scratch);
+        xT = block_sum(xT, scratch);
+        xS = block_sum(xS, scratch);
+        if (tid == 0) {
             const float avgF = (float)bMeanT;
             const double lnAvgB = log((double)avgF);
             const float boost = (float)exp((cp.lnAvgIn - lnAvgB) / 0.6);
@@ -1335,8 +1447,20 @@ int sgz_corr_rescore_device(sgz_context *ctx, sgz_candidate *device_cands, int64
     if (capacity == 0) return SGZ_OK;
     SGZ_HIP(ctx, hipSetDevice(ctx->device));
     const int grid = (int)std::min<int64_t>(capacity, 4096);
-    hipLaunchKernelGGL(rescore_kernel, dim3(grid), dim3(kRescoreThreads), 0, ctx->stream, ctx->d_files, ctx->d_tnorm, ctx->norm,
-                       ctx->cp, ctx->aMeanT, ctx->aMeanS, device_cands, device_count, (long long)capacity);
+    const long long perWindow = (long long)ctx->cp.L * ctx->cp.numCh;
+    if (perWindow <= 36 * 1024) {
+        const size_t ldsBytes = (size_t)perWindow * sizeof(float);
+        if (ldsBytes > 48 * 1024)
+            SGZ_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(rescore_lds_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
+        hipLaunchKernelGGL(rescore_lds_kernel, dim3(grid), dim3(kRescoreThreads), ldsBytes, ctx->stream, ctx->d_files,
+                           ctx->d_tnorm, ctx->norm, ctx->cp, ctx->aMeanT, ctx->aMeanS, device_cands, device_count,
+                           (long long)capacity);
+    } else {
+        hipLaunchKernelGGL(rescore_kernel, dim3(grid), dim3(kRescoreThreads), 0, ctx->stream, ctx->d_files,
+                           ctx->d_tnorm, ctx->norm, ctx->cp, ctx->aMeanT, ctx->aMeanS, device_cands, device_count,
+                           (long long)capacity);
+    }
     SGZ_HIP(ctx, hipGetLastError());
     return SGZ_OK;
 }

@@ -43,7 +43,7 @@ class SearchParams:
     screen_mode: str = "auto"  # "f16": half-precision matrix-core kernel, "f32": fp32-product kernel,
                                # "auto": f16 where available (normalised features, target fits LDS), else f32
     margin: float | None = None  # screening keeps windows with sim > T0 - margin; None: per mode (MARGIN)
-    screen_head: bool = True   # numPerFile == 1 and f16 screening: the head files are screened as well
+    screen_head: bool = True   # numPerFile == 1 and f16 screening: search over bounds, no exact head run
 
 
 # Default margins.  f32: many times the largest screening error observed against the exact kernel
@@ -76,20 +76,24 @@ def _feed_dense_head(ctx: Context, sel: Selector, files: Sequence[int], global_i
     return len(files)
 
 
-def _search_over_bounds(ctx: Context, p: SearchParams, head: int) -> list[N.Match] | None:
-    """All files through the half-precision kernel; the bounds it writes pick the windows that are re-scored
-    exactly (Context.corr_compact_bounded).  None: the shortcut does not apply (see sgz_sel_feed_screened)."""
+def _search_over_bounds(ctx: Context, p: SearchParams) -> list[N.Match] | None:
+    """numPerFile = 1: the sliding loop keeps, per file, a running strict maximum of the similarities that
+    exceed the worst global entry (impl/FeatureCorrelationImpl.scala:124-150, :234-239), so a file can only
+    contribute its largest similarity, first occurrence.  All files go through the half-precision kernel;
+    per file, the windows whose upper bound reaches the file's largest lower bound are re-scored exactly
+    (Context.corr_compact_bounded with every file a "head" file), and the exact per-file maxima are fed to
+    the selection in file order.  None: the shortcut does not apply (see sgz_sel_feed_screened)."""
     nf = ctx.num_files
     ctx.corr_run_screen_f16(0, nf)
     try:
-        cands = ctx.corr_compact_bounded(0, nf, head, p.capacity)
+        cands = ctx.corr_compact_bounded(0, nf, nf, p.capacity)
     except N.NativeError as e:
         if e.code != N.SGZ_E_OVERFLOW:
             raise
         return None
     sel = Selector(p.num_matches, p.num_per_file, p.min_spacing, p.step_size, ctx.target_frames)
     try:
-        return sel.result() if sel.feed_screened(cands, head, nf) else None
+        return sel.result() if sel.feed_screened(cands, nf, nf) else None
     finally:
         sel.close()
 
@@ -99,7 +103,7 @@ def search(ctx: Context, p: SearchParams) -> list[N.Match]:
     nf = ctx.num_files
     if (p.screen and p.screen_head and p.num_per_file == 1 and p.num_matches >= 1 and nf > 0
             and _screen_mode(ctx, p) == "f16"):
-        out = _search_over_bounds(ctx, p, min(nf, p.num_matches))
+        out = _search_over_bounds(ctx, p)
         if out is not None:
             return out
     sel = Selector(p.num_matches, p.num_per_file, p.min_spacing, p.step_size, ctx.target_frames)

@@ -1,0 +1,28 @@
+"""Candidate counts and re-scoring time on the bench workload."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import strugatzki_amd as S
+from strugatzki_amd import _native as N
+import bench as B
+
+L, FR, NF = 2584, 25839, 120
+plants = B.plant_list(10, L, [int(round(j * (NF - 1) / 9)) for j in range(10)], FR)
+npl = [N.Plant(p["file"], p["offset"], p["src_file"], p["src_offset"], p["length"], p["amp"], p["gain"]) for p in plants]
+ctx = S.Context(0)
+ctx.db_reset(14)
+for g in range(NF):
+    ctx.db_add_synthetic(B.SEED, g, FR, npl)
+ctx.set_norms(B.norms_default())
+c2 = S.Context(0); c2.db_reset(14); c2.db_add_synthetic(B.SEED, B.TARGET_FILE, B.TARGET_START + L + 16, [])
+tgt = c2.db_read_file(0)[B.TARGET_START:B.TARGET_START + L].copy(); c2.close()
+ctx.corr_set_target(tgt, 0.5, 8.0)
+ctx.corr_run_screen_f16(0, NF); ctx.synchronize()
+for rep in range(2):
+    t = time.perf_counter(); c = ctx.corr_compact_bounded(0, NF, 10, 1 << 16); dt = time.perf_counter() - t
+    print(f"bounded: {len(c)} candidates (head files: {(c['file'] < 10).sum()}), {dt*1e3:.3f} ms incl. compaction, re-scoring, copy", flush=True)
+for thr in (0.3, 0.2, 0.19, 0.18, 0.15, 0.12):
+    for rs in (False, True):
+        ctx.synchronize()
+        t = time.perf_counter(); c = ctx.corr_compact(0, NF, thr, 1 << 16, rescore=rs); dt = time.perf_counter() - t
+        print(f"thr {thr}: {len(c)} candidates, rescore={rs}: {dt*1e3:.3f} ms", flush=True)
