@@ -639,246 +639,162 @@ __global__ __launch_bounds__(256) void compact_bounded_kernel(const FileDesc *__
 }
 
 // ---------------------------------------------------------------------------
-// rescore_kernel: exact re-evaluation of listed windows, one workgroup per
-// window, straight from the raw frames with the reference's own two-pass
-// arithmetic (MathUtil.stat then MathUtil.correlate, impl/MathUtil.scala:29-62,
-// 177-196): fp32 normalise, fp64 mean, fp64 sums of (b - mean)^2 and of
-// (a - aMean)(b - bMean).  Sums are combined in a fixed tree order.
+// Exact re-evaluation of listed windows, straight from the raw frames with the
+// reference's own two-pass arithmetic (MathUtil.stat then MathUtil.correlate,
+// impl/MathUtil.scala:29-62, 177-196): fp32 normalise, fp64 mean, fp64 sums of
+// (b - mean)^2 and of (a - aMean)(b - bMean).
+//
+// A window is cut into `slices` runs of frames; one 256-thread workgroup takes
+// one (window, slice) pair, so that a short list still fills the GPU:
+//   rescore_sum_kernel    partial sums of the normalised values        -> part[.][0..1]
+//   rescore_cross_kernel  mean from all partial sums (fixed order), then partial
+//                         sums of squares and cross terms              -> part[.][2..5]
+//   rescore_final_kernel  one thread per window: totals in slice order, sim, boost
+// Thread t of the first (256 / numCh) * numCh threads owns channel t % numCh and
+// every (256 / numCh)-th frame of the slice: consecutive threads read consecutive
+// values, and a thread's channel constants stay in registers.
 // ---------------------------------------------------------------------------
-constexpr int kRescoreThreads = 1024;
-constexpr int kRescoreWaves = kRescoreThreads / 64;
+constexpr int kRsThreads = 256;
+constexpr int kRsParts = 6;  // sumT, sumS, sqT, sqS, crossT, crossS
 
-__device__ __forceinline__ double block_sum(double v, double *scratch /* kRescoreWaves doubles */)
+__device__ __forceinline__ double block_sum_256(double v, double *scratch /* 4 doubles */)
 {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
     __syncthreads();  // scratch may still be read from the previous call
     if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
     __syncthreads();
-    static_assert(kRescoreWaves == 16, "the cross-wave step folds 16 partial sums");
-    double p = scratch[threadIdx.x & 15];
-#pragma unroll
-    for (int off = 8; off >= 1; off >>= 1) p += __shfl_xor(p, off, 64);
-    return p;
+    return (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
 }
 
-__global__ __launch_bounds__(kRescoreThreads) void rescore_kernel(
-    const FileDesc *__restrict__ files, const float *__restrict__ tnorm,  // [numCh][L] normalised target
-    NormParams nrm, CorrParams cp, double aMeanT, double aMeanS, sgz_candidate *__restrict__ cands,
-    const unsigned long long *__restrict__ count, long long capacity)
-{
-    constexpr int NT = kRescoreThreads, U = 4;
-    __shared__ double scratch[kRescoreWaves];
-    const long long n = min((long long)*count, capacity);
-    const int numCh = cp.numCh, L = cp.L;
-    // Elements are walked in memory order (e = i * numCh + c), NT at a time and U loads in flight per thread:
-    // coalesced reads of the raw frames; (i, c) of a thread's next element advance by a fixed (di, dc).
-    const int total = L * numCh;
-    const int di = NT / numCh, dc = NT - di * numCh;
-    const int i0 = (int)threadIdx.x / numCh, c0 = (int)threadIdx.x - i0 * numCh;
-    for (long long ci = blockIdx.x; ci < n; ci += gridDim.x) {
-        const sgz_candidate cd = cands[ci];
-        const FileDesc fd = files[cd.file];
-        const float *raw = fd.raw + (long long)cd.offset * numCh;
-        // pass 1: sums
-        double sT = 0.0, sS = 0.0;
-        {
-            int c = c0, e = threadIdx.x;
-            auto add = [&](float v) {
-                if (nrm.enabled) v = (v - nrm.mn[c]) / nrm.d[c];
-                if (c == 0) sT += (double)v; else sS += (double)v;
-                c += dc;
-                if (c >= numCh) c -= numCh;
-            };
-            for (; e + (U - 1) * NT < total; e += U * NT) {
-                float v[U];
-#pragma unroll
-                for (int u = 0; u < U; u++) v[u] = raw[e + u * NT];
-#pragma unroll
-                for (int u = 0; u < U; u++) add(v[u]);
-            }
-            for (; e < total; e += NT) add(raw[e]);
-        }
-        sT = block_sum(sT, scratch);
-        sS = block_sum(sS, scratch);
-        const double nT = (double)L, nS = (double)L * (double)(numCh - 1);
-        const double bMeanT = sT / nT, bMeanS = sS / nS;
-        // pass 2: squared deviations and cross terms
-        double qT = 0.0, qS = 0.0, xT = 0.0, xS = 0.0;
-        {
-            int i = i0, c = c0, e = threadIdx.x;
-            auto next = [&](int &ii, int &cc) {
-                ii += di;
-                cc += dc;
-                if (cc >= numCh) {
-                    cc -= numCh;
-                    ii += 1;
-                }
-            };
-            auto add = [&](float v, float af, int cc) {
-                if (nrm.enabled) v = (v - nrm.mn[cc]) / nrm.d[cc];
-                const double a = (double)af;
-                if (cc == 0) {
-                    const double d = (double)v - bMeanT;
-                    qT += d * d;
-                    xT += (a - aMeanT) * d;
-                } else {
-                    const double d = (double)v - bMeanS;
-                    qS += d * d;
-                    xS += (a - aMeanS) * d;
-                }
-            };
-            for (; e + (U - 1) * NT < total; e += U * NT) {
-                float v[U], af[U];
-                int cs[U];
-#pragma unroll
-                for (int u = 0; u < U; u++) {
-                    v[u] = raw[e + u * NT];
-                    af[u] = tnorm[(long long)c * L + i];
-                    cs[u] = c;
-                    next(i, c);
-                }
-#pragma unroll
-                for (int u = 0; u < U; u++) add(v[u], af[u], cs[u]);
-            }
-            for (; e < total; e += NT) {
-                add(raw[e], tnorm[(long long)c * L + i], c);
-                next(i, c);
-            }
-        }
-        qT = block_sum(qT, scratch);
-        qS = block_sum(qS, scratch);
-        xT = block_sum(xT, scratch);
-        xS = block_sum(xS, scratch);
-        if (threadIdx.x == 0) {
-            const float avgF = (float)bMeanT;
-            const double lnAvgB = log((double)avgF);
-            const float boost = (float)exp((cp.lnAvgIn - lnAvgB) / 0.6);
-            float sim = 0.0f;
-            if (boost <= cp.maxBoost) {
-                float temporal = 0.0f, spectral = 0.0f;
-                if (cp.w > 0.0f) temporal = (float)(xT / (cp.aStdT * sqrt(qT / nT) * nT));
-                if (cp.w < 1.0f) spectral = (float)(xS / (cp.aStdS * sqrt(qS / nS) * nS));
-                sim = temporal * cp.w + spectral * (1.0f - cp.w);
-            }
-            cands[ci].sim = sim;
-            cands[ci].boost = boost;
-        }
-    }
-}
+struct RescoreGeom {
+    int slices;       // per window
+    int sliceFrames;  // frames per slice (the last one may be shorter)
+};
 
-// LDS-resident variant for windows of at most 36 K values: the normalised values of the window are kept in
-// LDS between the two passes (one read of the raw frames, one fp32 division per value), eight loads in
-// flight per thread.
-__global__ __launch_bounds__(kRescoreThreads) void rescore_lds_kernel(
-    const FileDesc *__restrict__ files, const float *__restrict__ tnorm, NormParams nrm, CorrParams cp,
-    double aMeanT, double aMeanS, sgz_candidate *__restrict__ cands, const unsigned long long *__restrict__ count,
-    long long capacity)
+template <bool kCross>
+__global__ __launch_bounds__(kRsThreads) void rescore_pass_kernel(
+    const FileDesc *__restrict__ files, const float *__restrict__ tframes /* normalised target [L][numCh] */,
+    const float *__restrict__ normTab /* min[64], max - min[64] */, int normEnabled, CorrParams cp, RescoreGeom rg,
+    double aMeanT, double aMeanS,
+    const sgz_candidate *__restrict__ cands, const unsigned long long *__restrict__ count, long long capacity,
+    double *__restrict__ part /* [window][slice][kRsParts] */)
 {
-    constexpr int NT = kRescoreThreads, U = 8;
-    extern __shared__ __attribute__((aligned(16))) float vals[];
-    __shared__ double scratch[kRescoreWaves];
-    __shared__ float smn[SGZ_MAX_CHANNELS], sdv[SGZ_MAX_CHANNELS];
+    constexpr int U = 6;
+    __shared__ double scratch[4];
     const long long n = min((long long)*count, capacity);
-    if ((long long)blockIdx.x >= n) return;
+    const long long work = n * rg.slices;
+    if ((long long)blockIdx.x >= work) return;
     const int numCh = cp.numCh, L = cp.L;
     const int tid = threadIdx.x;
-#pragma unroll
-    for (int c = 0; c < SGZ_MAX_CHANNELS; c++) {  // static indices: the parameter block stays in scalar registers
-        if (tid == c) {
-            smn[c] = nrm.mn[c];
-            sdv[c] = nrm.d[c];
-        }
-    }
-    const int total = L * numCh;
-    const int di = NT / numCh, dc = NT - di * numCh;
-    const int i0 = tid / numCh, c0 = tid - i0 * numCh;
+    const int rows = kRsThreads / numCh;  // frames per sweep
+    const int stride = rows * numCh;      // values per sweep
+    const int i0 = tid / numCh, c = tid - i0 * numCh;
+    const bool active = tid < stride;
+    const bool isT = c == 0;
+    const float mn = active ? normTab[c] : 0.0f, dv = active ? normTab[SGZ_MAX_CHANNELS + c] : 1.0f;
+    const double aMean = isT ? aMeanT : aMeanS;
     const double nT = (double)L, nS = (double)L * (double)(numCh - 1);
-    for (long long ci = blockIdx.x; ci < n; ci += gridDim.x) {
-        __syncthreads();  // smn / sdv written; vals of the previous window no longer read
+    for (long long w = blockIdx.x; w < work; w += gridDim.x) {
+        const long long ci = w / rg.slices;
+        const int g = (int)(w - ci * rg.slices);
+        const int f0 = g * rg.sliceFrames;
+        const int fl = min(rg.sliceFrames, L - f0);                            // frames of this slice
+        const int K = active && i0 < fl ? (fl - i0 + rows - 1) / rows : 0;     // values of this thread
         const sgz_candidate cd = cands[ci];
         const FileDesc fd = files[cd.file];
-        const float *raw = fd.raw + (long long)cd.offset * numCh;
-        double sT = 0.0, sS = 0.0;
-        {
-            int c = c0, e = tid;
-            auto add = [&](float v, int ee) {
-                if (nrm.enabled) v = (v - smn[c]) / sdv[c];
-                vals[ee] = v;
-                if (c == 0) sT += (double)v; else sS += (double)v;
-                c += dc;
-                if (c >= numCh) c -= numCh;
-            };
-            for (; e + (U - 1) * NT < total; e += U * NT) {
-                float v[U];
-#pragma unroll
-                for (int u = 0; u < U; u++) v[u] = raw[e + u * NT];
-#pragma unroll
-                for (int u = 0; u < U; u++) add(v[u], e + u * NT);
+        const float *raw = fd.raw + ((long long)cd.offset + f0) * numCh + tid;
+        double bMean = 0.0;
+        if (kCross) {
+            double sT = 0.0, sS = 0.0;
+            for (int k = 0; k < rg.slices; k++) {  // slice order: the same total in every workgroup
+                sT += part[(ci * rg.slices + k) * kRsParts + 0];
+                sS += part[(ci * rg.slices + k) * kRsParts + 1];
             }
-            for (; e < total; e += NT) add(raw[e], e);
+            bMean = isT ? sT / nT : sS / nS;
         }
-        sT = block_sum(sT, scratch);
-        sS = block_sum(sS, scratch);
-        const double bMeanT = sT / nT, bMeanS = sS / nS;
-        double qT = 0.0, qS = 0.0, xT = 0.0, xS = 0.0;
-        {
-            int i = i0, c = c0, e = tid;
-            auto next = [&](int &ii, int &cc) {
-                ii += di;
-                cc += dc;
-                if (cc >= numCh) {
-                    cc -= numCh;
-                    ii += 1;
-                }
-            };
-            auto add = [&](float v, float af, int cc) {
-                const double a = (double)af;
-                if (cc == 0) {
-                    const double d = (double)v - bMeanT;
-                    qT += d * d;
-                    xT += (a - aMeanT) * d;
+        const float *tn = tframes + (long long)f0 * numCh + tid;
+        double s = 0.0, q = 0.0, x = 0.0;
+        int k = 0;
+        for (; k + U <= K; k += U) {
+            float v[U], af[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                v[u] = raw[(k + u) * stride];
+                if (kCross) af[u] = tn[(k + u) * stride];
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (normEnabled) v[u] = (v[u] - mn) / dv;
+                if (kCross) {
+                    const double d = (double)v[u] - bMean;
+                    q += d * d;
+                    x += ((double)af[u] - aMean) * d;
                 } else {
-                    const double d = (double)v - bMeanS;
-                    qS += d * d;
-                    xS += (a - aMeanS) * d;
+                    s += (double)v[u];
                 }
-            };
-            for (; e + (U - 1) * NT < total; e += U * NT) {
-                float af[U];
-                int cs[U];
-#pragma unroll
-                for (int u = 0; u < U; u++) {
-                    af[u] = tnorm[(long long)c * L + i];
-                    cs[u] = c;
-                    next(i, c);
-                }
-#pragma unroll
-                for (int u = 0; u < U; u++) add(vals[e + u * NT], af[u], cs[u]);
-            }
-            for (; e < total; e += NT) {
-                add(vals[e], tnorm[(long long)c * L + i], c);
-                next(i, c);
             }
         }
-        qT = block_sum(qT, scratch);
-        qS = block_sum(qS, scratch);
-        xT = block_sum(xT, scratch);
-        xS = block_sum(xS, scratch);
-        if (tid == 0) {
-            const float avgF = (float)bMeanT;
-            const double lnAvgB = log((double)avgF);
-            const float boost = (float)exp((cp.lnAvgIn - lnAvgB) / 0.6);
-            float sim = 0.0f;
-            if (boost <= cp.maxBoost) {
-                float temporal = 0.0f, spectral = 0.0f;
-                if (cp.w > 0.0f) temporal = (float)(xT / (cp.aStdT * sqrt(qT / nT) * nT));
-                if (cp.w < 1.0f) spectral = (float)(xS / (cp.aStdS * sqrt(qS / nS) * nS));
-                sim = temporal * cp.w + spectral * (1.0f - cp.w);
+        for (; k < K; k++) {
+            float v = raw[k * stride];
+            if (normEnabled) v = (v - mn) / dv;
+            if (kCross) {
+                const double d = (double)v - bMean;
+                q += d * d;
+                x += ((double)tn[k * stride] - aMean) * d;
+            } else {
+                s += (double)v;
             }
-            cands[ci].sim = sim;
-            cands[ci].boost = boost;
         }
+        double *out = part + w * kRsParts;
+        if (kCross) {
+            const double qT = block_sum_256(isT ? q : 0.0, scratch);
+            const double qS = block_sum_256(isT ? 0.0 : q, scratch);
+            const double xT = block_sum_256(isT ? x : 0.0, scratch);
+            const double xS = block_sum_256(isT ? 0.0 : x, scratch);
+            if (tid == 0) {
+                out[2] = qT;
+                out[3] = qS;
+                out[4] = xT;
+                out[5] = xS;
+            }
+        } else {
+            const double sT = block_sum_256(isT ? s : 0.0, scratch);
+            const double sS = block_sum_256(isT ? 0.0 : s, scratch);
+            if (tid == 0) {
+                out[0] = sT;
+                out[1] = sS;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void rescore_final_kernel(CorrParams cp, RescoreGeom rg,
+                                                            sgz_candidate *__restrict__ cands,
+                                                            const unsigned long long *__restrict__ count,
+                                                            long long capacity, const double *__restrict__ part)
+{
+    const long long n = min((long long)*count, capacity);
+    const double nT = (double)cp.L, nS = (double)cp.L * (double)(cp.numCh - 1);
+    for (long long ci = (long long)blockIdx.x * blockDim.x + threadIdx.x; ci < n;
+         ci += (long long)gridDim.x * blockDim.x) {
+        double t[kRsParts] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        for (int k = 0; k < rg.slices; k++)
+#pragma unroll
+            for (int j = 0; j < kRsParts; j++) t[j] += part[(ci * rg.slices + k) * kRsParts + j];
+        const double bMeanT = t[0] / nT;
+        const float avgF = (float)bMeanT;
+        const double lnAvgB = log((double)avgF);
+        const float boost = (float)exp((cp.lnAvgIn - lnAvgB) / 0.6);
+        float sim = 0.0f;
+        if (boost <= cp.maxBoost) {
+            float temporal = 0.0f, spectral = 0.0f;
+            if (cp.w > 0.0f) temporal = (float)(t[4] / (cp.aStdT * sqrt(t[2] / nT) * nT));
+            if (cp.w < 1.0f) spectral = (float)(t[5] / (cp.aStdS * sqrt(t[3] / nS) * nS));
+            sim = temporal * cp.w + spectral * (1.0f - cp.w);
+        }
+        cands[ci].sim = sim;
+        cands[ci].boost = boost;
     }
 }
 
@@ -1116,6 +1032,16 @@ int sgz_set_norms(sgz_context *ctx, const float *norms)
         }
     }
     ctx->have_target = false;  // target statistics depend on the norms
+    SGZ_HIP(ctx, hipSetDevice(ctx->device));
+    SGZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int rc;
+    if ((rc = ensure(ctx, ctx->d_normtab, ctx->normtab_cap, (size_t)2 * SGZ_MAX_CHANNELS))) return rc;
+    float tab[2 * SGZ_MAX_CHANNELS];
+    for (int c = 0; c < SGZ_MAX_CHANNELS; c++) {
+        tab[c] = ctx->norm.mn[c];
+        tab[SGZ_MAX_CHANNELS + c] = ctx->norm.enabled ? ctx->norm.d[c] : 1.0f;
+    }
+    SGZ_HIP(ctx, hipMemcpy(ctx->d_normtab, tab, sizeof tab, hipMemcpyHostToDevice));
     return SGZ_OK;
 }
 
@@ -1195,8 +1121,13 @@ int sgz_corr_set_target(sgz_context *ctx, const float *frames, int num_frames, f
     SGZ_HIP(ctx, hipStreamSynchronize(ctx->screen_stream));
     if ((rc = ensure(ctx, ctx->d_aprime, ctx->aprime_cap, ap.size()))) return rc;
     SGZ_HIP(ctx, hipMemcpy(ctx->d_aprime, ap.data(), sizeof(double) * ap.size(), hipMemcpyHostToDevice));
-    if ((rc = ensure(ctx, ctx->d_tnorm, ctx->tnorm_cap, tb.size()))) return rc;
-    SGZ_HIP(ctx, hipMemcpy(ctx->d_tnorm, tb.data(), sizeof(float) * tb.size(), hipMemcpyHostToDevice));
+    // normalised target twice: channel-major [numCh][L], then frame-major [L][numCh]
+    std::vector<float> tboth(2 * tb.size());
+    std::memcpy(tboth.data(), tb.data(), sizeof(float) * tb.size());
+    for (int c = 0; c < numCh; c++)
+        for (int i = 0; i < L; i++) tboth[tb.size() + (size_t)i * numCh + c] = tb[(size_t)c * L + i];
+    if ((rc = ensure(ctx, ctx->d_tnorm, ctx->tnorm_cap, tboth.size()))) return rc;
+    SGZ_HIP(ctx, hipMemcpy(ctx->d_tnorm, tboth.data(), sizeof(float) * tboth.size(), hipMemcpyHostToDevice));
     ctx->aMeanT = tMean;
     ctx->aMeanS = sMean;
     std::vector<float> apf(ap.size());
@@ -1446,21 +1377,33 @@ int sgz_corr_rescore_device(sgz_context *ctx, sgz_candidate *device_cands, int64
     if (!device_count || capacity < 0 || (capacity > 0 && !device_cands)) return ctx->fail(SGZ_E_ARG, "bad buffers");
     if (capacity == 0) return SGZ_OK;
     SGZ_HIP(ctx, hipSetDevice(ctx->device));
-    const int grid = (int)std::min<int64_t>(capacity, 4096);
+    // A slice holds about 4 K values; the number of candidates is only known on the device, so a fixed grid
+    // of small workgroups strides over the (window, slice) pairs.
     const long long perWindow = (long long)ctx->cp.L * ctx->cp.numCh;
-    if (perWindow <= 36 * 1024) {
-        const size_t ldsBytes = (size_t)perWindow * sizeof(float);
-        if (ldsBytes > 48 * 1024)
-            SGZ_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(rescore_lds_kernel),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
-        hipLaunchKernelGGL(rescore_lds_kernel, dim3(grid), dim3(kRescoreThreads), ldsBytes, ctx->stream, ctx->d_files,
-                           ctx->d_tnorm, ctx->norm, ctx->cp, ctx->aMeanT, ctx->aMeanS, device_cands, device_count,
-                           (long long)capacity);
-    } else {
-        hipLaunchKernelGGL(rescore_kernel, dim3(grid), dim3(kRescoreThreads), 0, ctx->stream, ctx->d_files,
-                           ctx->d_tnorm, ctx->norm, ctx->cp, ctx->aMeanT, ctx->aMeanS, device_cands, device_count,
-                           (long long)capacity);
+    RescoreGeom rg;
+    rg.slices = (int)std::min<long long>(std::max<long long>((perWindow + 4095) / 4096, 1), 64);
+    rg.sliceFrames = (ctx->cp.L + rg.slices - 1) / rg.slices;
+    rg.slices = (ctx->cp.L + rg.sliceFrames - 1) / rg.sliceFrames;  // no empty slice
+    int rc;
+    if ((rc = ensure(ctx, ctx->d_rs_part, ctx->rs_part_cap, (size_t)capacity * rg.slices * kRsParts))) return rc;
+    if (!ctx->d_normtab) {  // sgz_set_norms was never called: normalisation is off, the table is not read
+        if ((rc = ensure(ctx, ctx->d_normtab, ctx->normtab_cap, (size_t)2 * SGZ_MAX_CHANNELS))) return rc;
+        SGZ_HIP(ctx, hipMemsetAsync(ctx->d_normtab, 0, sizeof(float) * 2 * SGZ_MAX_CHANNELS, ctx->stream));
     }
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+    const int grid = (int)std::min<long long>((long long)capacity * rg.slices, 8ll * cus);
+    const float *tframes = ctx->d_tnorm + perWindow;
+    hipLaunchKernelGGL(rescore_pass_kernel<false>, dim3(grid), dim3(kRsThreads), 0, ctx->stream, ctx->d_files, tframes,
+                       ctx->d_normtab, ctx->norm.enabled, ctx->cp, rg, ctx->aMeanT, ctx->aMeanS, device_cands, device_count,
+                       (long long)capacity, ctx->d_rs_part);
+    SGZ_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(rescore_pass_kernel<true>, dim3(grid), dim3(kRsThreads), 0, ctx->stream, ctx->d_files, tframes,
+                       ctx->d_normtab, ctx->norm.enabled, ctx->cp, rg, ctx->aMeanT, ctx->aMeanS, device_cands, device_count,
+                       (long long)capacity, ctx->d_rs_part);
+    SGZ_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(rescore_final_kernel, dim3((int)std::min<int64_t>((capacity + 255) / 256, 64)), dim3(256), 0,
+                       ctx->stream, ctx->cp, rg, device_cands, device_count, (long long)capacity, ctx->d_rs_part);
     SGZ_HIP(ctx, hipGetLastError());
     return SGZ_OK;
 }

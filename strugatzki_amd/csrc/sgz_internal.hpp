@@ -146,6 +146,10 @@ struct sgz_context {
     float *d_thr = nullptr;                  // per head file: largest lower bound; then their minimum
     size_t thr_cap = 0;
     sgz_candidate *h_pinned = nullptr;       // pinned staging of the first candidate transfer
+    float *d_normtab = nullptr;              // norms as a device table: min[64], then max - min[64]
+    size_t normtab_cap = 0;
+    double *d_rs_part = nullptr;             // partial sums of the exact re-scoring [window][slice][6]
+    size_t rs_part_cap = 0;
 
     sgz_candidate *d_cand = nullptr;         // [count header][records]
     size_t cand_cap = 0;
