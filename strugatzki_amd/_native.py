@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libstrugatzki_amd.so")
+LIB_PATH = os.environ.get("SGZ_LIB_PATH") or os.path.join(_HERE, "lib", "libstrugatzki_amd.so")
 
 SGZ_OK = 0
 SGZ_E_ARG = -1

@@ -43,7 +43,15 @@ constexpr int kHThreads = kHWaves * 64;
 // fp32 summation.
 constexpr float kHalfRelErr = 1.0e-3f;
 
-__host__ __device__ constexpr size_t half_buf_bytes(int XU, int LAd) { return (size_t)XU * 16 + (size_t)LAd * 8; }
+// One staged channel: XU 16-byte units of database frames, then the two target copies (LAd dwords each);
+// rounded up to whole 1 KiB pieces, the unit one wave-wide direct-to-LDS load fills.
+__host__ __device__ constexpr size_t half_buf_bytes(int XU, int LAd)
+{
+    return (((size_t)XU * 16 + (size_t)LAd * 8) + 1023) & ~(size_t)1023;
+}
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_void;
 
 size_t half_lds_bytes(const HalfGeom &hg) { return 2 * half_buf_bytes(hg.XU, hg.LAd) + 2 * kHTileW * sizeof(float); }
 
@@ -51,8 +59,10 @@ size_t half_lds_bytes(const HalfGeom &hg) { return 2 * half_buf_bytes(hg.XU, hg.
 // Per channel the workgroup stages (double buffered) the frames
 // [o0, o0 + 8 XU) of the file in natural order and the two dword-aligned
 // copies of the target channel (even shifts read copy 0, odd shifts copy 1,
-// which is stored one element further left).
-template <int NSTAGE>
+// which is stored one element further left).  Staging uses direct-to-LDS loads
+// (global_load_lds_dwordx4: per-lane source address, destination = wave-uniform
+// base + 16 * lane), issued a phase ahead and retired by the barrier that ends
+// the phase, so no registers hold data in flight.
 __global__ __launch_bounds__(kHThreads, 4) void corr_mfma_kernel(
     const FileDesc *__restrict__ files, const TileDesc *__restrict__ tiles, const _Float16 *__restrict__ planarH,
     const double *__restrict__ prefix, const double *__restrict__ tbase, const uint32_t *__restrict__ aimg,
@@ -70,23 +80,15 @@ __global__ __launch_bounds__(kHThreads, 4) void corr_mfma_kernel(
     const long long rowLen = fd.M * kR;
     const _Float16 *fplanar = planarH + fd.planar_off + td.o0;
 
-    uint4 st[NSTAGE];
-    auto stage_load = [&](int c) {
+    const int nPieces = (nV + 63) >> 6;  // 1 KiB pieces per staged channel
+    auto stage = [&](int c, int buf) {
         const uint4 *xsrc = reinterpret_cast<const uint4 *>(fplanar + (long long)c * rowLen);
         const uint4 *asrc = reinterpret_cast<const uint4 *>(aimg + (size_t)c * 2 * hg.LAd);
-#pragma unroll
-        for (int it = 0; it < NSTAGE; it++) {
-            const int v = min(tid + it * kHThreads, nV - 1);  // surplus threads re-read the last vector
+        unsigned char *dst = lds + buf * bufBytes;
+        for (int piece = q; piece < nPieces; piece += kHWaves) {
+            const int v = min(piece * 64 + lane, nV - 1);  // surplus lanes of the last piece fill padding
             const uint4 *src = v < hg.XU ? xsrc + v : asrc + (v - hg.XU);
-            st[it] = *src;
-        }
-    };
-    auto stage_store = [&](int buf) {
-        uint4 *dst = reinterpret_cast<uint4 *>(lds + buf * bufBytes);
-#pragma unroll
-        for (int it = 0; it < NSTAGE; it++) {
-            const int v = tid + it * kHThreads;
-            if (v < nV) dst[v] = st[it];
+            __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)(dst + (size_t)piece * 1024), 16, 0, 0);
         }
     };
 
@@ -126,12 +128,11 @@ __global__ __launch_bounds__(kHThreads, 4) void corr_mfma_kernel(
     const int numCh = cp.numCh;
     auto channel_of = [&](int ph) { return ph + 1 < numCh ? ph + 1 : 0; };
 
-    stage_load(channel_of(0));
-    stage_store(0);
+    stage(channel_of(0), 0);
     __syncthreads();
 
     for (int ph = 0; ph < numCh; ph++) {
-        if (ph + 1 < numCh) stage_load(channel_of(ph + 1));
+        if (ph + 1 < numCh) stage(channel_of(ph + 1), (ph + 1) & 1);
         const uint4 *Xu = reinterpret_cast<const uint4 *>(lds + (ph & 1) * bufBytes) + hBase;
         const uint32_t *Ad = reinterpret_cast<const uint32_t *>(lds + (ph & 1) * bufBytes + (size_t)hg.XU * 16) + aBase;
 
@@ -163,8 +164,7 @@ __global__ __launch_bounds__(kHThreads, 4) void corr_mfma_kernel(
             }
         }
 
-        if (ph + 1 < numCh) stage_store((ph + 1) & 1);
-        __syncthreads();
+        __syncthreads();  // also retires the loads staged above
         if (ph == numCh - 2) {  // all MFCC channels done
             reduce(redS4, acc);
 #pragma unroll
@@ -215,8 +215,6 @@ static bool half_geom(int L, HalfGeom &hg)
     hg.S2 = S2;
     hg.LAd = LAd;
     hg.XU = XU;
-    const int nV = XU + LAd / 2;
-    if (nV > kHStageV * kHThreads) return false;
     if (half_lds_bytes(hg) > 160 * 1024) return false;
     return true;
 }
@@ -267,26 +265,15 @@ int half_screen_launch(sgz_context *ctx, int tile_begin, int tile_end, hipStream
     const HalfGeom &hg = ctx->hg;
     if (hg.S2 <= 0) return ctx->fail(SGZ_E_STATE, "half-precision screening is not available for this target");
     const size_t ldsBytes = half_lds_bytes(hg);
-    const int nV = hg.XU + hg.LAd / 2;
     const _Float16 *planarH = reinterpret_cast<const _Float16 *>(ctx->d_planar_h);
     const uint32_t *aimg = reinterpret_cast<const uint32_t *>(ctx->d_aimg_h);
-    if (nV <= 3 * kHThreads) {
-        auto kern = corr_mfma_kernel<3>;
-        if (ldsBytes > 64 * 1024)
-            SGZ_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
-        hipLaunchKernelGGL(kern, dim3(tile_end - tile_begin), dim3(kHThreads), ldsBytes, stream, ctx->d_files,
-                           ctx->d_tiles_h + tile_begin, planarH, ctx->d_prefix, ctx->d_tbase, aimg, ctx->cp, hg,
-                           ctx->d_sim, ctx->d_boost, ctx->d_lo);
-    } else {
-        auto kern = corr_mfma_kernel<kHStageV>;
-        if (ldsBytes > 64 * 1024)
-            SGZ_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
-        hipLaunchKernelGGL(kern, dim3(tile_end - tile_begin), dim3(kHThreads), ldsBytes, stream, ctx->d_files,
-                           ctx->d_tiles_h + tile_begin, planarH, ctx->d_prefix, ctx->d_tbase, aimg, ctx->cp, hg,
-                           ctx->d_sim, ctx->d_boost, ctx->d_lo);
-    }
+    auto kern = corr_mfma_kernel;
+    if (ldsBytes > 64 * 1024)
+        SGZ_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
+    hipLaunchKernelGGL(kern, dim3(tile_end - tile_begin), dim3(kHThreads), ldsBytes, stream, ctx->d_files,
+                       ctx->d_tiles_h + tile_begin, planarH, ctx->d_prefix, ctx->d_tbase, aimg, ctx->cp, hg,
+                       ctx->d_sim, ctx->d_boost, ctx->d_lo);
     SGZ_HIP(ctx, hipGetLastError());
     return SGZ_OK;
 }

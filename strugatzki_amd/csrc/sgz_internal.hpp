@@ -66,7 +66,6 @@ struct CorrParams {
 constexpr int kHNB = 8;                 // 16x16 output tiles per wave (columns of 16 chunks each)
 constexpr int kHTileW = kHNB * 256;     // windows per workgroup tile
 constexpr int kHWaves = 8;              // waves per workgroup; wave q takes the 32-lag steps s = q, q + 8, ...
-constexpr int kHStageV = 6;             // 16-byte vectors one thread stages per channel, at most
 
 struct HalfGeom {
     int S2;    // 32-lag steps: 32 * S2 >= L + 15
