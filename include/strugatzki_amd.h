@@ -155,7 +155,7 @@ SGZ_API int sgz_corr_run_screen(sgz_context *ctx, int file_begin, int file_end);
  * BOUND of sgz_corr_run's value: the half-precision result plus the largest
  * error the operand roundings can cause for that window (about 1e-3 * sqrt(1 +
  * (mean offset / std-dev)^2); observed errors are near 1e-5), so that a
- * threshold test never loses a window; boosts are the exact ones.  Several times
+ * threshold test never loses a window; boosts are fp32 evaluations (about 1e-6).  Several times
  * the throughput of sgz_corr_run_screen.  Only for normalised features
  * (sgz_set_norms with norms) and targets whose staged channel fits LDS:
  * sgz_corr_screen_f16_available tells (1 / 0), and the run fails with

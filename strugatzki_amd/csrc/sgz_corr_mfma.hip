@@ -19,7 +19,7 @@
 // means and std-devs still come from the fp64 prefix sums.  The result is a
 // screening value: callers re-score every window that comes within a margin of
 // their bound with the exact kernel (rescore_kernel) before using it.  What the
-// kernel stores is an upper bound of the similarity (window_result<true>): the
+// kernel stores is an upper bound of the similarity (window_bounds): the
 // half-precision value plus the largest error the roundings can cause for that
 // window, so a threshold test on it never loses a window.
 #include <hip/hip_runtime.h>
@@ -120,16 +120,37 @@ __global__ __launch_bounds__(kHThreads, 4) void corr_mfma_kernel(
         }
     };
 
-    f32x4 acc[NB];
-#pragma unroll
-    for (int t = 0; t < NB; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-
     // phase order: the MFCC channels 1 .. numCh-1 first (one sum), the loudness channel last
     const int numCh = cp.numCh;
     auto channel_of = [&](int ph) { return ph + 1 < numCh ? ph + 1 : 0; };
 
     stage(channel_of(0), 0);
+
+    // window statistics of this thread's windows: their loads are in flight while the first channel lands
+    Epilogue ep;
+    ep.pre = prefix + fd.prefix_off;
+    ep.tbase = tbase + fd.tbase_off;
+    ep.frames = fd.frames;
+    ep.nptiles = fd.nptiles;
+    ep.tileShift = cp.prepTileShift;
+    CorrParams cph = cp;
+    cph.sumAT = hg.sumAT;
+    cph.sumAS = hg.sumAS;
+    constexpr int kPerThread = kHTileW / kHThreads;
+    WindowCoeffs wc[kPerThread];
+#pragma unroll
+    for (int k = 0; k < kPerThread; k++) {
+        const long long o = (long long)td.o0 + tid + k * kHThreads;
+        float boost;
+        wc[k] = window_coeffs(cph, ep, o < fd.num_windows ? o : 0, kHalfRelErr, boost);
+        if (o < fd.num_windows) boostOut[fd.win_off + o] = boost;
+        if (k & 1) asm volatile("" ::: "memory");  // two windows' loads in flight at a time
+    }
     __syncthreads();
+
+    f32x4 acc[NB];
+#pragma unroll
+    for (int t = 0; t < NB; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int ph = 0; ph < numCh; ph++) {
         if (ph + 1 < numCh) stage(channel_of(ph + 1), (ph + 1) & 1);
@@ -173,27 +194,16 @@ __global__ __launch_bounds__(kHThreads, 4) void corr_mfma_kernel(
     }
     reduce(redT4, acc);
 
-    Epilogue ep;
-    ep.pre = prefix + fd.prefix_off;
-    ep.tbase = tbase + fd.tbase_off;
-    ep.frames = fd.frames;
-    ep.nptiles = fd.nptiles;
-    ep.tileShift = cp.prepTileShift;
-    CorrParams cph = cp;
-    cph.sumAT = hg.sumAT;
-    cph.sumAS = hg.sumAS;
     const float *redS = reinterpret_cast<const float *>(redS4);
     const float *redT = reinterpret_cast<const float *>(redT4);
 #pragma unroll
-    for (int k = 0; k < kHTileW / kHThreads; k++) {
+    for (int k = 0; k < kPerThread; k++) {
         const int wdw = tid + k * kHThreads;
         const long long o = (long long)td.o0 + wdw;
         if (o < fd.num_windows) {
-            float sim, boost;
-            float lo;
-            window_result<true>(cph, ep, o, (double)redT[wdw], (double)redS[wdw], sim, boost, kHalfRelErr, &lo);
+            float sim, lo;
+            window_bounds(wc[k], redT[wdw], redS[wdw], sim, lo);
             simOut[fd.win_off + o] = sim;
-            boostOut[fd.win_off + o] = boost;
             loOut[fd.win_off + o] = lo;
         }
     }
