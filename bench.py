@@ -168,7 +168,7 @@ def main() -> int:
 
     def step():
         if world > 1:
-            return S.search_sharded(ctx, params, head_global, tail_global)
+            return S.search_sharded(ctx, params, head_global, tail_global, num_files_total=total_files)
         return S.search(ctx, params)
 
     def sync():

@@ -180,14 +180,42 @@ std::vector<Match> runFeatureCorrelation(sgz_context *ctx, const FeatureCorrelat
         ~SelGuard() { sgz_sel_destroy(s); }
     } guard{sel};
 
-    // GPU: all similarities; host: replay of the match bookkeeping in file order
-    // Head files: exact fp64 kernel, fed densely.  Tail files: screening kernel (fp32 products); the windows
-    // within `margin` of the bound are re-scored exactly on the GPU before they are fed.
-    const int head = std::min(nf, std::max(cfg.numMatches, 1));
-    const float margin = 1e-5f;
+    // GPU: all similarities; host: replay of the match bookkeeping in file order.
+    const bool f16 = sgz_corr_screen_f16_available(ctx) == 1;
+    const int64_t cap = 1 << 16;
+    std::vector<sgz_candidate> cands;
+    bool done = false;
+    if (f16 && cfg.numPerFile == 1 && cfg.numMatches >= 1 && nf > 0) {
+        // numPerFile = 1: a file can only contribute its largest similarity, first occurrence.  All files go
+        // through the half-precision kernel; per file the windows whose upper bound reaches the file's largest
+        // lower bound are re-scored exactly and the exact maxima are fed in file order.
+        cands.resize((size_t)cap);
+        int64_t count = 0;
+        check(ctx, sgz_corr_run_screen_f16(ctx, 0, nf));
+        const int rc = sgz_corr_compact_bounded(ctx, 0, nf, nf, cands.data(), cap, &count);
+        if (rc != SGZ_E_OVERFLOW) {
+            check(ctx, rc);
+            sgz_selector *quick = sgz_sel_create(cfg.numMatches, cfg.numPerFile, cfg.minSpacing, stepSize, L);
+            if (!quick) throw Error(SGZ_E_ARG, "illegal selection parameters");
+            const int frc = sgz_sel_feed_screened(quick, cands.data(), count, nf, nf);
+            if (frc == SGZ_OK) {
+                sgz_sel_destroy(guard.s);
+                guard.s = sel = quick;
+                done = true;
+            } else {
+                sgz_sel_destroy(quick);
+                if (frc != SGZ_E_STATE) throw Error(frc, "selector rejected its input");
+            }
+        }
+    }
+    // General case.  Head files: exact fp64 kernel, fed densely.  Tail files: a screening kernel (half-precision
+    // matrix-core kernel, which writes upper bounds, or fp32 products); the windows within `margin` of the bound
+    // are re-scored exactly on the GPU before they are fed.
+    const int head = done ? nf : std::min(nf, std::max(cfg.numMatches, 1));
+    const float margin = f16 ? 1e-6f : 1e-5f;
     bool screened = head < nf;
-    check(ctx, sgz_corr_run(ctx, 0, head));
-    if (head < nf) check(ctx, sgz_corr_run_screen(ctx, head, nf));
+    if (!done) check(ctx, sgz_corr_run(ctx, 0, head));
+    if (head < nf) check(ctx, f16 ? sgz_corr_run_screen_f16(ctx, head, nf) : sgz_corr_run_screen(ctx, head, nf));
     std::vector<float> sim, boost;
     auto feedDense = [&](int f0, int f1) {
         int64_t total = 0;
@@ -203,7 +231,7 @@ std::vector<Match> runFeatureCorrelation(sgz_context *ctx, const FeatureCorrelat
             pos += (size_t)n;
         }
     };
-    feedDense(0, head);
+    if (!done) feedDense(0, head);
     checkAborted(obs, 0.6);
     int f = head;
     if (f < nf && !sgz_sel_is_full(sel) && screened) {  // dense feeding needs exact values
@@ -215,8 +243,7 @@ std::vector<Match> runFeatureCorrelation(sgz_context *ctx, const FeatureCorrelat
         f++;
     }
     if (f < nf) {
-        const int64_t cap = 1 << 16;
-        std::vector<sgz_candidate> cands((size_t)cap);
+        cands.resize((size_t)cap);
         int64_t count = 0;
         const int rc = screened ? sgz_corr_compact_rescored(ctx, f, nf, sgz_sel_threshold(sel) - margin, cands.data(),
                                                             cap, &count)

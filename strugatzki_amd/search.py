@@ -152,29 +152,35 @@ def shard_files(num_files: int, head: int, rank: int, world: int) -> list[int]:
     return [g for g in range(head, num_files) if (g - head) % world == rank]
 
 
-def exchange_candidates(rec, cnt, capacity: int, group=None) -> np.ndarray:
+def exchange_candidates(rec, cnt, capacity: int, group=None) -> np.ndarray | None:
     """The one collective of the search: all-gather of fixed-size candidate
     buffers and their fill counts.  `rec` is an int32 [capacity][4] tensor whose
     rows are sgz_candidate records (file already translated to the global id),
     `cnt` a 1-element int64 tensor; both live on the GPU for the nccl (RCCL)
     backend and on the host for gloo.  Returns all ranks' candidates sorted by
-    (file, offset)."""
+    (file, offset), records that several ranks hold (replicated files) once;
+    None when some rank's buffer overflowed (every rank sees that)."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
-    n_local = int(cnt.item())
-    if n_local > capacity:
-        raise RuntimeError(f"candidate buffer overflow ({n_local} > {capacity}); raise SearchParams.capacity")
     recs = [torch.empty_like(rec) for _ in range(world)]
     cnts = [torch.empty_like(cnt) for _ in range(world)]
     dist.all_gather(cnts, cnt, group=group)
+    counts = [int(c.item()) for c in cnts]
+    if max(counts) > capacity:
+        return None
     dist.all_gather(recs, rec, group=group)
-    parts = [recs[r][: int(cnts[r].item())].cpu().numpy() for r in range(world)]
+    parts = [recs[r][: counts[r]].cpu().numpy() for r in range(world)]
     allc = np.concatenate(parts, axis=0) if parts else np.zeros((0, 4), np.int32)
     cands = np.ascontiguousarray(allc, dtype=np.int32).view(N.CANDIDATE_DTYPE).reshape(-1)
     order = np.lexsort((cands["offset"], cands["file"]))
-    return cands[order]
+    cands = cands[order]
+    if len(cands) > 1:  # replicated files: every rank computed the same record
+        keep = np.ones(len(cands), dtype=bool)
+        keep[1:] = (cands["file"][1:] != cands["file"][:-1]) | (cands["offset"][1:] != cands["offset"][:-1])
+        cands = cands[keep]
+    return cands
 
 
 def finish_selection(sel: Selector, cands: np.ndarray) -> list[N.Match]:
@@ -183,18 +189,64 @@ def finish_selection(sel: Selector, cands: np.ndarray) -> list[N.Match]:
     return sel.result()
 
 
-def search_sharded(ctx: Context, p: SearchParams, head_global: Sequence[int], tail_global: Sequence[int],
-                   group=None) -> list[N.Match]:
-    """Multi-process search, one process per GPU.  The context holds the head
-    files first (global ids `head_global`, identical on every rank) and then this
-    rank's tail files (`tail_global`, ascending)."""
+def _device_buffers(cap: int):
     import torch
 
+    dev = torch.device("cuda", torch.cuda.current_device())
+    rec = torch.zeros((cap, 4), dtype=torch.int32, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    torch.cuda.current_stream().synchronize()  # buffers are zeroed before the library's stream writes them
+    return rec, cnt, dev
+
+
+def _to_global_ids(rec, cnt, cap: int, local_to_global: Sequence[int], dev) -> None:
+    import torch
+
+    n_local = min(int(cnt.item()), cap)
+    if n_local:
+        lut = torch.tensor(list(local_to_global), dtype=torch.int32, device=dev)
+        rec[:n_local, 0] = lut[rec[:n_local, 0].long()]
+
+
+def _sharded_over_bounds(ctx: Context, p: SearchParams, local_to_global: Sequence[int], num_files_total: int,
+                         group=None) -> list[N.Match] | None:
+    """numPerFile = 1 (see _search_over_bounds): every rank finds the exact maxima of its own files, the
+    ranks exchange them and replay the selection over all files in global order."""
+    nloc = ctx.num_files
+    cap = p.capacity
+    ctx.corr_run_screen_f16(0, nloc)
+    rec, cnt, dev = _device_buffers(cap)
+    ctx.corr_compact_bounded_device(0, nloc, nloc, rec.data_ptr(), cap, cnt.data_ptr())
+    ctx.corr_rescore_device(rec.data_ptr(), cap, cnt.data_ptr())
+    ctx.synchronize()
+    _to_global_ids(rec, cnt, cap, local_to_global, dev)
+    cands = exchange_candidates(rec, cnt, cap, group)
+    if cands is None:
+        return None
+    sel = Selector(p.num_matches, p.num_per_file, p.min_spacing, p.step_size, ctx.target_frames)
+    try:
+        return sel.result() if sel.feed_screened(cands, num_files_total, num_files_total) else None
+    finally:
+        sel.close()
+
+
+def search_sharded(ctx: Context, p: SearchParams, head_global: Sequence[int], tail_global: Sequence[int],
+                   group=None, num_files_total: int | None = None) -> list[N.Match]:
+    """Multi-process search, one process per GPU.  The context holds the head
+    files first (global ids `head_global`, identical on every rank) and then this
+    rank's tail files (`tail_global`, ascending).  `num_files_total` is the number
+    of files over all ranks (global ids 0 .. num_files_total-1); it enables the
+    search over bounds for numPerFile = 1."""
     nh, nt = len(head_global), len(tail_global)
     assert ctx.num_files == nh + nt
+    mode = _screen_mode(ctx, p) if p.screen else None
+    if (p.screen and p.screen_head and p.num_per_file == 1 and p.num_matches >= 1 and mode == "f16"
+            and num_files_total is not None and ctx.num_files > 0):
+        out = _sharded_over_bounds(ctx, p, list(head_global) + list(tail_global), num_files_total, group)
+        if out is not None:  # every rank holds the same candidates, so all ranks agree on this
+            return out
     sel = Selector(p.num_matches, p.num_per_file, p.min_spacing, p.step_size, ctx.target_frames)
     ctx.corr_run(0, nh)
-    mode = _screen_mode(ctx, p) if p.screen else None
     margin = p.margin if p.margin is not None or not p.screen else MARGIN[mode]
     if nt:
         if p.screen:
@@ -205,20 +257,16 @@ def search_sharded(ctx: Context, p: SearchParams, head_global: Sequence[int], ta
     if not sel.is_full:  # every rank replayed the same head, so all ranks agree on this
         raise RuntimeError("head files did not fill the match set; enlarge the head (degenerate equal sims)")
     cap = p.capacity
-    dev = torch.device("cuda", torch.cuda.current_device())
-    rec = torch.zeros((cap, 4), dtype=torch.int32, device=dev)
-    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
-    torch.cuda.current_stream().synchronize()  # buffers are zeroed before the library's stream writes them
+    rec, cnt, dev = _device_buffers(cap)
     thr = sel.threshold - margin if p.screen else sel.threshold
     ctx.corr_compact_device(nh, nh + nt, thr, rec.data_ptr(), cap, cnt.data_ptr())
     if p.screen:
         ctx.corr_rescore_device(rec.data_ptr(), cap, cnt.data_ptr())
     ctx.synchronize()
-    n_local = min(int(cnt.item()), cap)
-    if n_local:  # local file index -> global id
-        lut = torch.tensor(list(head_global) + list(tail_global), dtype=torch.int32, device=dev)
-        rec[:n_local, 0] = lut[rec[:n_local, 0].long()]
+    _to_global_ids(rec, cnt, cap, list(head_global) + list(tail_global), dev)
     cands = exchange_candidates(rec, cnt, cap, group)
+    if cands is None:
+        raise RuntimeError(f"candidate buffer overflow (> {cap}); raise SearchParams.capacity")
     out = finish_selection(sel, cands)
     sel.close()
     return out

@@ -78,6 +78,91 @@ def test_two_rank_exchange_reproduces_single_process_result(num_matches, num_per
     assert ret[0] == expect and ret[1] == expect
 
 
+def _worker_bounds(rank, world, port, case, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from strugatzki_amd import _native as N
+        from strugatzki_amd.engine import Selector, match_tuple
+        from strugatzki_amd.search import exchange_candidates, shard_files
+
+        num_matches, nf, L, sims, boosts, cap, overflow_rank = case
+        head = num_matches
+        rec = np.zeros(cap, dtype=N.CANDIDATE_DTYPE)
+        n = 0
+        # the replicated head files and this rank's slice of the tail: per file, the windows a screening
+        # bound of 2e-3 could not tell from the maximum
+        for g in list(range(head)) + shard_files(nf, head, rank, world):
+            idx = np.flatnonzero(sims[g] >= sims[g].max() - np.float32(2e-3))
+            rec["file"][n:n + len(idx)] = g
+            rec["offset"][n:n + len(idx)] = idx
+            rec["sim"][n:n + len(idx)] = sims[g][idx]
+            rec["boost"][n:n + len(idx)] = boosts[g][idx]
+            n += len(idx)
+        rec_t = torch.from_numpy(rec.view(np.int32).reshape(cap, 4).copy())
+        cnt_t = torch.tensor([cap + 5 if rank == overflow_rank else n], dtype=torch.int64)
+        cands = exchange_candidates(rec_t, cnt_t, cap)
+        if cands is None:
+            ret[rank] = None
+            return
+        assert len(np.unique(cands[["file", "offset"]])) == len(cands)  # replicated head records arrive once
+        sel = Selector(num_matches, 1, 0, STEP, L)
+        assert sel.feed_screened(cands, nf, nf)
+        ret[rank] = [match_tuple(m) for m in sel.result()]
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("overflow_rank", [-1, 1])
+def test_two_rank_search_over_bounds(overflow_rank):
+    """numPerFile = 1: the ranks exchange the exact per-file maxima (plus near-maxima) and replay all files."""
+    L, ts, nf, frames, num_matches = 64, 7, 20, 500, 6
+    db = synth_db(nf, frames, make_plants(6, L, nf, frames, ts))
+    tgt = synth_target(ts, L)
+    cfg = corr_config(ts, L, num_matches=num_matches, num_per_file=1)
+    want, sims, boosts = O.correlation_run(cfg, tgt, norms_default(), db)
+    case = (num_matches, nf, L, sims, boosts, 4096, overflow_rank)
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_bounds, args=(world, _free_port(), case, ret), nprocs=world, join=True)
+    if overflow_rank >= 0:  # every rank learns of the overflow and takes the other path
+        assert ret[0] is None and ret[1] is None
+    else:
+        expect = [O.match_tuple(w) for w in want]
+        assert ret[0] == expect and ret[1] == expect
+
+
+def test_feed_screened_matches_dense_feeding():
+    """Feeding only the per-file maximum equals feeding every window, for numPerFile = 1 (with and without
+    minSpacing), and the shortcut refuses what it cannot decide."""
+    from strugatzki_amd import _native as N
+    from strugatzki_amd.engine import Selector, match_tuple
+    L, ts, nf, frames = 48, 5, 9, 300
+    db = synth_db(nf, frames, make_plants(3, L, nf, frames, ts))
+    tgt = synth_target(ts, L)
+    for num_matches, min_spacing in [(4, 0), (4, 50 * STEP), (20, 0), (1, 0)]:
+        cfg = corr_config(ts, L, num_matches=num_matches, num_per_file=1, min_spacing=min_spacing)
+        want, sims, boosts = O.correlation_run(cfg, tgt, norms_default(), db)
+        rows = []
+        for g in range(nf):
+            for o in np.flatnonzero(sims[g] >= sims[g].max() - np.float32(1e-3)):
+                rows.append((g, o, sims[g][o], boosts[g][o]))
+        cands = np.array(rows, dtype=N.CANDIDATE_DTYPE)
+        sel = Selector(num_matches, 1, min_spacing, STEP, L)
+        assert sel.feed_screened(cands, nf, nf)
+        assert [match_tuple(m) for m in sel.result()] == [O.match_tuple(w) for w in want]
+        sel.close()
+    # a file without candidates, and numPerFile != 1, are refused
+    sel = Selector(4, 1, 0, STEP, L)
+    assert not sel.feed_screened(cands[cands["file"] != 3], nf, nf)
+    sel.close()
+    sel = Selector(4, 2, 0, STEP, L)
+    assert not sel.feed_screened(cands, nf, nf)
+    sel.close()
+
+
 def test_shard_files_partitions_the_tail():
     from strugatzki_amd.search import shard_files
     parts = [shard_files(37, 5, r, 4) for r in range(4)]

@@ -239,6 +239,34 @@ def test_search_over_bounds_and_its_fallbacks(ctx, case):
         assert abs(g.sim - w.sim) <= 1.2e-7
 
 
+@pytest.mark.parametrize("screen_head", [True, False])
+def test_search_sharded_single_rank_rccl(screen_head):
+    """The multi-GPU entry point with a one-rank RCCL group: candidate buffers on the GPU, one all-gather.
+    Runs tests/sharded_rank.py as a child process (same workload as below)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    L, ts, nf, frames, num_matches = 96, 17, 14, 900, 4
+    db = synth_db(nf, frames, make_plants(5, L, nf, frames, ts))
+    tgt = synth_target(ts, L)
+    want, _, _ = O.correlation_run(corr_config(ts, L, num_matches=num_matches, num_per_file=1), tgt, norms_default(),
+                                   db, dense=False)
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "sharded_rank.py")
+    res = subprocess.run([sys.executable, script, str(port), "1" if screen_head else "0"], capture_output=True,
+                         text=True, timeout=110)
+    assert res.returncode == 0, res.stderr[-2000:]
+    got = json.loads(res.stdout.strip().splitlines()[-1])
+    assert [(g[0], g[1], g[2]) for g in got] == [(w.file, w.start, w.stop) for w in want]
+    for g, w in zip(got, want):
+        assert abs(g[3] - w.sim) <= 1.2e-7
+
+
 def test_search_falls_back_to_dense_on_candidate_overflow(ctx):
     import strugatzki_amd as S
     L, ts, nf, frames = 64, 4, 6, 500
