@@ -93,6 +93,25 @@ def cpu_baseline(L: int, frames_per_file: int, budget_s: float) -> dict:
     }
 
 
+def pmc_traffic_bytes(kernel: str):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this command
+    (profiles/r01_pmc_summary.csv): 2 x FETCH_SIZE (gfx950 tallies 128-byte read requests at 64 bytes) +
+    WRITE_SIZE, both in KiB.  None when the summary does not hold the kernel."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_summary.csv")
+    try:
+        import csv
+        vals = {}
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                if row["kernel"] == kernel.split("<")[0] and row["counter"] in ("FETCH_SIZE", "WRITE_SIZE"):
+                    vals[row["counter"]] = float(row["mean_per_dispatch"])
+        if len(vals) == 2:
+            return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+    except OSError:
+        pass
+    return None
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -218,7 +237,7 @@ def main() -> int:
         achieved = tail_flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         alg_bytes = tail_windows * 64.0
         peak = {"f64": PEAK_F64_TFLOPS, "f32": PEAK_F32_TFLOPS, "f16": PEAK_F16_TFLOPS}[mode]
-        kernel = {"f64": "corr_kernel<double>", "f32": "corr_kernel<float>", "f16": "corr_mfma_kernel<3>"}[mode]
+        kernel = {"f64": "corr_kernel<double>", "f32": "corr_kernel<float>", "f16": "corr_mfma_kernel"}[mode]
         note = {
             "f64": "fp64 FMA on the vector pipe; MI355X fp64 vector and matrix peaks are both 78.6 TFLOP/s",
             "f32": "tail launch: fp32 products / partial sums on the vector pipe (157.3 TFLOP/s peak, the same as the "
@@ -258,7 +277,7 @@ def main() -> int:
                 "peak": peak,
                 "unit": "TFLOP/s",
                 "frac": achieved / peak,
-                "traffic": None,
+                "traffic": pmc_traffic_bytes(kernel),
                 "kernel_ms": k_ms,
                 "windows_per_launch": tail_windows,
                 "flop_per_window": 2.0 * NUM_CH * L,
