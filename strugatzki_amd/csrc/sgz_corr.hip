@@ -102,7 +102,8 @@ __global__ __launch_bounds__(256) void prep_kernel(const FileDesc *__restrict__ 
                                                    const PrepTile *__restrict__ ptiles,
                                                    T *__restrict__ planar, double *__restrict__ prefix,
                                                    double *__restrict__ tbase, NormParams nrm, int numCh, int cb,
-                                                   double kT, double kS, int *__restrict__ hflags)
+                                                   double kT, double kS, int *__restrict__ hflags,
+                                                   int *__restrict__ lokey)
 {
     extern __shared__ __attribute__((aligned(16))) float xs[];
     __shared__ double wtot[4][4];
@@ -166,6 +167,8 @@ __global__ __launch_bounds__(256) void prep_kernel(const FileDesc *__restrict__ 
             }
         }
         if (outOfRange) hflags[pt.file] = 1;
+        // the matrix-core kernel that follows folds its lower bounds into this per-file maximum
+        if (pt.chunk0 == 0 && tid == 0) lokey[pt.file] = bound_key(-INFINITY);
     } else {
         // idx = tid + 256*k over [rows][cb]; cb is a power of two
         const int cbShift = 31 - __clz(cb);
@@ -551,55 +554,20 @@ __global__ __launch_bounds__(256) void compact_kernel(const FileDesc *__restrict
 // Search over bounds (half-precision screening run): with numPerFile = 1 a head
 // file contributes its largest similarity, first occurrence (the sliding loop of
 // impl/FeatureCorrelationImpl.scala:234-239 keeps a running strict maximum).
-// file_bound_kernel finds, per head file, the largest lower bound: every window
-// whose upper bound reaches it may hold the maximum.  bound_min_kernel takes the
-// minimum of those over the head files: no match set that the head files fill
+// The matrix-core kernel leaves, per file, the largest lower bound (an atomic
+// maximum over order-preserving integer keys): every window whose upper bound
+// reaches it may hold the maximum.  bound_min_kernel takes the minimum of those
+// over the head files: no match set that the head files fill
 // can end with a smaller worst entry, so tail windows whose upper bound does not
 // exceed it cannot be offered.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void file_bound_kernel(const FileDesc *__restrict__ files,
-                                                          const float *__restrict__ up,
-                                                          const float *__restrict__ lo, float *__restrict__ thr,
-                                                          int *__restrict__ hflags)
-{
-    __shared__ float wmax[16];
-    __shared__ int wbad[16];
-    const FileDesc fd = files[blockIdx.x];
-    float best = -INFINITY;
-    int bad = 0;
-    for (long long o = threadIdx.x; o < fd.num_windows; o += 1024) {
-        const float l = lo[fd.win_off + o], u = up[fd.win_off + o];
-        bad |= (l != l) || (u != u);
-        best = fmaxf(best, l);
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        best = fmaxf(best, __shfl_xor(best, off, 64));
-        bad |= __shfl_xor(bad, off, 64);
-    }
-    if ((threadIdx.x & 63) == 0) {
-        wmax[threadIdx.x >> 6] = best;
-        wbad[threadIdx.x >> 6] = bad;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int k = 1; k < 16; k++) {
-            best = fmaxf(best, wmax[k]);
-            bad |= wbad[k];
-        }
-        thr[blockIdx.x] = best;
-        // a NaN similarity changes what the reference's loop keeps: leave such files to the exact path
-        if (bad || fd.num_windows == 0) hflags[blockIdx.x] = hflags[blockIdx.x] | 2;
-    }
-}
-
-__global__ __launch_bounds__(64) void bound_min_kernel(float *__restrict__ thr, int n)
+__global__ __launch_bounds__(64) void bound_min_kernel(const int *__restrict__ lokey, int n, float *__restrict__ out)
 {
     float v = INFINITY;
-    for (int k = threadIdx.x; k < n; k += 64) v = fminf(v, thr[k]);
+    for (int k = threadIdx.x; k < n; k += 64) v = fminf(v, bound_from_key(lokey[k]));
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
-    if (threadIdx.x == 0) thr[n] = v;
+    if (threadIdx.x == 0) out[0] = v;
 }
 
 // Windows of head files (file < headEnd) whose upper bound reaches the file's own bound, windows of the
@@ -608,7 +576,8 @@ __global__ __launch_bounds__(256) void compact_bounded_kernel(const FileDesc *__
                                                               const TileDesc *__restrict__ tiles,
                                                               const float *__restrict__ up,
                                                               const float *__restrict__ boost,
-                                                              const float *__restrict__ thr, int headEnd,
+                                                              const int *__restrict__ lokey,
+                                                              const float *__restrict__ tailThr, int headEnd,
                                                               sgz_candidate *__restrict__ out, long long capacity,
                                                               unsigned long long *__restrict__ count,
                                                               const int *__restrict__ hflags)
@@ -617,7 +586,7 @@ __global__ __launch_bounds__(256) void compact_bounded_kernel(const FileDesc *__
     const FileDesc fd = files[td.file];
     if (hflags[td.file] && td.o0 == 0 && threadIdx.x == 0) atomicAdd(count, (unsigned long long)capacity + 1ull);
     const bool headFile = td.file < headEnd;
-    const float t = headFile ? thr[td.file] : thr[headEnd];
+    const float t = headFile ? bound_from_key(lokey[td.file]) : tailThr[0];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const long long o = (long long)td.o0 + k * 256 + threadIdx.x;
@@ -886,6 +855,10 @@ int build_layout(sgz_context *ctx)
     if ((rc = ensure(ctx, ctx->d_sim, ctx->dense_cap, (size_t)wins))) return rc;
     if ((rc = ensure(ctx, ctx->d_boost, ctx->boost_cap, (size_t)wins))) return rc;
     if (halfOk && (rc = ensure(ctx, ctx->d_lo, ctx->lo_cap, (size_t)wins))) return rc;
+    if (halfOk && (rc = ensure(ctx, ctx->d_lokey, ctx->lokey_cap, (size_t)nf))) return rc;
+    if (halfOk && nf)  // key of -inf; files without windows keep it (no prep tile resets them)
+        SGZ_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ctx->d_lokey), (int)0x807fffff, (size_t)nf,
+                                       ctx->stream));
     ctx->lo_begin = ctx->lo_end = 0;
     // the three tables are consumed by kernels queued later on ctx->stream
     if (nf) SGZ_HIP(ctx, hipMemcpyAsync(ctx->d_files, ctx->h_files.data(), sizeof(FileDesc) * nf,
@@ -1207,7 +1180,9 @@ static int corr_run_impl(sgz_context *ctx, int file_begin, int file_end, int mod
     // The screening path has its own planar image (fp32) and its own stream, so that a screening run
     // over one file range overlaps with an exact run over another.
     float *planarF = ctx->d_planar_f;
-    hipStream_t stream = exact ? ctx->stream : ctx->screen_stream;
+    // (the matrix-core screening is compute bound like the exact kernel: nothing to gain from a second
+    // stream, and its consumers on ctx->stream then need no cross-stream wait)
+    hipStream_t stream = mode == kRunScreenF32 ? ctx->screen_stream : ctx->stream;
     // an earlier run over some of these files (possibly on the other stream) writes the same outputs
     for (const auto &run : ctx->runs)
         if (run.fb < file_end && run.fe > file_begin) SGZ_HIP(ctx, hipStreamWaitEvent(stream, run.done, 0));
@@ -1216,15 +1191,15 @@ static int corr_run_impl(sgz_context *ctx, int file_begin, int file_end, int mod
     if (exact)
         hipLaunchKernelGGL(prep_kernel<double>, dim3(pt1 - pt0), dim3(256), prepLds, stream, ctx->d_files,
                            ctx->d_ptiles + pt0, ctx->d_planar, ctx->d_prefix, ctx->d_tbase, ctx->norm, ctx->numCh, cb,
-                           ctx->cp.kT, ctx->cp.kS, ctx->d_hflags);
+                           ctx->cp.kT, ctx->cp.kS, ctx->d_hflags, ctx->d_lokey);
     else if (half)
         hipLaunchKernelGGL(prep_kernel<_Float16>, dim3(pt1 - pt0), dim3(256), prepLds, stream, ctx->d_files,
                            ctx->d_ptiles + pt0, reinterpret_cast<_Float16 *>(ctx->d_planar_h), ctx->d_prefix,
-                           ctx->d_tbase, ctx->norm, ctx->numCh, cb, ctx->cp.kT, ctx->cp.kS, ctx->d_hflags);
+                           ctx->d_tbase, ctx->norm, ctx->numCh, cb, ctx->cp.kT, ctx->cp.kS, ctx->d_hflags, ctx->d_lokey);
     else
         hipLaunchKernelGGL(prep_kernel<float>, dim3(pt1 - pt0), dim3(256), prepLds, stream, ctx->d_files,
                            ctx->d_ptiles + pt0, planarF, ctx->d_prefix, ctx->d_tbase, ctx->norm, ctx->numCh, cb,
-                           ctx->cp.kT, ctx->cp.kS, ctx->d_hflags);
+                           ctx->cp.kT, ctx->cp.kS, ctx->d_hflags, ctx->d_lokey);
     SGZ_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(tile_scan_kernel, dim3(file_end - file_begin), dim3(256), 0, stream, ctx->d_files,
                        file_begin, ctx->d_tbase);
@@ -1350,19 +1325,18 @@ int sgz_corr_compact_bounded_device(sgz_context *ctx, int file_begin, int file_e
         return ctx->fail(SGZ_E_STATE, "files are not covered by one sgz_corr_run_screen_f16 run starting at file 0");
     SGZ_HIP(ctx, hipSetDevice(ctx->device));
     int rc;
-    if ((rc = ensure(ctx, ctx->d_thr, ctx->thr_cap, (size_t)nf + 1))) return rc;
+    if ((rc = ensure(ctx, ctx->d_thr, ctx->thr_cap, (size_t)1))) return rc;
+    SGZ_HIP(ctx, hipMemsetAsync(device_count, 0, sizeof(unsigned long long), ctx->stream));
     for (const auto &run : ctx->runs)
         if (run.fb < need_end) SGZ_HIP(ctx, hipStreamWaitEvent(ctx->stream, run.done, 0));
-    SGZ_HIP(ctx, hipMemsetAsync(device_count, 0, sizeof(unsigned long long), ctx->stream));
-    hipLaunchKernelGGL(file_bound_kernel, dim3(head_end), dim3(1024), 0, ctx->stream, ctx->d_files, ctx->d_sim,
-                       ctx->d_lo, ctx->d_thr, ctx->d_hflags);
-    SGZ_HIP(ctx, hipGetLastError());
-    hipLaunchKernelGGL(bound_min_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->d_thr, head_end);
-    SGZ_HIP(ctx, hipGetLastError());
+    if (head_end < file_end) {  // tail files present: they are filtered by the smallest head bound
+        hipLaunchKernelGGL(bound_min_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->d_lokey, head_end, ctx->d_thr);
+        SGZ_HIP(ctx, hipGetLastError());
+    }
     const int t0 = ctx->tile_begin[file_begin], t1 = ctx->tile_begin[file_end];
     if (t1 > t0) {
         hipLaunchKernelGGL(compact_bounded_kernel, dim3(t1 - t0), dim3(256), 0, ctx->stream, ctx->d_files,
-                           ctx->d_tiles + t0, ctx->d_sim, ctx->d_boost, ctx->d_thr, head_end, device_out,
+                           ctx->d_tiles + t0, ctx->d_sim, ctx->d_boost, ctx->d_lokey, ctx->d_thr, head_end, device_out,
                            (long long)capacity, device_count, ctx->d_hflags);
         SGZ_HIP(ctx, hipGetLastError());
     }

@@ -6,6 +6,14 @@
 
 namespace sgz {
 
+// Order-preserving integer key of a float (for atomicMax over floats of either sign); its own inverse.
+__device__ __forceinline__ int bound_key(float x)
+{
+    const int b = __float_as_int(x);
+    return b >= 0 ? b : b ^ 0x7fffffff;
+}
+__device__ __forceinline__ float bound_from_key(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7fffffff); }
+
 // Prefix sums of the per-frame moments: P(q, i) = sum over frames < i.
 struct Epilogue {
     const double *pre;    // 4 arrays of `frames` in-tile inclusive sums

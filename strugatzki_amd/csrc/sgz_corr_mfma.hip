@@ -66,7 +66,8 @@ size_t half_lds_bytes(const HalfGeom &hg) { return 2 * half_buf_bytes(hg.XU, hg.
 __global__ __launch_bounds__(kHThreads, 4) void corr_mfma_kernel(
     const FileDesc *__restrict__ files, const TileDesc *__restrict__ tiles, const _Float16 *__restrict__ planarH,
     const double *__restrict__ prefix, const double *__restrict__ tbase, const uint32_t *__restrict__ aimg,
-    CorrParams cp, HalfGeom hg, float *__restrict__ simOut, float *__restrict__ boostOut, float *__restrict__ loOut)
+    CorrParams cp, HalfGeom hg, float *__restrict__ simOut, float *__restrict__ boostOut, float *__restrict__ loOut,
+    int *__restrict__ lokey, int *__restrict__ hflags)
 {
     constexpr int NB = kHNB;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -196,6 +197,8 @@ __global__ __launch_bounds__(kHThreads, 4) void corr_mfma_kernel(
 
     const float *redS = reinterpret_cast<const float *>(redS4);
     const float *redT = reinterpret_cast<const float *>(redT4);
+    float best = -INFINITY;
+    int bad = 0;
 #pragma unroll
     for (int k = 0; k < kPerThread; k++) {
         const int wdw = tid + k * kHThreads;
@@ -205,7 +208,31 @@ __global__ __launch_bounds__(kHThreads, 4) void corr_mfma_kernel(
             window_bounds(wc[k], redT[wdw], redS[wdw], sim, lo);
             simOut[fd.win_off + o] = sim;
             loOut[fd.win_off + o] = lo;
+            best = fmaxf(best, lo);
+            bad |= (lo != lo) || (sim != sim);
         }
+    }
+    // the file's largest lower bound (one atomic per workgroup); a NaN similarity changes what the reference's
+    // loop keeps, so such files are flagged and left to the exact path
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        best = fmaxf(best, __shfl_xor(best, off, 64));
+        bad |= __shfl_xor(bad, off, 64);
+    }
+    float *wbest = reinterpret_cast<float *>(lds);  // the staging buffers are free now
+    int *wbad = reinterpret_cast<int *>(lds) + kHWaves;
+    if (lane == 0) {
+        wbest[q] = best;
+        wbad[q] = bad;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int k = 1; k < kHWaves; k++) {
+            best = fmaxf(best, wbest[k]);
+            bad |= wbad[k];
+        }
+        atomicMax(&lokey[td.file], bound_key(best));
+        if (bad) atomicOr(&hflags[td.file], 2);
     }
 }
 
@@ -283,7 +310,7 @@ int half_screen_launch(sgz_context *ctx, int tile_begin, int tile_end, hipStream
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
     hipLaunchKernelGGL(kern, dim3(tile_end - tile_begin), dim3(kHThreads), ldsBytes, stream, ctx->d_files,
                        ctx->d_tiles_h + tile_begin, planarH, ctx->d_prefix, ctx->d_tbase, aimg, ctx->cp, hg,
-                       ctx->d_sim, ctx->d_boost, ctx->d_lo);
+                       ctx->d_sim, ctx->d_boost, ctx->d_lo, ctx->d_lokey, ctx->d_hflags);
     SGZ_HIP(ctx, hipGetLastError());
     return SGZ_OK;
 }

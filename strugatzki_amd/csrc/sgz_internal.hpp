@@ -142,7 +142,9 @@ struct sgz_context {
     float *d_lo = nullptr;                   // lower bounds of the half-precision screening run
     size_t lo_cap = 0;
     int lo_begin = 0, lo_end = 0;            // files whose d_sim / d_lo hold bounds of the latest such run
-    float *d_thr = nullptr;                  // per head file: largest lower bound; then their minimum
+    int *d_lokey = nullptr;                  // per file: largest lower bound of that run, as an ordered integer key
+    size_t lokey_cap = 0;
+    float *d_thr = nullptr;                  // smallest of the head files' bounds (filter of the tail files)
     size_t thr_cap = 0;
     sgz_candidate *h_pinned = nullptr;       // pinned staging of the first candidate transfer
     float *d_normtab = nullptr;              // norms as a device table: min[64], then max - min[64]
