@@ -102,7 +102,7 @@ SGZ_API int sgz_db_reset(sgz_context *ctx, int num_channels);
  * Replaces AudioFile.openRead + afExtr.read, impl/FeatureCorrelationImpl.scala:169,195. */
 SGZ_API int sgz_db_add_file(sgz_context *ctx, const float *frames, int64_t num_frames);
 /* Appends a feature file that already sits in device memory (not copied, not
- * freed; must stay valid until the next sgz_db_reset). */
+ * freed; must stay valid until the next sgz_db_reset; 16-byte aligned). */
 SGZ_API int sgz_db_add_file_device(sgz_context *ctx, const float *device_frames, int64_t num_frames);
 /* Appends a synthetic feature file generated on the GPU: moving-average
  * filtered counter-based noise, optionally overlaid with noisy copies

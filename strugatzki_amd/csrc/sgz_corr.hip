@@ -121,20 +121,50 @@ __global__ __launch_bounds__(256) void prep_kernel(const FileDesc *__restrict__ 
     const float *src = fd.raw + f0 * numCh;
     const long long validElems = (fd.frames - f0) * numCh;  // may be <= 0 for padding tiles
     {
-        const int dfr = 256 / numCh, dc = 256 - dfr * numCh;
-        int fr = tid / numCh, c = tid - fr * numCh;
-        for (int e = tid; e < total; e += 256) {
-            float v = 0.0f;
-            if (e < validElems) {
-                v = src[e];
-                if (nrm.enabled) v = (v - nrm.mn[c]) / nrm.d[c];
+        // 16-byte loads, four per thread in flight; (fr, c) of a vector's first element by one division
+        const int nvec = total >> 2;  // total is a multiple of 64
+        for (int v0 = tid; v0 < nvec; v0 += 4 * 256) {
+            float4 x[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int v = v0 + u * 256;
+                const long long e0 = 4ll * v;
+                x[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (v < nvec) {
+                    if (e0 + 3 < validElems) {
+                        x[u] = *reinterpret_cast<const float4 *>(src + e0);
+                    } else {  // the file ends inside this vector
+                        if (e0 < validElems) x[u].x = src[e0];
+                        if (e0 + 1 < validElems) x[u].y = src[e0 + 1];
+                        if (e0 + 2 < validElems) x[u].z = src[e0 + 2];
+                    }
+                }
             }
-            xs[c * cstride + (fr & (kR - 1)) * jstride + (fr >> 4)] = v;
-            fr += dfr;
-            c += dc;
-            if (c >= numCh) {
-                c -= numCh;
-                fr += 1;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int v = v0 + u * 256;
+                if (v < nvec) {
+                    const int e0 = 4 * v;
+                    int fr = e0 / numCh, c = e0 - fr * numCh;
+                    const float xv[4] = {x[u].x, x[u].y, x[u].z, x[u].w};
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        float val = xv[j];
+                        if (nrm.enabled && e0 + j < validElems) {
+                            // the half-precision image and its bounds do not need the reference's exact fp32
+                            // quotient (re-scoring recomputes it): reciprocal multiply there
+                            if constexpr (std::is_same<T, _Float16>::value)
+                                val = (val - nrm.mn[c]) * __builtin_amdgcn_rcpf(nrm.d[c]);
+                            else
+                                val = (val - nrm.mn[c]) / nrm.d[c];
+                        }
+                        xs[c * cstride + (fr & (kR - 1)) * jstride + (fr >> 4)] = val;
+                        if (++c == numCh) {
+                            c = 0;
+                            fr++;
+                        }
+                    }
+                }
             }
         }
     }
@@ -200,12 +230,28 @@ __global__ __launch_bounds__(256) void prep_kernel(const FileDesc *__restrict__ 
             m[k][0] = m[k][1] = m[k][2] = m[k][3] = 0.0;
             if (k < per && fr < tileFrames && gf < fd.frames) {
                 const int j = fr & (kR - 1), mm = fr >> 4;
-                const double t = (double)xs[j * jstride + mm] - kT;
-                double s1 = 0.0, s2 = 0.0;
-                for (int c = 1; c < numCh; c++) {
-                    const double d = (double)xs[c * cstride + j * jstride + mm] - kS;
-                    s1 += d;
-                    s2 = fma(d, d, s2);
+                double t, s1, s2;
+                if constexpr (std::is_same<T, _Float16>::value) {
+                    // screening statistics: the 13-term sums of one frame in fp32, the running sums in fp64
+                    const float kSf = (float)kS;
+                    float f1 = 0.0f, f2 = 0.0f;
+                    for (int c = 1; c < numCh; c++) {
+                        const float d = xs[c * cstride + j * jstride + mm] - kSf;
+                        f1 += d;
+                        f2 = fmaf(d, d, f2);
+                    }
+                    t = (double)(xs[j * jstride + mm] - (float)kT);
+                    s1 = (double)f1;
+                    s2 = (double)f2;
+                } else {
+                    t = (double)xs[j * jstride + mm] - kT;
+                    s1 = 0.0;
+                    s2 = 0.0;
+                    for (int c = 1; c < numCh; c++) {
+                        const double d = (double)xs[c * cstride + j * jstride + mm] - kS;
+                        s1 += d;
+                        s2 = fma(d, d, s2);
+                    }
                 }
                 m[k][0] = t;
                 m[k][1] = t * t;
@@ -926,6 +972,8 @@ int sgz_db_add_file_device(sgz_context *ctx, const float *device_frames, int64_t
     if (ctx->numCh == 0) return ctx->fail(SGZ_E_STATE, "sgz_db_reset has not been called");
     if (num_frames < 0 || (num_frames > 0 && !device_frames))
         return ctx->fail(SGZ_E_ARG, "bad device_frames / num_frames");
+    if (reinterpret_cast<uintptr_t>(device_frames) & 15)
+        return ctx->fail(SGZ_E_ARG, "device_frames must be 16-byte aligned");
     DbFile f;
     f.frames = num_frames;
     f.owned = false;
