@@ -241,6 +241,22 @@ SGZ_API void sgz_sel_destroy(sgz_selector *sel);
  * order.  Leaving out windows is legal iff they could not pass the gate. */
 SGZ_API int sgz_sel_feed_file(sgz_selector *sel, int file, int64_t n, const int32_t *offsets,
                       const float *sims, const float *boosts);
+/* One database file of a search with punch-out (impl/FeatureCorrelationImpl.scala:182-397).
+ * in_sim / in_boost: similarity and boost of the punch-in target at every window offset of the file
+ * (num_frames - in_frames + 1 values, e.g. sgz_corr_read_dense after sgz_corr_run with the punch-in
+ * target); out_sim / out_boost: the same for the punch-out target (num_frames - out_frames + 1 values,
+ * indexed by window offset in the file).  min_punch / max_punch in feature frames (fullToFeat of the
+ * config values, :116-117).  Replays the reference's bookkeeping: the punch-in pass covers
+ * num_frames - min_punch frames and only finds the first window that passes the gate (:212); every
+ * punch-in window from there on whose sim exceeds lowestSim^2 is paired with the punch-out windows
+ * min_punch .. max_punch frames later, sim = sqrt(inSim * outSim) (:362), match span = [in offset,
+ * out offset) in sample frames, boostOut from the punch-out window.  Where the reference's two pairing
+ * loops run past what its passes wrote to their temp files (their bounds count frames, not windows:
+ * :322, :352), this replay stops at the last window.  The selector must have been created with
+ * target_frames = in_frames. */
+SGZ_API int sgz_sel_feed_file_punch(sgz_selector *sel, int file, int64_t num_frames, int in_frames, int out_frames,
+                                    int min_punch, int max_punch, const float *in_sim, const float *in_boost,
+                                    const float *out_sim, const float *out_boost);
 /* Feeds a whole candidate list, sorted by (file, offset): one sgz_sel_feed_file per
  * file that occurs in it, in ascending file order (files without candidates
  * need no call: nothing of theirs could pass the gate). */

@@ -153,7 +153,7 @@ constexpr const char *kNormalizeName = "feat_norms.aif";
 // compatible feature file to the GPU, correlates, selects.  Database entries
 // are visited in lexicographic order of their meta file names (the reference
 // iterates a Set[File], whose order is unspecified).  Matches come back in
-// descending similarity.  punchOut is not supported yet.
+// descending similarity.  With punchOut the spans of the matches run from the punch-in to the punch-out offset.
 std::vector<Match> runFeatureCorrelation(sgz_context *ctx, const FeatureCorrelationConfig &cfg,
                                          const Observer &obs = nullptr);
 

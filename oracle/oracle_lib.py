@@ -51,6 +51,19 @@ class CorrConfig(C.Structure):
     ]
 
 
+class PunchConfig(C.Structure):
+    """sgzo_punch_config: FeatureCorrelation with punchOut, minPunch, maxPunch."""
+    _fields_ = [
+        ("base", CorrConfig),
+        ("punch_out_start", C.c_int64),
+        ("punch_out_stop", C.c_int64),
+        ("out_temporal_weight", C.c_float),
+        ("pad_", C.c_int32),
+        ("min_punch", C.c_int64),
+        ("max_punch", C.c_int64),
+    ]
+
+
 class SegmConfig(C.Structure):
     _fields_ = [
         ("has_start", C.c_int32),
@@ -230,6 +243,30 @@ def correlation_run(cfg: CorrConfig, target: np.ndarray, norms: np.ndarray | Non
     if n < 0:
         raise ValueError("oracle rejected the correlation arguments")
     return [out[i] for i in range(n)], sims, boosts
+
+
+def correlation_run_punch(cfg: PunchConfig, target: np.ndarray, norms: np.ndarray | None, db: list[np.ndarray]):
+    """Punch-in / punch-out search.  Returns (matches, dense_in, dense_out): per file [2][frames] arrays
+    (row 0 sim, row 1 boost) indexed by window offset in the file, NaN where the reference computes nothing."""
+    target = np.ascontiguousarray(target, dtype=np.float32)
+    nrm = None if norms is None else np.ascontiguousarray(norms, dtype=np.float32)
+    db = [np.ascontiguousarray(x, dtype=np.float32) for x in db]
+    nf = len(db)
+    fpp = C.POINTER(C.c_float)
+    frames = (fpp * max(nf, 1))(*[_fp(x) for x in db])
+    counts = (C.c_int64 * max(nf, 1))(*[x.shape[0] for x in db])
+    din = [np.full((2, max(x.shape[0], 1)), np.nan, dtype=np.float32) for x in db]
+    dout = [np.full((2, max(x.shape[0], 1)), np.nan, dtype=np.float32) for x in db]
+    in_p = (fpp * max(nf, 1))(*[_fp(a) for a in din])
+    out_p = (fpp * max(nf, 1))(*[_fp(a) for a in dout])
+    out = (Match * max(cfg.base.num_matches, 1))()
+    fn = lib().sgzo_correlation_run_punch
+    fn.restype = C.c_int
+    n = fn(C.byref(cfg), _fp(target), C.c_int64(target.shape[0]), _fp(nrm), frames, counts, C.c_int(nf), in_p, out_p,
+           out)
+    if n < 0:
+        raise ValueError("oracle rejected the correlation arguments")
+    return [out[i] for i in range(n)], din, dout
 
 
 def segmentation_run(cfg: SegmConfig, frames: np.ndarray, norms: np.ndarray | None):

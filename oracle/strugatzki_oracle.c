@@ -237,7 +237,7 @@ static int64_t span_spacing(int64_t aStart, int64_t aStop, int64_t bStart, int64
 }
 
 /* ------------------------------------------------------------------------- */
-/* FeatureCorrelation (no punch-out): impl/FeatureCorrelationImpl.scala       */
+/* FeatureCorrelation: impl/FeatureCorrelationImpl.scala                       */
 /* ------------------------------------------------------------------------- */
 
 typedef struct {
@@ -415,6 +415,226 @@ SGZO_API int sgzo_correlation_run(const sgzo_corr_config *cfg,
     for (int i = 0; i < n; i++) matches[i] = sel.allPrio.e[i];
     free(eInBuf);
     free(tb);
+    oset_free(&sel.allPrio);
+    oset_free(&sel.entryPrio);
+    return n;
+}
+
+/* ------------------------------------------------------------------------- */
+/* FeatureCorrelation with punch-out: impl/FeatureCorrelationImpl.scala:182-397 */
+/* ------------------------------------------------------------------------- */
+
+typedef struct {
+    sgzo_corr_config base;     /* punch-in span and weight, selection parameters */
+    int64_t punch_out_start;   /* Punch.span of punchOut, sample frames */
+    int64_t punch_out_stop;
+    float out_temporal_weight;
+    int32_t pad_;
+    int64_t min_punch;         /* sample frames */
+    int64_t max_punch;
+} sgzo_punch_config;
+
+typedef struct {
+    float *tb;                 /* [numCh][L] normalised */
+    int L;
+    double tMean, tStd, sMean, sStd, lnAvgLoudness;
+} in_matrix;
+
+/* readInBuffer, :83-98 */
+static int read_in_buffer(in_matrix *m, const float *target, int64_t targetFrames, int numCh, int step,
+                          const float *normBuf, int64_t spanStart, int64_t spanStop)
+{
+    const int start = sgzo_full_to_feat(spanStart, step);
+    const int stop = sgzo_full_to_feat(spanStop, step);
+    const int L = stop - start;
+    if (L <= 0 || start < 0 || (int64_t)start + L > targetFrames) return -1;
+    m->L = L;
+    m->tb = (float *)malloc(sizeof(float) * (size_t)numCh * L);
+    for (int ch = 0; ch < numCh; ch++)
+        for (int i = 0; i < L; i++) m->tb[(size_t)ch * L + i] = target[(size_t)(start + i) * numCh + ch];
+    sgzo_normalize(normBuf, m->tb, numCh, L, 0, L);
+    sgzo_stat(m->tb, L, 0, L, 0, 1, &m->tMean, &m->tStd);
+    sgzo_stat(m->tb + L, L, 0, L, 0, numCh - 1, &m->sMean, &m->sStd);
+    m->lnAvgLoudness = log((double)sgzo_avg(m->tb, 0, L));
+    return 0;
+}
+
+/* One iteration of the sliding loops (:193-210 and :286-301): similarity and boost of the ring contents. */
+static void ring_window(const in_matrix *m, const float *ring, int numCh, int ringOff, float w, float maxBoost,
+                        float *simOut, float *boostOut)
+{
+    const int L = m->L;
+    const double lnAvgB = log((double)sgzo_avg(ring, 0, L));
+    const float boost = (float)exp((m->lnAvgLoudness - lnAvgB) / 0.6);
+    float sim = 0.0f;
+    if (boost <= maxBoost) {
+        float temporal = 0.0f, spectral = 0.0f;
+        if (w > 0.0f) {
+            double bMean, bStd;
+            sgzo_stat(ring, L, 0, L, 0, 1, &bMean, &bStd);
+            temporal = sgzo_correlate(m->tb, L, m->tMean, m->tStd, L, 1, ring, L, bMean, bStd, ringOff, 0);
+        }
+        if (w < 1.0f) {
+            double bMean, bStd;
+            sgzo_stat(ring, L, 0, L, 1, numCh - 1, &bMean, &bStd);
+            spectral = sgzo_correlate(m->tb + L, L, m->sMean, m->sStd, L, numCh - 1, ring, L, bMean, bStd, ringOff, 1);
+        }
+        sim = temporal * w + spectral * (1.0f - w);
+    }
+    *simOut = sim;
+    *boostOut = boost;
+}
+
+/* The sliding pass over `left` frames of a file starting at frame `pos` (:190-246 / :283-317): writes one
+ * (sim, boost) per iteration, returns their number. */
+static int64_t sliding_pass(const in_matrix *m, float *ring, const float *src, int64_t pos, int64_t left, int numCh,
+                            const float *normBuf, float w, float maxBoost, float *sims, float *boosts)
+{
+    const int L = m->L;
+    int readSz = L, readOff = 0;
+    int64_t logicalOff = 0;
+    while (left > 0) {
+        const int chunkLen = (int)(left < readSz ? left : readSz);
+        for (int i = 0; i < chunkLen; i++)
+            for (int ch = 0; ch < numCh; ch++)
+                ring[(size_t)ch * L + readOff + i] = src[(size_t)(pos + i) * numCh + ch];
+        pos += chunkLen;
+        sgzo_normalize(normBuf, ring, numCh, L, readOff, chunkLen);
+        ring_window(m, ring, numCh, (int)(logicalOff % L), w, maxBoost, &sims[logicalOff], &boosts[logicalOff]);
+        left -= chunkLen;
+        readOff = (readOff + chunkLen) % L;
+        logicalOff += 1;
+        readSz = 1;
+    }
+    return logicalOff;
+}
+
+/*
+ * FeatureCorrelationImpl.body() with config.punchOut defined.  Arguments as for sgzo_correlation_run.
+ * Per file: the punch-in pass runs over numFrames - minPunch frames (:182-185) and adds no match; from the
+ * first window that passes the gate (:212) every (sim, boost) is kept (the reference's temp file tIn,
+ * first kept window = tInOff).  The punch-out pass (:262-317) starts at frame tInOff + minPunch.  Then
+ * every kept punch-in window whose sim exceeds lowestSim^2 is paired with the punch-out windows
+ * minPunch .. maxPunch frames later, sim = sqrt(inSim * outSim) (:319-383).
+ *
+ * Where the reference sizes its two pairing loops by frames left in the file (:322, :352), it reads
+ * its temp files past what the passes wrote (L - 1 frames short): that tail is undefined there (stale
+ * frames of an earlier file, or an I/O error).  This statement stops at the last written window.
+ *
+ * denseIn / denseOut (optional): per file [2][numFrames] arrays receiving sim (row 0) and boost (row 1) of
+ * the punch-in windows (index = window offset) and of the punch-out windows (index = window offset in the
+ * file, i.e. tInOff + minPunch + k); entries the reference does not compute are left untouched.
+ */
+SGZO_API int sgzo_correlation_run_punch(const sgzo_punch_config *pcfg, const float *target, int64_t targetFrames,
+                                        const float *norms, const float *const *dbFrames,
+                                        const int64_t *dbNumFrames, int numFiles, float *const *denseIn,
+                                        float *const *denseOut, sgzo_match *matches)
+{
+    const sgzo_corr_config *cfg = &pcfg->base;
+    const int numCh = cfg->num_coeffs + 1;
+    const int step = cfg->step_size;
+    const float *normBuf = cfg->normalize ? norms : NULL;
+    if (cfg->normalize && norms == NULL) return -1;
+    in_matrix mi, mo;
+    if (read_in_buffer(&mi, target, targetFrames, numCh, step, normBuf, cfg->punch_in_start, cfg->punch_in_stop))
+        return -1;
+    if (read_in_buffer(&mo, target, targetFrames, numCh, step, normBuf, pcfg->punch_out_start,
+                       pcfg->punch_out_stop)) {
+        free(mi.tb);
+        return -1;
+    }
+    const int minPunch = sgzo_full_to_feat(pcfg->min_punch, step); /* :116-117 */
+    const int maxPunch = sgzo_full_to_feat(pcfg->max_punch, step);
+    const float wIn = cfg->temporal_weight, wOut = pcfg->out_temporal_weight;
+
+    corr_sel sel;
+    oset_init(&sel.allPrio, cfg->num_matches + cfg->num_per_file + 2, 1);
+    oset_init(&sel.entryPrio, cfg->num_per_file + 2, 1);
+    sel.hasLast = 0;
+    sel.cfg = cfg;
+
+    float *eInBuf = (float *)calloc((size_t)numCh * mi.L, sizeof(float));  /* :154-155 */
+    float *eOutBuf = (float *)calloc((size_t)numCh * mo.L, sizeof(float));
+    int64_t maxFrames = 1;
+    for (int f = 0; f < numFiles; f++)
+        if (dbNumFrames[f] > maxFrames) maxFrames = dbNumFrames[f];
+    float *inSim = (float *)malloc(sizeof(float) * (size_t)maxFrames);
+    float *inBoost = (float *)malloc(sizeof(float) * (size_t)maxFrames);
+    float *outSim = (float *)malloc(sizeof(float) * (size_t)maxFrames);
+    float *outBoost = (float *)malloc(sizeof(float) * (size_t)maxFrames);
+
+    for (int f = 0; f < numFiles; f++) {
+        sel.entryPrio.size = 0;
+        sel.hasLast = 0;
+        const int64_t numFrames = dbNumFrames[f];
+        /* punch-in pass, :182-246 */
+        const int64_t nIn = sliding_pass(&mi, eInBuf, dbFrames[f], 0, numFrames - minPunch, numCh, normBuf, wIn,
+                                         cfg->max_boost, inSim, inBoost);
+        /* no match is added during this pass, so the gate of :212 is the same for every window */
+        const int hs0 = corr_entry_has_space(&sel);
+        const float low0 = corr_lowest_sim(&sel);
+        int64_t tInOff = -1;
+        for (int64_t i = 0; i < nIn; i++) {
+            if (denseIn && denseIn[f]) {
+                denseIn[f][i] = inSim[i];
+                denseIn[f][numFrames + i] = inBoost[i];
+            }
+            if (tInOff < 0 && (hs0 || inSim[i] > low0)) tInOff = i;
+        }
+        if (tInOff >= 0) {
+            const int64_t poOff0 = tInOff + minPunch;
+            const int64_t left = numFrames - poOff0;
+            if (left >= mo.L) { /* :260 */
+                const int64_t nOut = sliding_pass(&mo, eOutBuf, dbFrames[f], poOff0, left, numCh, normBuf, wOut,
+                                                  cfg->max_boost, outSim, outBoost);
+                if (denseOut && denseOut[f])
+                    for (int64_t k = 0; k < nOut; k++) {
+                        denseOut[f][poOff0 + k] = outSim[k];
+                        denseOut[f][numFrames + poOff0 + k] = outBoost[k];
+                    }
+                /* pairing, :319-383 */
+                for (int64_t piOff = tInOff; piOff < nIn; piOff++) {
+                    const float iSim = inSim[piOff], boostIn = inBoost[piOff];
+                    float low = corr_lowest_sim(&sel);
+                    int hs = corr_entry_has_space(&sel);
+                    if (iSim > low * low) {
+                        const int64_t seek = piOff - tInOff;
+                        int64_t left2 = nOut - seek;
+                        if (left2 > (int64_t)maxPunch - minPunch + 1) left2 = (int64_t)maxPunch - minPunch + 1;
+                        int64_t poOff = piOff + minPunch;
+                        for (int64_t j = 0; j < left2; j++, poOff++) {
+                            const float oSim = outSim[seek + j], boostOut = outBoost[seek + j];
+                            const float sim = (float)sqrt((double)(iSim * oSim)); /* Float product, :362 */
+                            if (hs || sim > low) {
+                                sgzo_match m;
+                                m.sim = sim;
+                                m.file = f;
+                                m.start = sgzo_feat_to_full((int)piOff, step);
+                                m.stop = sgzo_feat_to_full((int)poOff, step);
+                                m.boost_in = boostIn;
+                                m.boost_out = boostOut;
+                                corr_add_match(&sel, &m);
+                                low = corr_lowest_sim(&sel);
+                                hs = corr_entry_has_space(&sel);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        for (int i = 0; i < sel.entryPrio.size; i++) oset_add(&sel.allPrio, &sel.entryPrio.e[i]);
+        if (sel.allPrio.size > cfg->num_matches) sel.allPrio.size = cfg->num_matches;
+    }
+    const int n = sel.allPrio.size;
+    for (int i = 0; i < n; i++) matches[i] = sel.allPrio.e[i];
+    free(inSim);
+    free(inBoost);
+    free(outSim);
+    free(outBoost);
+    free(eInBuf);
+    free(eOutBuf);
+    free(mi.tb);
+    free(mo.tb);
     oset_free(&sel.allPrio);
     oset_free(&sel.entryPrio);
     return n;

@@ -95,6 +95,8 @@ SIGNATURES = {
     "sgz_sel_destroy": (None, [_vp]),
     "sgz_sel_feed_file": (C.c_int, [_vp, C.c_int, C.c_int64, _vp, _vp, _vp]),
     "sgz_sel_feed_candidates": (C.c_int, [_vp, _vp, C.c_int64]),
+    "sgz_sel_feed_file_punch": (C.c_int, [_vp, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp,
+                                          _vp]),
     "sgz_sel_feed_screened": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int]),
     "sgz_sel_is_full": (C.c_int, [_vp]),
     "sgz_sel_threshold": (C.c_float, [_vp]),

@@ -117,7 +117,6 @@ void writePng(const std::string &path, const int32_t *rgb, int w, int h)
 std::vector<Match> runFeatureCorrelation(sgz_context *ctx, const FeatureCorrelationConfig &cfg, const Observer &obs)
 {
     if (!ctx) throw Error(SGZ_E_ARG, "null context");
-    if (cfg.punchOut) throw Error(SGZ_E_ARG, "punchOut (in/out pairing) is not implemented");
     if (cfg.numMatches < 0 || cfg.numPerFile < 0) throw Error(SGZ_E_ARG, "numMatches / numPerFile must be >= 0");
     const FeatureExtractionConfig extrIn = FeatureExtractionConfig::fromXMLFile(cfg.metaInput);  // :35
     if (extrIn.fftOverlap < 1 || extrIn.fftSize < extrIn.fftOverlap) throw Error(SGZ_E_ARG, "bad fftSize / fftOverlap");
@@ -179,6 +178,59 @@ std::vector<Match> runFeatureCorrelation(sgz_context *ctx, const FeatureCorrelat
         sgz_selector *s;
         ~SelGuard() { sgz_sel_destroy(s); }
     } guard{sel};
+    auto collect = [&]() {
+        std::vector<sgz_match> raw((size_t)std::max(cfg.numMatches, 1));
+        const int n = sgz_sel_result(sel, raw.data(), cfg.numMatches);
+        std::vector<Match> out;
+        for (int i = 0; i < n; i++) {
+            Match m;
+            m.sim = raw[i].sim;
+            m.file = extrDBs[(size_t)dbIndex[(size_t)raw[i].file]].audioInput;  // :237
+            m.punch = Span::of(raw[i].start, raw[i].stop);
+            m.boostIn = raw[i].boost_in;
+            m.boostOut = raw[i].boost_out;
+            out.push_back(m);
+        }
+        return out;
+    };
+
+    if (cfg.punchOut) {
+        // Punch-in / punch-out search (:182-397): the similarities of both targets at every window of every
+        // file come from the exact kernel; the pairing is the reference's own sequential loop on the host.
+        const int oStart = fullToFeat(cfg.punchOut->span.start.value_or(0), stepSize);
+        const int oStop = fullToFeat(cfg.punchOut->span.stop.value_or(0), stepSize);
+        const int Lout = oStop - oStart;
+        if (Lout < 1 || oStart < 0 || (int64_t)oStop > afIn.numFrames)
+            throw Error(SGZ_E_IO, "punchOut span lies outside the input feature file");
+        const int minPunch = fullToFeat(cfg.minPunch, stepSize);  // :116-117
+        const int maxPunch = fullToFeat(cfg.maxPunch, stepSize);
+        if (minPunch < 0) throw Error(SGZ_E_ARG, "minPunch must be >= 0");
+        auto denseAll = [&](std::vector<float> &sim, std::vector<float> &boost, std::vector<size_t> &pos) {
+            pos.assign((size_t)nf + 1, 0);
+            for (int f = 0; f < nf; f++) pos[(size_t)f + 1] = pos[(size_t)f] + (size_t)sgz_corr_num_windows(ctx, f);
+            sim.resize(std::max<size_t>(pos[(size_t)nf], 1));
+            boost.resize(sim.size());
+            check(ctx, sgz_corr_run(ctx, 0, nf));
+            check(ctx, sgz_corr_read_dense_range(ctx, 0, nf, sim.data(), boost.data()));
+        };
+        std::vector<float> inSim, inBoost, outSim, outBoost;
+        std::vector<size_t> inPos, outPos;
+        denseAll(inSim, inBoost, inPos);
+        checkAborted(obs, 0.7);
+        check(ctx, sgz_corr_set_target(ctx, afIn.frames.data() + (size_t)oStart * numCh, Lout,
+                                       cfg.punchOut->temporalWeight, cfg.maxBoost));
+        denseAll(outSim, outBoost, outPos);
+        checkAborted(obs, 0.9);
+        for (int f = 0; f < nf; f++) {
+            const int rc = sgz_sel_feed_file_punch(sel, f, sgz_db_file_frames(ctx, f), L, Lout, minPunch, maxPunch,
+                                                   inSim.data() + inPos[(size_t)f], inBoost.data() + inPos[(size_t)f],
+                                                   outSim.data() + outPos[(size_t)f],
+                                                   outBoost.data() + outPos[(size_t)f]);
+            if (rc != SGZ_OK) throw Error(rc, "selector rejected its input");
+        }
+        checkAborted(obs, 1.0);
+        return collect();
+    }
 
     // GPU: all similarities; host: replay of the match bookkeeping in file order.
     const bool f16 = sgz_corr_screen_f16_available(ctx) == 1;
@@ -258,19 +310,7 @@ std::vector<Match> runFeatureCorrelation(sgz_context *ctx, const FeatureCorrelat
         }
     }
     checkAborted(obs, 1.0);
-    std::vector<sgz_match> raw((size_t)std::max(cfg.numMatches, 1));
-    const int n = sgz_sel_result(sel, raw.data(), cfg.numMatches);
-    std::vector<Match> out;
-    for (int i = 0; i < n; i++) {
-        Match m;
-        m.sim = raw[i].sim;
-        m.file = extrDBs[(size_t)dbIndex[(size_t)raw[i].file]].audioInput;  // :237
-        m.punch = Span::of(raw[i].start, raw[i].stop);
-        m.boostIn = raw[i].boost_in;
-        m.boostOut = raw[i].boost_out;
-        out.push_back(m);
-    }
-    return out;
+    return collect();
 }
 
 // -----------------------------------------------------------------------------

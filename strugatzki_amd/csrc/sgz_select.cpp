@@ -12,6 +12,7 @@
 // element.  Adding an element that compares equal to a present one leaves the
 // set as it is; removing removes whichever entry has that sim.
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -174,6 +175,64 @@ int sgz_sel_feed_file(sgz_selector *sel, int file, int64_t n, const int32_t *off
             m.boost_in = boosts[i];
             m.boost_out = 1.0f;
             sel->add_match(m);
+        }
+    }
+    for (const Entry &e : sel->entry.items()) sel->all.add(e);
+    sel->all.truncate((size_t)sel->num_matches);
+    return SGZ_OK;
+}
+
+int sgz_sel_feed_file_punch(sgz_selector *sel, int file, int64_t num_frames, int in_frames, int out_frames,
+                            int min_punch, int max_punch, const float *in_sim, const float *in_boost,
+                            const float *out_sim, const float *out_boost)
+{
+    if (!sel || num_frames < 0 || in_frames < 1 || out_frames < 1 || min_punch < 0) return SGZ_E_ARG;
+    sel->entry.clear();
+    sel->has_last = false;
+    // windows of the punch-in pass: it runs over num_frames - minPunch frames (:182-185)
+    const int64_t n_in = num_frames - min_punch >= in_frames ? num_frames - min_punch - in_frames + 1 : 0;
+    if (n_in > 0 && (!in_sim || !in_boost || !out_sim || !out_boost)) return SGZ_E_ARG;
+    // no match is added during that pass: its gate (:212) is the same for every window
+    const bool hs0 = sel->entry_has_space();
+    const float low0 = sel->lowest_sim();
+    int64_t t_in_off = -1;
+    for (int64_t i = 0; i < n_in; i++) {
+        if (hs0 || in_sim[i] > low0) {
+            t_in_off = i;
+            break;
+        }
+    }
+    if (t_in_off >= 0) {
+        const int64_t po_off0 = t_in_off + min_punch;
+        const int64_t left = num_frames - po_off0;
+        if (left >= out_frames) {  // :260
+            const int64_t n_out = left - out_frames + 1;
+            const int64_t span = (int64_t)max_punch - min_punch + 1;
+            for (int64_t pi = t_in_off; pi < n_in; pi++) {  // :322-383
+                const float isim = in_sim[pi];
+                float low = sel->lowest_sim();
+                bool hs = sel->entry_has_space();
+                if (!(isim > low * low)) continue;
+                const int64_t seek = pi - t_in_off;
+                const int64_t left2 = std::min(n_out - seek, span);
+                int64_t po = pi + min_punch;
+                for (int64_t j = 0; j < left2; j++, po++) {
+                    const float osim = out_sim[po];
+                    const float sim = (float)std::sqrt((double)(isim * osim));  // Float product, :362
+                    if (hs || sim > low) {
+                        Entry m;
+                        m.sim = sim;
+                        m.file = file;
+                        m.start = pi * sel->step_size;
+                        m.stop = po * sel->step_size;
+                        m.boost_in = in_boost[pi];
+                        m.boost_out = out_boost[po];
+                        sel->add_match(m);
+                        low = sel->lowest_sim();
+                        hs = sel->entry_has_space();
+                    }
+                }
+            }
         }
     }
     for (const Entry &e : sel->entry.items()) sel->all.add(e);

@@ -267,6 +267,18 @@ class Selector:
         if rc != N.SGZ_OK:
             raise N.NativeError(rc, "sgz_sel_feed_file")
 
+    def feed_file_punch(self, file: int, num_frames: int, in_frames: int, out_frames: int, min_punch: int,
+                        max_punch: int, in_sim: np.ndarray, in_boost: np.ndarray, out_sim: np.ndarray,
+                        out_boost: np.ndarray) -> None:
+        """One file of a punch-in / punch-out search from the dense results of both targets."""
+        a = [np.ascontiguousarray(x, dtype=np.float32) for x in (in_sim, in_boost, out_sim, out_boost)]
+        if len(a[0]) < max(0, num_frames - in_frames + 1) or len(a[2]) < max(0, num_frames - out_frames + 1):
+            raise ValueError("dense arrays are shorter than the file's windows")
+        rc = lib.sgz_sel_feed_file_punch(self._h, file, num_frames, in_frames, out_frames, min_punch, max_punch,
+                                         N.ptr(a[0]), N.ptr(a[1]), N.ptr(a[2]), N.ptr(a[3]))
+        if rc != N.SGZ_OK:
+            raise N.NativeError(rc, "sgz_sel_feed_file_punch")
+
     def feed_candidate_list(self, cands: np.ndarray) -> None:
         """All files of a (file, offset)-sorted candidate array in one call."""
         c = np.ascontiguousarray(cands, dtype=N.CANDIDATE_DTYPE)

@@ -147,6 +147,29 @@ def search(ctx: Context, p: SearchParams) -> list[N.Match]:
     return out
 
 
+def search_punch(ctx: Context, p: SearchParams, target_in: np.ndarray, weight_in: float, target_out: np.ndarray,
+                 weight_out: float, max_boost: float, min_punch: int, max_punch: int) -> list[N.Match]:
+    """Punch-in / punch-out search (impl/FeatureCorrelationImpl.scala:182-397) over the files of the context.
+    `target_in` / `target_out`: raw frames of the two punch spans; `min_punch` / `max_punch` in feature
+    frames.  Both targets are correlated with every window of every file by the exact kernel; the pairing
+    is the reference's sequential loop (Selector.feed_file_punch).  Leaves the punch-out target set."""
+    nf = ctx.num_files
+    sel = Selector(p.num_matches, p.num_per_file, p.min_spacing, p.step_size, len(target_in))
+    try:
+        dense = []
+        for tgt, w in ((target_in, weight_in), (target_out, weight_out)):
+            ctx.corr_set_target(tgt, w, max_boost)
+            ctx.corr_run(0, nf)
+            dense.append(ctx.corr_read_dense_range(0, nf) if nf else [])
+        for f in range(nf):
+            (isim, iboost), (osim, oboost) = dense[0][f], dense[1][f]
+            sel.feed_file_punch(f, ctx.file_frames(f), len(target_in), len(target_out), min_punch, max_punch,
+                                isim, iboost, osim, oboost)
+        return sel.result()
+    finally:
+        sel.close()
+
+
 def shard_files(num_files: int, head: int, rank: int, world: int) -> list[int]:
     """Global ids of the tail files rank `rank` owns (round robin keeps equal-length files balanced)."""
     return [g for g in range(head, num_files) if (g - head) % world == rank]

@@ -65,6 +65,14 @@ def synth_target(target_start: int, L: int, seed: int = SEED, num_ch: int = NUM_
     return O.synth_file(seed, TARGET_FILE, target_start + L + 16, num_ch)
 
 
+def punch_config(in_start: int, in_len: int, out_start: int, out_len: int, *, min_punch: int, max_punch: int,
+                 out_weight=0.5, **kw) -> "O.PunchConfig":
+    """Config of a punch-in / punch-out search; spans and punch lengths in feature frames."""
+    base = corr_config(in_start, in_len, **kw)
+    return O.PunchConfig(base, out_start * STEP, (out_start + out_len) * STEP, out_weight, 0, min_punch * STEP,
+                         max_punch * STEP)
+
+
 def corr_config(target_start: int, L: int, *, weight=0.5, normalize=True, max_boost=8.0, num_matches=10,
                 num_per_file=1, min_spacing=0, num_ch: int = NUM_CH) -> O.CorrConfig:
     return O.CorrConfig(target_start * STEP, (target_start + L) * STEP, weight, int(normalize), max_boost,

@@ -14,7 +14,8 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
-from common import NUM_CH, SEED, STEP, O, corr_config, make_plants, norms_default, synth_db, synth_target  # noqa: E402
+from common import (NUM_CH, SEED, STEP, O, corr_config, make_plants, norms_default, punch_config, synth_db,  # noqa: E402
+                    synth_target)
 
 
 def corr_fixture():
@@ -37,6 +38,27 @@ def corr_fixture():
     m, sims, boosts = O.correlation_run(cfg, tgt, None, db)
     out["sims_raw_w02"] = np.stack(sims)
     np.savez_compressed(os.path.join(HERE, "correlation.npz"), **out)
+
+
+PUNCH = dict(Lin=40, Lout=24, ts=12, gap=16, nf=3, frames=360,
+             settings=[(4, 1, 0, 10, 40), (5, 2, 20 * STEP, 0, 8)])  # numMatches, numPerFile, minSpacing, min/maxPunch
+
+
+def punch_fixture():
+    q = PUNCH
+    span = q["Lin"] + q["gap"] + q["Lout"]
+    db = synth_db(q["nf"], q["frames"], make_plants(2, span, q["nf"], q["frames"], q["ts"], amp_step=0.05))
+    tgt = synth_target(q["ts"], span)
+    norms = norms_default()
+    out = dict(db=np.stack(db), target=tgt, norms=norms)
+    for k, (nm, npf, ms, lo, hi) in enumerate(q["settings"]):
+        cfg = punch_config(q["ts"], q["Lin"], q["ts"] + q["Lin"] + q["gap"], q["Lout"], min_punch=lo, max_punch=hi,
+                           out_weight=0.25, num_matches=nm, num_per_file=npf, min_spacing=ms)
+        m, din, dout = O.correlation_run_punch(cfg, tgt, norms, db)
+        out[f"matches{k}"] = np.array([O.match_tuple(x) for x in m], dtype=np.float64)
+        out[f"dense_in{k}"] = np.stack(din)
+        out[f"dense_out{k}"] = np.stack(dout)
+    np.savez_compressed(os.path.join(HERE, "punch.npz"), **out)
 
 
 def segm_fixture():
@@ -62,6 +84,7 @@ def selfsim_fixture():
 
 if __name__ == "__main__":
     corr_fixture()
+    punch_fixture()
     segm_fixture()
     selfsim_fixture()
     for f in sorted(os.listdir(HERE)):

@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from common import NUM_CH, STEP, O, corr_config
+from common import NUM_CH, STEP, O, corr_config, punch_config
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -31,6 +31,46 @@ def test_oracle_reproduces_correlation_golden():
     cfg = corr_config(ts, L, weight=0.2, normalize=False, num_matches=3)
     _, sims, _ = O.correlation_run(cfg, g["target"], None, db)
     assert np.array_equal(np.stack(sims), g["sims_raw_w02"])
+
+
+def _punch_cases():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(G, "make_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.PUNCH
+
+
+def test_oracle_reproduces_punch_golden():
+    g, q = _load("punch.npz"), _punch_cases()
+    db = [np.ascontiguousarray(x) for x in g["db"]]
+    for k, (nm, npf, ms, lo, hi) in enumerate(q["settings"]):
+        cfg = punch_config(q["ts"], q["Lin"], q["ts"] + q["Lin"] + q["gap"], q["Lout"], min_punch=lo, max_punch=hi,
+                           out_weight=0.25, num_matches=nm, num_per_file=npf, min_spacing=ms)
+        m, din, dout = O.correlation_run_punch(cfg, g["target"], g["norms"], db)
+        assert np.array_equal(np.array([O.match_tuple(x) for x in m], dtype=np.float64), g[f"matches{k}"],
+                              equal_nan=True)
+        assert np.array_equal(np.stack(din), g[f"dense_in{k}"], equal_nan=True)
+        assert np.array_equal(np.stack(dout), g[f"dense_out{k}"], equal_nan=True)
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_punch_golden(ctx):
+    import strugatzki_amd as S
+    g, q = _load("punch.npz"), _punch_cases()
+    ctx.db_reset(NUM_CH)
+    for x in g["db"]:
+        ctx.db_add_file(np.ascontiguousarray(x))
+    ctx.set_norms(g["norms"])
+    tgt, ts, o0 = g["target"], q["ts"], q["ts"] + q["Lin"] + q["gap"]
+    for k, (nm, npf, ms, lo, hi) in enumerate(q["settings"]):
+        got = S.search_punch(ctx, S.SearchParams(nm, npf, ms, STEP), tgt[ts:ts + q["Lin"]], 0.5,
+                             tgt[o0:o0 + q["Lout"]], 0.25, 8.0, lo, hi)
+        want = g[f"matches{k}"]
+        assert len(got) == len(want) > 0
+        for m, w in zip(got, want):
+            assert (m.file, m.start, m.stop) == (int(w[1]), int(w[2]), int(w[3]))
+            assert abs(m.sim - w[0]) <= 1e-5 or (np.isnan(m.sim) and np.isnan(w[0]))
 
 
 def test_oracle_reproduces_segmentation_golden():

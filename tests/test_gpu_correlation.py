@@ -267,6 +267,36 @@ def test_search_sharded_single_rank_rccl(screen_head):
         assert abs(g[3] - w.sim) <= 1.2e-7
 
 
+@pytest.mark.parametrize("num_matches,num_per_file,min_spacing,min_punch,max_punch",
+                         [(5, 1, 0, 20, 60), (6, 3, 25 * STEP, 0, 12), (3, 1, 0, 40, 40)])
+def test_search_punch_out(ctx, num_matches, num_per_file, min_spacing, min_punch, max_punch):
+    """Punch-in / punch-out pairing over the GPU's dense similarities of both targets, against the oracle."""
+    import strugatzki_amd as S
+    from common import punch_config
+    Lin, Lout, ts, gap, nf, frames = 48, 32, 9, 20, 7, 420
+    db = synth_db(nf, frames, make_plants(3, Lin + gap + Lout, nf, frames, ts))
+    tgt = synth_target(ts, Lin + gap + Lout)
+    norms = norms_default()
+    o_start = ts + Lin + gap
+    cfg = punch_config(ts, Lin, o_start, Lout, min_punch=min_punch, max_punch=max_punch, out_weight=0.75,
+                       num_matches=num_matches, num_per_file=num_per_file, min_spacing=min_spacing)
+    want, din, dout = O.correlation_run_punch(cfg, tgt, norms, db)
+    _load(ctx, db, norms)
+    got = S.search_punch(ctx, S.SearchParams(num_matches, num_per_file, min_spacing, STEP), tgt[ts:ts + Lin], 0.5,
+                         tgt[o_start:o_start + Lout], 0.75, 8.0, min_punch, max_punch)
+    assert len(want) > 0
+    assert [(g.file, g.start, g.stop) for g in got] == [(w.file, w.start, w.stop) for w in want]
+    for g, w in zip(got, want):
+        # (a negative inSim * outSim gives a NaN similarity, which the gate lets in while the set has room)
+        assert abs(g.sim - w.sim) <= TOL or (np.isnan(g.sim) and np.isnan(w.sim))
+        assert abs(g.boost_in - w.boost_in) <= 2e-6 * w.boost_in
+        assert abs(g.boost_out - w.boost_out) <= 2e-6 * w.boost_out
+    # the punch-out similarities the oracle computed are those of the dense run with the punch-out target
+    sim_out, _ = ctx.corr_read_dense(2)
+    have = ~np.isnan(dout[2][0][:len(sim_out)])
+    assert have.any() and np.max(np.abs(sim_out[have] - dout[2][0][:len(sim_out)][have])) <= TOL
+
+
 def test_search_falls_back_to_dense_on_candidate_overflow(ctx):
     import strugatzki_amd as S
     L, ts, nf, frames = 64, 4, 6, 500

@@ -63,6 +63,30 @@ def test_feature_correlation_from_files(ctx, tmp_path, num_matches, num_per_file
     assert seen and seen[-1] == 1.0 and seen == sorted(seen)
 
 
+@pytest.mark.parametrize("num_matches,num_per_file,min_punch,max_punch", [(4, 1, 20, 60), (6, 2, 5, 200)])
+def test_feature_correlation_punch_out_from_files(ctx, tmp_path, num_matches, num_per_file, min_punch, max_punch):
+    """punchIn + punchOut: spans run from the punch-in to the punch-out offset, sim = sqrt(inSim * outSim)."""
+    from common import punch_config
+    Lin, Lout, ts, gap = 48, 32, 11, 30
+    db_dir, in_meta, db, _, norms, _ = _make_db(tmp_path, nf=6, frames=500, L=Lin + gap + Lout, ts=ts, nplants=3)
+    tgt = synth_target(ts, Lin + gap + Lout)
+    P.write_float_aiff(os.path.join(db_dir, "input_feat.aif"), tgt, RATE)
+    o_start = ts + Lin + gap
+    cfg = FeatureCorrelation.Config(db_dir, in_meta, FeatureCorrelation.Punch(Span(ts * STEP, (ts + Lin) * STEP), 0.5),
+                                    FeatureCorrelation.Punch(Span(o_start * STEP, (o_start + Lout) * STEP), 0.25),
+                                    min_punch * STEP, max_punch * STEP, True, 8.0, num_matches, num_per_file, 0)
+    got = FeatureCorrelation.run(ctx, cfg)
+    ocfg = punch_config(ts, Lin, o_start, Lout, min_punch=min_punch, max_punch=max_punch, out_weight=0.25,
+                        num_matches=num_matches, num_per_file=num_per_file)
+    want, _, _ = O.correlation_run_punch(ocfg, tgt, norms, db)
+    assert len(got) == len(want) > 0
+    for g, w in zip(got, want):
+        assert g.file == os.path.join(db_dir, f"snd{w.file:03d}.aif")
+        assert (g.punch.start, g.punch.stop) == (w.start, w.stop)
+        assert abs(g.sim - w.sim) <= 1e-5 or (np.isnan(g.sim) and np.isnan(w.sim))
+        assert abs(g.boostIn - w.boost_in) <= 2e-6 * w.boost_in and abs(g.boostOut - w.boost_out) <= 2e-6 * w.boost_out
+
+
 def test_feature_correlation_errors(ctx, tmp_path):
     L, ts = 64, 11
     db_dir, in_meta, *_ = _make_db(tmp_path, nf=2, L=L, ts=ts)
@@ -76,8 +100,9 @@ def test_feature_correlation_errors(ctx, tmp_path):
     with pytest.raises(P.N.NativeError):  # span beyond the input feature file
         FeatureCorrelation.run(ctx, FeatureCorrelation.Config(db_dir, in_meta, FeatureCorrelation.Punch(
             Span(0, 10 ** 9), 0.5), normalize=False))
-    with pytest.raises(P.N.NativeError):  # punch-out pairing is not implemented
-        FeatureCorrelation.run(ctx, FeatureCorrelation.Config(db_dir, in_meta, base.punchIn, base.punchIn,
+    with pytest.raises(P.N.NativeError):  # punch-out span beyond the input feature file
+        FeatureCorrelation.run(ctx, FeatureCorrelation.Config(db_dir, in_meta, base.punchIn,
+                                                              FeatureCorrelation.Punch(Span(0, 10 ** 9), 0.5),
                                                               normalize=False))
     aborted = FeatureCorrelation.Config(db_dir, in_meta, base.punchIn, normalize=False)
     with pytest.raises(P.N.NativeError) as e:

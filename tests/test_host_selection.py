@@ -55,6 +55,37 @@ def test_head_plus_candidates_replay_equals_oracle(num_matches, num_per_file, mi
     assert [match_tuple(m) for m in sel.result()] == [O.match_tuple(w) for w in want]
 
 
+PUNCH_CASES = [  # num_matches, num_per_file, min_spacing, min_punch, max_punch (feature frames)
+    (5, 1, 0, 20, 60), (3, 2, 30 * STEP, 10, 25), (8, 3, 0, 0, 5), (1, 1, 0, 40, 40), (6, 2, 0, 30, 400),
+    (4, 1, 0, 5, 3),  # maxPunch < minPunch: no pair at all
+]
+
+
+@pytest.mark.parametrize("num_matches,num_per_file,min_spacing,min_punch,max_punch", PUNCH_CASES)
+def test_punch_out_replay_equals_oracle(num_matches, num_per_file, min_spacing, min_punch, max_punch):
+    """sgz_sel_feed_file_punch over the oracle's dense punch-in / punch-out similarities."""
+    from common import punch_config
+    nf, frames, Lin, Lout, ts = 7, 420, 48, 32, 9
+    db = synth_db(nf, [frames, 300, frames, 90, frames, 200, frames], make_plants(3, Lin + 60, nf, 200, ts))
+    tgt = synth_target(ts, Lin + 120)
+    cfg = punch_config(ts, Lin, ts + Lin + 20, Lout, min_punch=min_punch, max_punch=max_punch,
+                       num_matches=num_matches, num_per_file=num_per_file, min_spacing=min_spacing)
+    want, din, dout = O.correlation_run_punch(cfg, tgt, norms_default(), db)
+    sel = Selector(num_matches, num_per_file, min_spacing, STEP, Lin)
+    for f in range(nf):
+        n = db[f].shape[0]
+        if n - min_punch < Lin:
+            continue  # the reference's stale-ring window for short files is not reproduced
+        sel.feed_file_punch(f, n, Lin, Lout, min_punch, max_punch, din[f][0], din[f][1], dout[f][0], dout[f][1])
+    got = sel.result()
+    # (a negative inSim * outSim gives a NaN similarity, which the reference's gate lets in while the set has
+    # room: compare through repr so that NaN equals NaN)
+    assert repr([match_tuple(g) for g in got]) == repr([O.match_tuple(w) for w in want])
+    if max_punch >= min_punch:
+        assert len(got) > 0 and all(g.stop - g.start >= min_punch * STEP for g in got)
+        assert all(g.stop - g.start <= max_punch * STEP for g in got)
+
+
 def test_equal_sims_are_one_set_element():
     """Two windows gated to sim 0f: the set keeps the first, the global set does not grow twice."""
     L = 8
