@@ -319,6 +319,17 @@ SGZ_API int sgz_selfsim_run(sgz_context *ctx, const float *frames1, int64_t num_
  * (impl/NonRealtimeProcessor.scala:93,107-108). */
 SGZ_API int64_t sgz_extract_num_frames(int64_t num_frames, int fft_size, int fft_overlap);
 
+/* FeatureStats over the database files [file_begin, file_end) of the context
+ * (impl/FeatureStatsImpl.scala:25-141): per file and channel the 1st and the 99th
+ * percentile from a 2048-bin histogram over [min, max] of the channel, warped by
+ * the power law that puts the channel mean at the middle bin; minmax_out
+ * receives, per channel, the smallest 1st and the largest 99th percentile over
+ * the files ([num_channels][2] doubles) -- the pairs the reference's command
+ * line writes to feat_norms.aif (Strugatzki.scala:414-429).  per_file_out (may
+ * be NULL): [files][num_channels][2].  Files must have at least one frame. */
+SGZ_API int sgz_feature_stats(sgz_context *ctx, int file_begin, int file_end, double *minmax_out,
+                              double *per_file_out);
+
 /* Extracts [loudness / 32, mfcc 0 .. num_coeffs-1] per hop from interleaved PCM
  * (host memory, num_frames x num_channels).  Takes the place of the scsynth
  * non-realtime render of impl/FeatureExtractionImpl.scala:40-69 and
@@ -357,6 +368,16 @@ SGZ_API int sgz_run_selfsimilarity_xml(sgz_context *ctx, const char *config_xml,
  * writes the feature AIFF <output> and, if <meta> is set, the config XML there.
  * Replaces impl/FeatureExtractionImpl.body() (:31-78). */
 SGZ_API int sgz_run_extraction_xml(sgz_context *ctx, const char *config_xml, sgz_progress_fn cb, void *user);
+/* FeatureStats.run (FeatureStats.scala:22-34, impl/FeatureStatsImpl.scala:31-54): the configuration is the
+ * list of feature files (AIFF / AIFC / WAVE, as written by the extraction); they replace the context's
+ * database.  minmax_out receives [channels][2] doubles, *num_channels the channel count (SGZ_E_OVERFLOW when
+ * it exceeds capacity_channels). */
+SGZ_API int sgz_run_feature_stats(sgz_context *ctx, const char *const *feature_files, int num_files,
+                                  sgz_progress_fn cb, void *user, double *minmax_out, int capacity_channels,
+                                  int *num_channels);
+/* Writes the pairs as the normalisation file the searches read: 2 frames (min, max) x num_channels, fp32
+ * AIFF at 44.1 kHz, what the reference's command line does with the result (Strugatzki.scala:414-429). */
+SGZ_API int sgz_write_norms_file(const char *path, const double *minmax, int num_channels);
 /* Text of the last failure of an sgz_run_* / sgz_*_xml / file call on this thread. */
 SGZ_API const char *sgz_host_last_error(void);
 SGZ_API void sgz_free_string(char *s);

@@ -18,6 +18,7 @@
 #include <optional>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "strugatzki_amd.h"
@@ -168,6 +169,15 @@ void runSelfSimilarity(sgz_context *ctx, const SelfSimilarityConfig &cfg, const 
 
 // impl/FeatureExtractionImpl.body(): audio file -> feature AIFF (+ meta XML).
 void runFeatureExtraction(sgz_context *ctx, const FeatureExtractionConfig &cfg, const Observer &obs = nullptr);
+
+// FeatureStats (FeatureStats.scala:22-34): Config = the feature files (*_feat.aif), Product = per channel
+// the (smallest 1st percentile, largest 99th percentile) over those files.  Replaces the files of the
+// context's database.
+std::vector<std::pair<double, double>> runFeatureStats(sgz_context *ctx, const std::vector<std::string> &featureFiles,
+                                                       const Observer &obs = nullptr);
+// Writes the pairs as the normalisation file the searches read (2 frames x numChannels, fp32 AIFF at
+// 44.1 kHz: Strugatzki.scala:414-429; file name Strugatzki.NormalizeName = "feat_norms.aif").
+void writeNormsFile(const std::string &path, const std::vector<std::pair<double, double>> &spans);
 
 // ---- feature / audio files -----------------------------------------------------
 struct AudioData {

@@ -269,6 +269,22 @@ def correlation_run_punch(cfg: PunchConfig, target: np.ndarray, norms: np.ndarra
     return [out[i] for i in range(n)], din, dout
 
 
+def feature_stats(files: list[np.ndarray]) -> np.ndarray:
+    """FeatureStats over feature files ([frames][numCh] each): [numCh][2] doubles (1st, 99th percentile)."""
+    files = [np.ascontiguousarray(x, dtype=np.float32) for x in files]
+    nch = files[0].shape[1]
+    fpp = C.POINTER(C.c_float)
+    ptrs = (fpp * len(files))(*[_fp(x) for x in files])
+    counts = (C.c_int64 * len(files))(*[x.shape[0] for x in files])
+    out = np.zeros((nch, 2), dtype=np.float64)
+    fn = lib().sgzo_feature_stats
+    fn.restype = C.c_int
+    rc = fn(ptrs, counts, C.c_int(len(files)), C.c_int(nch), out.ctypes.data_as(C.POINTER(C.c_double)))
+    if rc != 0:
+        raise ValueError("oracle rejected the feature statistics arguments")
+    return out
+
+
 def segmentation_run(cfg: SegmConfig, frames: np.ndarray, norms: np.ndarray | None):
     frames = np.ascontiguousarray(frames, dtype=np.float32)
     nrm = None if norms is None else np.ascontiguousarray(norms, dtype=np.float32)

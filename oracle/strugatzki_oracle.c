@@ -649,6 +649,93 @@ SGZO_API int64_t sgzo_correlation_num_windows(int64_t n, int32_t L)
 }
 
 /* ------------------------------------------------------------------------- */
+/* FeatureStats: impl/FeatureStatsImpl.scala:25-141                          */
+/* ------------------------------------------------------------------------- */
+
+/* Java's (double).toInt: NaN -> 0, saturating. */
+static int java_d2i(double v)
+{
+    if (v != v) return 0;
+    if (v >= 2147483647.0) return 2147483647;
+    if (v <= -2147483648.0) return (-2147483647 - 1);
+    return (int)v;
+}
+
+/*
+ * body1 (:56-140) for one feature file: per channel the 1st and the 99th
+ * percentile, from a 2048-bin histogram over the range [min, max] of the
+ * channel, warped by a power law that puts the mean at the middle bin.
+ * frames: interleaved [numFrames][numCh]; p01 / p99: numCh doubles each.
+ * Returns 0, or -1 for an empty file.
+ */
+SGZO_API int sgzo_feature_stats_file(const float *frames, int64_t numFrames, int numCh, double *p01, double *p99)
+{
+    if (numFrames <= 0 || numCh <= 0) return -1;
+    int *hist = (int *)malloc(sizeof(int) * 2048);
+    const double log05 = log(0.5);
+    for (int ch = 0; ch < numCh; ch++) {
+        float mx = -INFINITY, mn = INFINITY; /* :62-63 */
+        double sum = 0.0;
+        for (int64_t i = 0; i < numFrames; i++) { /* :72-83, frame order */
+            const float f = frames[(size_t)i * numCh + ch];
+            if (f < mn) mn = f;
+            if (f > mx) mx = f;
+            sum += f;
+        }
+        const double mean = sum / (double)numFrames;      /* :88 */
+        const float d = mx - mn;                          /* Float, :89 */
+        const double mnorm = (mean - (double)mn) / (double)d;
+        const double skew = log05 / log(mnorm);           /* :91 */
+        memset(hist, 0, sizeof(int) * 2048);
+        for (int64_t i = 0; i < numFrames; i++) {         /* :98-114 */
+            const float f = frames[(size_t)i * numCh + ch];
+            const float q = (f - mn) / d;                 /* Float arithmetic, :110 */
+            const int bin = java_d2i(pow((double)q, skew) * 2047 + 0.5);
+            if (bin >= 0 && bin < 2048) hist[bin] += 1;   /* the reference would throw outside */
+        }
+        const int p01n = java_d2i((double)numFrames * 0.01); /* :119-120 */
+        const int p99n = java_d2i((double)numFrames * 0.99);
+        const double skewr = 1.0 / skew;
+        int cnt = 0, i = 0;
+        while (cnt < p01n && i < 2048) cnt += hist[i++];
+        p01[ch] = pow((double)i / 2048, skewr) * (double)d + (double)mn; /* :128 */
+        while (cnt < p99n && i < 2048) cnt += hist[i++];
+        p99[ch] = pow((double)i / 2048, skewr) * (double)d + (double)mn; /* :133 */
+    }
+    free(hist);
+    return 0;
+}
+
+/* body (:31-54): the smallest 1st and the largest 99th percentile over all files.
+ * out: [numCh][2] doubles (min, max).  math.min / math.max propagate NaN. */
+SGZO_API int sgzo_feature_stats(const float *const *files, const int64_t *numFrames, int numFiles, int numCh,
+                                double *out)
+{
+    double *p01 = (double *)malloc(sizeof(double) * (size_t)numCh);
+    double *p99 = (double *)malloc(sizeof(double) * (size_t)numCh);
+    int rc = numFiles > 0 ? 0 : -1;
+    for (int f = 0; f < numFiles && rc == 0; f++) {
+        rc = sgzo_feature_stats_file(files[f], numFrames[f], numCh, p01, p99);
+        if (rc) break;
+        for (int ch = 0; ch < numCh; ch++) {
+            if (f == 0) {
+                out[2 * ch] = p01[ch];
+                out[2 * ch + 1] = p99[ch];
+            } else {
+                double a = out[2 * ch], b = p01[ch];
+                out[2 * ch] = (a != a || b != b) ? NAN : (a < b ? a : b);
+                a = out[2 * ch + 1];
+                b = p99[ch];
+                out[2 * ch + 1] = (a != a || b != b) ? NAN : (a > b ? a : b);
+            }
+        }
+    }
+    free(p01);
+    free(p99);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------- */
 /* FeatureSegmentation: impl/FeatureSegmentationImpl.scala:31-142            */
 /* ------------------------------------------------------------------------- */
 

@@ -19,6 +19,7 @@ SGZ_E_HIP = -2
 SGZ_E_STATE = -3
 SGZ_E_OVERFLOW = -4
 SGZ_E_IO = -5
+SGZ_MAX_CHANNELS = 64
 
 
 class Candidate(C.Structure):
@@ -78,6 +79,9 @@ SIGNATURES = {
     "sgz_corr_num_windows": (C.c_int64, [_vp, C.c_int]),
     "sgz_corr_run": (C.c_int, [_vp, C.c_int, C.c_int]),
     "sgz_corr_run_screen": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "sgz_feature_stats": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
+    "sgz_run_feature_stats": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int, _vp]),
+    "sgz_write_norms_file": (C.c_int, [C.c_char_p, _vp, C.c_int]),
     "sgz_corr_run_screen_f16": (C.c_int, [_vp, C.c_int, C.c_int]),
     "sgz_corr_screen_f16_available": (C.c_int, [_vp]),
     "sgz_corr_read_dense": (C.c_int, [_vp, C.c_int, _vp, _vp]),

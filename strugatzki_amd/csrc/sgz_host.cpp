@@ -400,6 +400,49 @@ void runSelfSimilarity(sgz_context *ctx, const SelfSimilarityConfig &cfg, const 
 // -----------------------------------------------------------------------------
 // FeatureExtraction: impl/FeatureExtractionImpl.scala:31-78, impl/NonRealtimeProcessor.scala:163-200
 // -----------------------------------------------------------------------------
+// -----------------------------------------------------------------------------
+// FeatureStats: impl/FeatureStatsImpl.scala:25-141
+// -----------------------------------------------------------------------------
+std::vector<std::pair<double, double>> runFeatureStats(sgz_context *ctx, const std::vector<std::string> &featureFiles,
+                                                       const Observer &obs)
+{
+    if (!ctx) throw Error(SGZ_E_ARG, "null context");
+    if (featureFiles.empty()) throw Error(SGZ_E_ARG, "no feature files");
+    int numCh = 0;
+    for (size_t i = 0; i < featureFiles.size(); i++) {
+        checkAborted(obs, 0.8 * (double)i / (double)featureFiles.size());
+        const AudioData af = readAudioFile(featureFiles[i]);
+        if (i == 0) {
+            numCh = af.numChannels;
+            check(ctx, sgz_db_reset(ctx, numCh));
+        } else if (af.numChannels != numCh) {  // require(mins.length == numCh ...), :41
+            throw Error(SGZ_E_IO, "feature file " + featureFiles[i] + " has a different number of channels");
+        }
+        if (af.numFrames < 1) throw Error(SGZ_E_IO, "feature file " + featureFiles[i] + " is empty");
+        check(ctx, sgz_db_add_file(ctx, af.frames.data(), af.numFrames));
+    }
+    std::vector<double> mm((size_t)numCh * 2);
+    check(ctx, sgz_feature_stats(ctx, 0, (int)featureFiles.size(), mm.data(), nullptr));
+    std::vector<std::pair<double, double>> out;
+    for (int c = 0; c < numCh; c++) out.emplace_back(mm[(size_t)2 * c], mm[(size_t)2 * c + 1]);
+    notify(obs, 1.0);
+    return out;
+}
+
+void writeNormsFile(const std::string &path, const std::vector<std::pair<double, double>> &spans)
+{
+    AudioData d;
+    d.numChannels = (int)spans.size();
+    d.numFrames = 2;
+    d.sampleRate = 44100.0;
+    d.frames.resize(spans.size() * 2);
+    for (size_t c = 0; c < spans.size(); c++) {
+        d.frames[c] = (float)spans[c].first;                  // frame 0: min
+        d.frames[spans.size() + c] = (float)spans[c].second;  // frame 1: max
+    }
+    writeFloatAiff(path, d);
+}
+
 void runFeatureExtraction(sgz_context *ctx, const FeatureExtractionConfig &cfg, const Observer &obs)
 {
     if (!ctx) throw Error(SGZ_E_ARG, "null context");
@@ -532,6 +575,36 @@ int sgz_run_extraction_xml(sgz_context *ctx, const char *config_xml, sgz_progres
     return guarded([&] {
         const auto cfg = strugatzki::FeatureExtractionConfig::fromXML(config_xml);
         strugatzki::runFeatureExtraction(ctx, cfg, makeObserver(cb, user));
+    });
+}
+
+int sgz_run_feature_stats(sgz_context *ctx, const char *const *feature_files, int num_files, sgz_progress_fn cb,
+                          void *user, double *minmax_out, int capacity_channels, int *num_channels)
+{
+    if (!feature_files || num_files < 1 || !minmax_out || !num_channels) return SGZ_E_ARG;
+    return guarded([&] {
+        std::vector<std::string> paths;
+        for (int i = 0; i < num_files; i++) {
+            if (!feature_files[i]) throw strugatzki::Error(SGZ_E_ARG, "null path");
+            paths.emplace_back(feature_files[i]);
+        }
+        const auto spans = strugatzki::runFeatureStats(ctx, paths, makeObserver(cb, user));
+        *num_channels = (int)spans.size();
+        if ((int)spans.size() > capacity_channels) throw strugatzki::Error(SGZ_E_OVERFLOW, "minmax_out is too small");
+        for (size_t c = 0; c < spans.size(); c++) {
+            minmax_out[2 * c] = spans[c].first;
+            minmax_out[2 * c + 1] = spans[c].second;
+        }
+    });
+}
+
+int sgz_write_norms_file(const char *path, const double *minmax, int num_channels)
+{
+    if (!path || !minmax || num_channels < 1) return SGZ_E_ARG;
+    return guarded([&] {
+        std::vector<std::pair<double, double>> spans;
+        for (int c = 0; c < num_channels; c++) spans.emplace_back(minmax[2 * c], minmax[2 * c + 1]);
+        strugatzki::writeNormsFile(path, spans);
     });
 }
 

@@ -189,6 +189,17 @@ class Context:
     def synchronize(self) -> None:
         self._check(lib.sgz_synchronize(self._h))
 
+    # ---- feature statistics ------------------------------------------------
+    def feature_stats(self, file_begin: int = 0, file_end: int | None = None, per_file: bool = False):
+        """[numCh][2] doubles: smallest 1st / largest 99th percentile over the files (FeatureStats); with
+        per_file=True also the [files][numCh][2] percentiles of every file."""
+        if file_end is None:
+            file_end = self.num_files
+        out = np.zeros((self.num_channels, 2), dtype=np.float64)
+        pf = np.zeros((max(file_end - file_begin, 1), self.num_channels, 2), dtype=np.float64) if per_file else None
+        self._check(lib.sgz_feature_stats(self._h, file_begin, file_end, N.ptr(out), N.ptr(pf) if per_file else None))
+        return (out, pf) if per_file else out
+
     # ---- segmentation / self-similarity ----------------------------------
     def segm_curve(self, frames: np.ndarray, norms: np.ndarray | None, af_start: int, af_stop: int, half_win: int,
                    temporal_weight: float) -> np.ndarray:

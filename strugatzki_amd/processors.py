@@ -11,6 +11,7 @@ body runs: files, norms, GPU kernels, selection.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import xml.etree.ElementTree as ET
 from dataclasses import dataclass, field
 from typing import Callable, Optional
@@ -124,6 +125,31 @@ class FeatureExtraction:
     def run(ctx: Context, config: "FeatureExtraction.Config", observer: Observer = None) -> None:
         cb = _callback(observer)
         _host_check(lib.sgz_run_extraction_xml(ctx._h, config.to_xml().encode(), cb, None))
+
+
+class FeatureStats:
+    """FeatureStats.scala:22-34: Config = the feature files, Product = per channel (min, max)."""
+
+    NORMALIZE_NAME = "feat_norms.aif"  # Strugatzki.NormalizeName
+
+    @staticmethod
+    def run(ctx: Context, config: list[str], observer: Observer = None) -> list[tuple[float, float]]:
+        """Per channel the smallest 1st and the largest 99th percentile over the given feature files
+        (impl/FeatureStatsImpl.scala:31-54).  Replaces the files of the context's database."""
+        paths = [os.fspath(p).encode() for p in config]
+        arr = (C.c_char_p * max(len(paths), 1))(*paths)
+        out = np.zeros((N.SGZ_MAX_CHANNELS, 2), dtype=np.float64)
+        nch = C.c_int(0)
+        cb = _callback(observer)
+        _host_check(lib.sgz_run_feature_stats(ctx._h, arr, len(paths), cb, None, N.ptr(out), N.SGZ_MAX_CHANNELS,
+                                              C.byref(nch)))
+        return [(float(a), float(b)) for a, b in out[: nch.value]]
+
+    @staticmethod
+    def write_norms(path: str, spans: list[tuple[float, float]]) -> None:
+        """The normalisation file the searches read (Strugatzki.scala:414-429)."""
+        a = np.ascontiguousarray(spans, dtype=np.float64)
+        _host_check(lib.sgz_write_norms_file(os.fspath(path).encode(), N.ptr(a), a.shape[0]))
 
 
 class FeatureCorrelation:

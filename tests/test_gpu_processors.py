@@ -110,6 +110,37 @@ def test_feature_correlation_errors(ctx, tmp_path):
     assert "aborted" in str(e.value)
 
 
+def test_feature_stats(ctx, tmp_path):
+    """FeatureStats on the GPU against the oracle: array level (per file and merged) and from files, and the
+    norms file it writes is the one the searches read."""
+    db = synth_db(5, [3000, 1800, 2600, 900, 4100])
+    db[3] = db[3] * np.float32(1.7) - np.float32(0.2)  # one file with another range
+    want = O.feature_stats(db)
+    ctx.db_reset(NUM_CH)
+    for x in db:
+        ctx.db_add_file(x)
+    got, per = ctx.feature_stats(per_file=True)
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=0)
+    for f, x in enumerate(db):
+        np.testing.assert_allclose(per[f], O.feature_stats([x]), rtol=1e-12, atol=0)
+    d = str(tmp_path)
+    paths = []
+    for f, x in enumerate(db):
+        paths.append(os.path.join(d, f"s{f}_feat.aif"))
+        P.write_float_aiff(paths[-1], x, RATE)
+    seen = []
+    spans = P.FeatureStats.run(ctx, paths, lambda p: seen.append(p) or True)
+    np.testing.assert_allclose(np.array(spans), want, rtol=1e-12, atol=0)
+    assert seen and seen[-1] == 1.0
+    norms_path = os.path.join(d, P.FeatureStats.NORMALIZE_NAME)
+    P.FeatureStats.write_norms(norms_path, spans)
+    frames, rate = P.read_audio_file(norms_path)
+    assert frames.shape == (2, NUM_CH) and rate == 44100.0
+    assert np.array_equal(frames, np.array(spans, dtype=np.float64).T.astype(np.float32))
+    with pytest.raises(P.N.NativeError):
+        P.FeatureStats.run(ctx, [os.path.join(d, "missing_feat.aif")])
+
+
 def test_feature_segmentation_from_files(ctx, tmp_path):
     d = str(tmp_path)
     frames = np.concatenate([O.synth_file(SEED, k, 300, NUM_CH) * np.float32(1.0 - 0.25 * (k % 2)) for k in range(4)])

@@ -166,3 +166,18 @@ def test_selfsim_auto_decimation_cap():
     cfg = O.SelfSimConfig(0, 0, 0, 0, 44100, 1, 0.5, 0, 1.0, 1.0, 0, 1, STEP, NUM_CH - 1)
     ext, decim, _, num_corrs = O.selfsim_geometry(cfg, 155039, 155039)
     assert num_corrs == 155039 - 172 + 1 and decim == 4 and ext == num_corrs // 4 == 38717
+
+
+def test_feature_stats_percentiles_bracket_the_data():
+    """FeatureStats (impl/FeatureStatsImpl.scala:56-140): the warped-histogram percentiles lie close to the true
+    1st / 99th percentiles of each file, and the merge takes the outermost ones."""
+    from common import synth_db
+    db = synth_db(3, [4000, 2500, 1200])
+    mm = O.feature_stats(db)
+    per = [O.feature_stats([x]) for x in db]
+    for ch in range(db[0].shape[1]):
+        assert mm[ch, 0] == min(p[ch, 0] for p in per) and mm[ch, 1] == max(p[ch, 1] for p in per)
+        for x, p in zip(db, per):
+            lo, hi = np.percentile(x[:, ch], [1, 99])
+            spread = x[:, ch].max() - x[:, ch].min()
+            assert abs(p[ch, 0] - lo) < 0.02 * spread and abs(p[ch, 1] - hi) < 0.02 * spread
