@@ -368,6 +368,12 @@ SGZ_API int sgz_run_selfsimilarity_xml(sgz_context *ctx, const char *config_xml,
  * writes the feature AIFF <output> and, if <meta> is set, the config XML there.
  * Replaces impl/FeatureExtractionImpl.body() (:31-78). */
 SGZ_API int sgz_run_extraction_xml(sgz_context *ctx, const char *config_xml, sgz_progress_fn cb, void *user);
+/* CrossSimilarity.run with the reference's <crosssimilarity> document (CrossSimilarity.scala:182-246,
+ * impl/CrossSimilarityImpl.scala:32-173): the shorter span is correlated with every offset of the longer
+ * one (exact kernel); the similarities are written to <output> as a 1-channel fp32 AIFF at the feature
+ * rate of input 1.  The ring of the reference (8192 frames wide, offsets wrapping at the target length:
+ * :118-119, 140, 165) is taken as the target length.  Replaces the files of the context's database. */
+SGZ_API int sgz_run_crosssimilarity_xml(sgz_context *ctx, const char *config_xml, sgz_progress_fn cb, void *user);
 /* FeatureStats.run (FeatureStats.scala:22-34, impl/FeatureStatsImpl.scala:31-54): the configuration is the
  * list of feature files (AIFF / AIFC / WAVE, as written by the extraction); they replace the context's
  * database.  minmax_out receives [channels][2] doubles, *num_channels the channel count (SGZ_E_OVERFLOW when

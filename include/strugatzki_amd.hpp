@@ -119,6 +119,24 @@ struct FeatureSegmentationConfig {
     bool operator==(const FeatureSegmentationConfig &o) const;
 };
 
+// ---- CrossSimilarity (CrossSimilarity.scala:24-279) ---------------------------
+struct CrossSimilarityConfig {
+    std::string databaseFolder = "database";
+    std::string metaInput1 = "input1_feat.xml";
+    std::string metaInput2 = "input2_feat.xml";
+    std::string audioOutput = "output.aif";
+    std::string audioOutputType = "aiff";  // AudioFileType.id; only "aiff" can be written here
+    Span span1 = Span::all();
+    Span span2 = Span::all();
+    float temporalWeight = 0.5f;
+    bool normalize = true;
+    float maxBoost = 8.0f;
+
+    std::string toXML() const;  // <crosssimilarity>...</crosssimilarity>
+    static CrossSimilarityConfig fromXML(const std::string &xml);
+    bool operator==(const CrossSimilarityConfig &o) const;
+};
+
 // ---- SelfSimilarity ----------------------------------------------------------
 enum class ColorScheme : int { GrayScale = 0, PsychoOptical = 1 };  // logical names "gray", "psycho"
 
@@ -169,6 +187,13 @@ void runSelfSimilarity(sgz_context *ctx, const SelfSimilarityConfig &cfg, const 
 
 // impl/FeatureExtractionImpl.body(): audio file -> feature AIFF (+ meta XML).
 void runFeatureExtraction(sgz_context *ctx, const FeatureExtractionConfig &cfg, const Observer &obs = nullptr);
+
+// CrossSimilarity (impl/CrossSimilarityImpl.scala:32-173): the shorter of the two spans is the target, the
+// longer one is slid past it; the similarity of every offset goes to a 1-channel fp32 audio file at the
+// feature rate of input 1.  The reference's ring buffer is 8192 frames wide while its offsets wrap at
+// the target length (:118-119, 140, 165), which only agrees for targets of exactly 8192 frames; this
+// implements the evident intent: ring = target length, len2 - len1 + 1 output values.
+void runCrossSimilarity(sgz_context *ctx, const CrossSimilarityConfig &cfg, const Observer &obs = nullptr);
 
 // FeatureStats (FeatureStats.scala:22-34): Config = the feature files (*_feat.aif), Product = per channel
 // the (smallest 1st percentile, largest 99th percentile) over those files.  Replaces the files of the

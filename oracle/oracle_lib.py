@@ -269,6 +269,31 @@ def correlation_run_punch(cfg: PunchConfig, target: np.ndarray, norms: np.ndarra
     return [out[i] for i in range(n)], din, dout
 
 
+def crosssim_span(span_start, span_stop, num_frames: int, step: int) -> tuple[int, int]:
+    """(first frame, frame count) of a span (None = open end) in a feature file; CrossSimilarityImpl.openInput."""
+    a, n = C.c_int64(), C.c_int64()
+    lib().sgzo_crosssim_span(C.c_int(span_start is not None), C.c_int(span_stop is not None),
+                             C.c_int64(span_start or 0), C.c_int64(span_stop or 0), C.c_int64(num_frames),
+                             C.c_int(step), C.byref(a), C.byref(n))
+    return a.value, n.value
+
+
+def crosssim_run(frames1: np.ndarray, frames2: np.ndarray, norms: np.ndarray | None, weight: float,
+                 max_boost: float) -> np.ndarray:
+    """Similarity curve of the shorter array slid along the longer one (CrossSimilarity)."""
+    f1 = np.ascontiguousarray(frames1, dtype=np.float32)
+    f2 = np.ascontiguousarray(frames2, dtype=np.float32)
+    nrm = None if norms is None else np.ascontiguousarray(norms, dtype=np.float32)
+    out = np.zeros(max(f1.shape[0], f2.shape[0], 1), dtype=np.float32)
+    fn = lib().sgzo_crosssim_run
+    fn.restype = C.c_int64
+    n = fn(_fp(f1), C.c_int64(f1.shape[0]), _fp(f2), C.c_int64(f2.shape[0]), C.c_int(f1.shape[1]), _fp(nrm),
+           C.c_float(weight), C.c_float(max_boost), _fp(out))
+    if n < 0:
+        raise ValueError("oracle rejected the cross-similarity arguments")
+    return out[:n].copy()
+
+
 def feature_stats(files: list[np.ndarray]) -> np.ndarray:
     """FeatureStats over feature files ([frames][numCh] each): [numCh][2] doubles (1st, 99th percentile)."""
     files = [np.ascontiguousarray(x, dtype=np.float32) for x in files]

@@ -649,6 +649,59 @@ SGZO_API int64_t sgzo_correlation_num_windows(int64_t n, int32_t L)
 }
 
 /* ------------------------------------------------------------------------- */
+/* CrossSimilarity: impl/CrossSimilarityImpl.scala:32-173                     */
+/* ------------------------------------------------------------------------- */
+
+/* openInput (:67-80): frame range of a span in a feature file of numFrames frames. */
+SGZO_API void sgzo_crosssim_span(int hasStart, int hasStop, int64_t spanStart, int64_t spanStop, int64_t numFrames,
+                                 int step, int64_t *startOut, int64_t *lenOut)
+{
+    const int64_t s0 = hasStart ? sgzo_full_to_feat(spanStart, step) : 0;
+    const int64_t s1 = hasStop ? sgzo_full_to_feat(spanStop, step) : numFrames;
+    const int64_t stop = numFrames < s1 ? numFrames : s1;
+    int64_t start = stop < s0 ? stop : s0;
+    if (start < 0) start = 0;
+    *startOut = start;
+    *lenOut = stop - start;
+}
+
+/*
+ * The sliding loop (:98-168) over two spans given as interleaved frame arrays
+ * (already cut to their spans).  The shorter one (the second one on a tie,
+ * :92-94) is the target.  The reference allocates its ring 8192 frames wide and
+ * fills 8192 frames in the first round while every offset wraps at the target
+ * length (:118-119, 140, 165); the two only agree for a target of exactly 8192
+ * frames.  This statement takes the ring as the target length, so that output k
+ * is the similarity of the target with frames k .. k + len1 - 1 of the longer
+ * span.  out: room for max(n1, n2) values; returns their number, -1 on bad input.
+ */
+SGZO_API int64_t sgzo_crosssim_run(const float *frames1, int64_t n1, const float *frames2, int64_t n2, int numCh,
+                                   const float *norms, float weight, float maxBoost, float *out)
+{
+    const int firstIsShort = n1 < n2;
+    const float *tg = firstIsShort ? frames1 : frames2;
+    const float *db = firstIsShort ? frames2 : frames1;
+    const int64_t len1 = firstIsShort ? n1 : n2, len2 = firstIsShort ? n2 : n1;
+    if (len1 < 1 || len1 >= 0x7FFFFFFF || numCh < 2) return -1;
+    in_matrix m;
+    m.L = (int)len1;
+    m.tb = (float *)malloc(sizeof(float) * (size_t)numCh * (size_t)len1);
+    for (int ch = 0; ch < numCh; ch++)
+        for (int64_t i = 0; i < len1; i++) m.tb[(size_t)ch * len1 + i] = tg[(size_t)i * numCh + ch];
+    sgzo_normalize(norms, m.tb, numCh, m.L, 0, m.L); /* :102 */
+    sgzo_stat(m.tb, m.L, 0, m.L, 0, 1, &m.tMean, &m.tStd);
+    sgzo_stat(m.tb + m.L, m.L, 0, m.L, 0, numCh - 1, &m.sMean, &m.sStd);
+    m.lnAvgLoudness = log((double)sgzo_avg(m.tb, 0, m.L));
+    float *ring = (float *)calloc((size_t)numCh * (size_t)len1, sizeof(float));
+    float *boosts = (float *)malloc(sizeof(float) * (size_t)len2);
+    const int64_t n = sliding_pass(&m, ring, db, 0, len2, numCh, norms, weight, maxBoost, out, boosts);
+    free(boosts);
+    free(ring);
+    free(m.tb);
+    return n;
+}
+
+/* ------------------------------------------------------------------------- */
 /* FeatureStats: impl/FeatureStatsImpl.scala:25-141                          */
 /* ------------------------------------------------------------------------- */
 

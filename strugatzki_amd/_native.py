@@ -125,6 +125,7 @@ SIGNATURES = {
          C.POINTER(C.c_int64)],
     ),
     "sgz_run_extraction_xml": (C.c_int, [_vp, C.c_char_p, _vp, _vp]),
+    "sgz_run_crosssimilarity_xml": (C.c_int, [_vp, C.c_char_p, _vp, _vp]),
     "sgz_run_correlation_xml": (C.c_int, [_vp, C.c_char_p, _vp, _vp, C.POINTER(_vp)]),
     "sgz_run_segmentation_xml": (C.c_int, [_vp, C.c_char_p, _vp, _vp, C.POINTER(_vp)]),
     "sgz_run_selfsimilarity_xml": (C.c_int, [_vp, C.c_char_p, _vp, _vp]),

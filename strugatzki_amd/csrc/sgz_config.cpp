@@ -416,6 +416,41 @@ bool FeatureSegmentationConfig::operator==(const FeatureSegmentationConfig &o) c
            minSpacing == o.minSpacing;
 }
 
+// ---- CrossSimilarity (CrossSimilarity.scala:182-246) -------------------------------
+std::string CrossSimilarityConfig::toXML() const
+{
+    std::string o = "<crosssimilarity>\n  <database>" + escape(databaseFolder) + "</database>\n  <input1>" +
+                    escape(metaInput1) + "</input1>\n  <input2>" + escape(metaInput2) + "</input2>\n  <output>" +
+                    escape(audioOutput) + "</output>\n  <outputType>" + escape(audioOutputType) + "</outputType>\n";
+    if (span1.start || span1.stop) o += "  <span1>" + spanChildren(span1) + "</span1>\n";
+    if (span2.start || span2.stop) o += "  <span2>" + spanChildren(span2) + "</span2>\n";
+    o += "  <weight>" + fstr(temporalWeight) + "</weight>\n  <normalize>" + bstr(normalize) +
+         "</normalize>\n  <maxBoost>" + fstr(maxBoost) + "</maxBoost>\n</crosssimilarity>";
+    return o;
+}
+CrossSimilarityConfig CrossSimilarityConfig::fromXML(const std::string &xml)
+{
+    auto r = parseRoot(xml, "crosssimilarity");
+    CrossSimilarityConfig c;
+    c.databaseFolder = r->childText("database");
+    c.metaInput1 = r->childText("input1");
+    c.metaInput2 = r->childText("input2");
+    c.audioOutput = r->childText("output");
+    c.audioOutputType = r->childText("outputType");
+    c.span1 = r->child("span1") ? spanFromNode(r->child("span1")) : Span::all();
+    c.span2 = r->child("span2") ? spanFromNode(r->child("span2")) : Span::all();
+    c.temporalWeight = toFloat(r->childText("weight"), "weight");
+    c.normalize = toBool(r->childText("normalize"), "normalize");
+    c.maxBoost = toFloat(r->childText("maxBoost"), "maxBoost");
+    return c;
+}
+bool CrossSimilarityConfig::operator==(const CrossSimilarityConfig &o) const
+{
+    return databaseFolder == o.databaseFolder && metaInput1 == o.metaInput1 && metaInput2 == o.metaInput2 &&
+           audioOutput == o.audioOutput && audioOutputType == o.audioOutputType && span1 == o.span1 &&
+           span2 == o.span2 && temporalWeight == o.temporalWeight && normalize == o.normalize && maxBoost == o.maxBoost;
+}
+
 // ---- SelfSimilarity --------------------------------------------------------------
 std::string SelfSimilarityConfig::toXML() const
 {

@@ -401,6 +401,65 @@ void runSelfSimilarity(sgz_context *ctx, const SelfSimilarityConfig &cfg, const 
 // FeatureExtraction: impl/FeatureExtractionImpl.scala:31-78, impl/NonRealtimeProcessor.scala:163-200
 // -----------------------------------------------------------------------------
 // -----------------------------------------------------------------------------
+// CrossSimilarity: impl/CrossSimilarityImpl.scala:32-173
+// -----------------------------------------------------------------------------
+void runCrossSimilarity(sgz_context *ctx, const CrossSimilarityConfig &cfg, const Observer &obs)
+{
+    if (!ctx) throw Error(SGZ_E_ARG, "null context");
+    if (cfg.audioOutputType != "aiff") throw Error(SGZ_E_ARG, "only outputType aiff can be written");
+    const FeatureExtractionConfig e1 = FeatureExtractionConfig::fromXMLFile(cfg.metaInput1);
+    const FeatureExtractionConfig e2 = FeatureExtractionConfig::fromXMLFile(cfg.metaInput2);
+    if (e1.fftSize != e2.fftSize || e1.fftOverlap != e2.fftOverlap || e1.numCoeffs != e2.numCoeffs)  // :39-41
+        throw Error(SGZ_E_ARG, "Analysis settings for " + cfg.metaInput1 + " and " + cfg.metaInput2 + " differ.");
+    if (e1.fftOverlap < 1 || e1.fftSize < e1.fftOverlap) throw Error(SGZ_E_ARG, "bad fftSize / fftOverlap");
+    const int stepSize = e1.fftSize / e1.fftOverlap;
+    const int numCh = e1.numCoeffs + 1;
+    std::vector<float> norms;
+    if (cfg.normalize) norms = readNorms(cfg.databaseFolder, numCh);  // :48-58
+    const AudioData a1 = readAudioFile(e1.featureOutput);
+    const AudioData a2 = readAudioFile(e2.featureOutput);
+    if (a1.numChannels != numCh || a2.numChannels != numCh)
+        throw Error(SGZ_E_IO, "feature file has the wrong number of channels");
+    // openInput, :67-80
+    auto open = [&](const AudioData &af, const Span &sp, int64_t &start, int64_t &len) {
+        const int64_t s0 = sp.start ? fullToFeat(*sp.start, stepSize) : 0;
+        const int64_t s1 = sp.stop ? fullToFeat(*sp.stop, stepSize) : af.numFrames;
+        const int64_t stop = std::min<int64_t>(af.numFrames, s1);
+        start = std::max<int64_t>(0, std::min(stop, s0));
+        len = stop - start;
+    };
+    int64_t st1, ln1, st2, ln2;
+    open(a1, cfg.span1, st1, ln1);
+    open(a2, cfg.span2, st2, ln2);
+    // :92-94 -- the shorter span is read in completely, the longer one piecewise
+    const bool firstIsShort = ln1 < ln2;
+    const AudioData &tg = firstIsShort ? a1 : a2;
+    const AudioData &db = firstIsShort ? a2 : a1;
+    const int64_t tgStart = firstIsShort ? st1 : st2, tgLen = firstIsShort ? ln1 : ln2;
+    const int64_t dbStart = firstIsShort ? st2 : st1, dbLen = firstIsShort ? ln2 : ln1;
+    if (tgLen < 1) throw Error(SGZ_E_ARG, "empty span");
+    if (tgLen >= 0x7FFFFFFF) throw Error(SGZ_E_ARG, "span too large");  // :96
+    checkAborted(obs, 0.0);
+    check(ctx, sgz_db_reset(ctx, numCh));
+    check(ctx, sgz_db_add_file(ctx, db.frames.data() + (size_t)dbStart * numCh, dbLen));
+    check(ctx, sgz_set_norms(ctx, cfg.normalize ? norms.data() : nullptr));
+    check(ctx, sgz_corr_set_target(ctx, tg.frames.data() + (size_t)tgStart * numCh, (int)tgLen, cfg.temporalWeight,
+                                   cfg.maxBoost));
+    check(ctx, sgz_corr_run(ctx, 0, 1));
+    const int64_t n = sgz_corr_num_windows(ctx, 0);
+    AudioData out;
+    out.numChannels = 1;
+    out.numFrames = n;
+    out.sampleRate = a1.sampleRate;  // :86
+    out.frames.resize((size_t)std::max<int64_t>(n, 1));
+    if (n > 0) check(ctx, sgz_corr_read_dense(ctx, 0, out.frames.data(), nullptr));
+    out.frames.resize((size_t)n);
+    checkAborted(obs, 0.9);
+    writeFloatAiff(cfg.audioOutput, out);
+    notify(obs, 1.0);
+}
+
+// -----------------------------------------------------------------------------
 // FeatureStats: impl/FeatureStatsImpl.scala:25-141
 // -----------------------------------------------------------------------------
 std::vector<std::pair<double, double>> runFeatureStats(sgz_context *ctx, const std::vector<std::string> &featureFiles,
@@ -578,6 +637,15 @@ int sgz_run_extraction_xml(sgz_context *ctx, const char *config_xml, sgz_progres
     });
 }
 
+int sgz_run_crosssimilarity_xml(sgz_context *ctx, const char *config_xml, sgz_progress_fn cb, void *user)
+{
+    if (!config_xml) return SGZ_E_ARG;
+    return guarded([&] {
+        const auto cfg = strugatzki::CrossSimilarityConfig::fromXML(config_xml);
+        strugatzki::runCrossSimilarity(ctx, cfg, makeObserver(cb, user));
+    });
+}
+
 int sgz_run_feature_stats(sgz_context *ctx, const char *const *feature_files, int num_files, sgz_progress_fn cb,
                           void *user, double *minmax_out, int capacity_channels, int *num_channels)
 {
@@ -621,6 +689,7 @@ int sgz_config_roundtrip_xml(const char *kind, const char *xml, char **out_xml)
         else if (k == "segmentation") o = strugatzki::FeatureSegmentationConfig::fromXML(xml).toXML();
         else if (k == "break") o = strugatzki::Break::fromXML(xml).toXML();
         else if (k == "selfsimilarity") o = strugatzki::SelfSimilarityConfig::fromXML(xml).toXML();
+        else if (k == "crosssimilarity") o = strugatzki::CrossSimilarityConfig::fromXML(xml).toXML();
         else throw strugatzki::Error(SGZ_E_ARG, "unknown config kind " + k);
         *out_xml = dupString(o);
     });

@@ -326,6 +326,58 @@ class SelfSimilarity:
         _host_check(lib.sgz_run_selfsimilarity_xml(ctx._h, config.to_xml().encode(), cb, None))
 
 
+class CrossSimilarity:
+    @dataclass
+    class Config:
+        """CrossSimilarity.scala:30-246; XML document <crosssimilarity>."""
+        databaseFolder: str = "database"
+        metaInput1: str = "input1_feat.xml"
+        metaInput2: str = "input2_feat.xml"
+        audioOutput: str = "output.aif"
+        audioOutputType: str = "aiff"
+        span1: Span = Span()
+        span2: Span = Span()
+        temporalWeight: float = 0.5
+        normalize: bool = True
+        maxBoost: float = 8.0
+
+        def to_xml(self) -> str:
+            def sp(tag, s):
+                if s.start is None and s.stop is None:
+                    return ""
+                a = "" if s.start is None else f"<start>{s.start}</start>"
+                b = "" if s.stop is None else f"<stop>{s.stop}</stop>"
+                return f"<{tag}>{a}{b}</{tag}>"
+            return (f"<crosssimilarity><database>{escape(self.databaseFolder)}</database>"
+                    f"<input1>{escape(self.metaInput1)}</input1><input2>{escape(self.metaInput2)}</input2>"
+                    f"<output>{escape(self.audioOutput)}</output><outputType>{escape(self.audioOutputType)}</outputType>"
+                    f"{sp('span1', self.span1)}{sp('span2', self.span2)}<weight>{_f(self.temporalWeight)}</weight>"
+                    f"<normalize>{_b(self.normalize)}</normalize><maxBoost>{_f(self.maxBoost)}</maxBoost>"
+                    f"</crosssimilarity>")
+
+        @staticmethod
+        def from_xml(xml: str) -> "CrossSimilarity.Config":
+            r = ET.fromstring(xml)
+
+            def sp(tag):
+                e = r.find(tag)
+                if e is None:
+                    return Span()
+                a, b = e.find("start"), e.find("stop")
+                return Span(None if a is None else int(a.text), None if b is None else int(b.text))
+            return CrossSimilarity.Config(_text(r, "database"), _text(r, "input1"), _text(r, "input2"),
+                                          _text(r, "output"), _text(r, "outputType"), sp("span1"), sp("span2"),
+                                          float(np.float32(_text(r, "weight"))),
+                                          _text(r, "normalize").strip() == "true",
+                                          float(np.float32(_text(r, "maxBoost"))))
+
+    @staticmethod
+    def run(ctx: Context, config: "CrossSimilarity.Config", observer: Observer = None) -> None:
+        """Writes the similarity curve to config.audioOutput.  Replaces the files of the context's database."""
+        cb = _callback(observer)
+        _host_check(lib.sgz_run_crosssimilarity_xml(ctx._h, config.to_xml().encode(), cb, None))
+
+
 # ---- feature / audio files ------------------------------------------------------
 def write_float_aiff(path: str, frames: np.ndarray, sample_rate: float) -> None:
     a = np.ascontiguousarray(frames, dtype=np.float32)

@@ -169,3 +169,19 @@ def test_read_pcm_aiff_and_wave(tmp_path):
     assert sr == 44100 and np.array_equal(got, pcm.astype(np.float32) / 32768)
     with pytest.raises(P.N.NativeError):
         P.read_audio_file(str(tmp_path / "missing.aif"))
+
+
+def test_crosssimilarity_config_roundtrip():
+    """<crosssimilarity> (CrossSimilarity.scala:182-246): Python mirror and C++ parser / printer agree; open
+    spans are left out of the document."""
+    from strugatzki_amd.processors import CrossSimilarity, Span, roundtrip_native
+    cfgs = [CrossSimilarity.Config(),
+            CrossSimilarity.Config("db & co", "a_feat.xml", "b<1>_feat.xml", "out.aif", "aiff", Span(100, 90000),
+                                   Span(None, 44100), 0.25, False, 3.5),
+            CrossSimilarity.Config(span1=Span(5, None))]
+    for c in cfgs:
+        xml = c.to_xml()
+        assert CrossSimilarity.Config.from_xml(xml) == c
+        back = roundtrip_native("crosssimilarity", xml)
+        assert CrossSimilarity.Config.from_xml(back) == c
+        assert ("<span1>" in back) == (c.span1 != Span()) and ("<span2>" in back) == (c.span2 != Span())

@@ -110,6 +110,35 @@ def test_feature_correlation_errors(ctx, tmp_path):
     assert "aborted" in str(e.value)
 
 
+@pytest.mark.parametrize("swap", [False, True])
+def test_cross_similarity_from_files(ctx, tmp_path, swap):
+    """CrossSimilarity: the similarity curve file against the oracle; either input may be the shorter one."""
+    d = str(tmp_path)
+    long_ = O.synth_file(SEED, 3, 900, NUM_CH)
+    short = O.synth_file(SEED, 4, 400, NUM_CH)
+    short[100:200] = long_[333:433]
+    norms = norms_default()
+    _write_norms(d, norms)
+    m_long, m_short = _write_entry(d, "long", long_), _write_entry(d, "short", short)
+    span_short, span_long = P.Span(95 * STEP, 210 * STEP), P.Span(20 * STEP, None)
+    out = os.path.join(d, "xsim.aif")
+    cfg = P.CrossSimilarity.Config(d, m_long if swap else m_short, m_short if swap else m_long, out, "aiff",
+                                   span_long if swap else span_short, span_short if swap else span_long, 0.5, True,
+                                   8.0)
+    seen = []
+    P.CrossSimilarity.run(ctx, cfg, lambda p: seen.append(p) or True)
+    a0, an = O.crosssim_span(95 * STEP, 210 * STEP, 400, STEP)
+    b0, bn = O.crosssim_span(20 * STEP, None, 900, STEP)
+    want = O.crosssim_run(short[a0:a0 + an], long_[b0:b0 + bn], norms, 0.5, 8.0)
+    got, rate = P.read_audio_file(out)
+    assert got.shape == (len(want), 1) and abs(rate - RATE) < 1e-9
+    np.testing.assert_allclose(got[:, 0], want, rtol=0, atol=1e-5)
+    assert int(np.argmax(got[:, 0])) == int(np.argmax(want))
+    assert seen and seen[-1] == 1.0
+    with pytest.raises(P.N.NativeError):
+        P.CrossSimilarity.run(ctx, P.CrossSimilarity.Config(d, m_short, m_long, out, "wav"))
+
+
 def test_feature_stats(ctx, tmp_path):
     """FeatureStats on the GPU against the oracle: array level (per file and merged) and from files, and the
     norms file it writes is the one the searches read."""

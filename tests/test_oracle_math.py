@@ -181,3 +181,22 @@ def test_feature_stats_percentiles_bracket_the_data():
             lo, hi = np.percentile(x[:, ch], [1, 99])
             spread = x[:, ch].max() - x[:, ch].min()
             assert abs(p[ch, 0] - lo) < 0.02 * spread and abs(p[ch, 1] - hi) < 0.02 * spread
+
+
+def test_crosssim_is_the_correlation_of_the_shorter_span():
+    """CrossSimilarity (impl/CrossSimilarityImpl.scala:92-168, ring = target length): the curve equals the
+    punch-in similarities of FeatureCorrelation with the shorter span as the target; argument order is free."""
+    from common import STEP, corr_config, norms_default, synth_db, synth_target
+    long_ = synth_db(1, 500)[0]
+    short = long_[120:180].copy()
+    norms = norms_default()
+    a = O.crosssim_run(short, long_, norms, 0.5, 8.0)
+    b = O.crosssim_run(long_, short, norms, 0.5, 8.0)
+    assert len(a) == 500 - 60 + 1 and np.array_equal(a, b)
+    assert abs(a[120] - 1.0) < 1e-6 and int(np.argmax(a)) == 120
+    cfg = corr_config(0, 60, num_matches=1)
+    _, sims, _ = O.correlation_run(cfg, short, norms, [long_])
+    assert np.array_equal(a, sims[0])
+    assert O.crosssim_span(None, None, 500, STEP) == (0, 500)
+    assert O.crosssim_span(10 * STEP, 700 * STEP, 500, STEP) == (10, 490)
+    assert O.crosssim_span(900 * STEP, None, 500, STEP) == (500, 0)
