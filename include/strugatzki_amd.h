@@ -132,8 +132,9 @@ SGZ_API int sgz_corr_set_target(sgz_context *ctx, const float *frames, int num_f
 
 /* Number of sliding windows the reference loop visits for database file `file`
  * with the current target (impl/FeatureCorrelationImpl.scala:182-190,242-246):
- * frames - L + 1.  Files shorter than the target have 0 windows here; the
- * reference's single stale-ring window for such files is not reproduced. */
+ * frames - L + 1.  A non-empty file shorter than the target has 1 window, scored
+ * as the reference does over the file's frames followed by what earlier files of
+ * this context left in the L-frame ring (:154, :190-195); an empty file has 0. */
 SGZ_API int64_t sgz_corr_num_windows(const sgz_context *ctx, int file);
 
 /* Computes boost and similarity of every window of files [file_begin, file_end)

@@ -53,6 +53,7 @@ void sgz_destroy(sgz_context *ctx)
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+    for (float *p : ctx->stale_images) (void)hipFree(p);
     for (auto &r : ctx->runs) (void)hipEventDestroy(r.done);
     for (auto &e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);

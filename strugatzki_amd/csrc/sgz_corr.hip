@@ -844,10 +844,54 @@ int build_layout(sgz_context *ctx)
     const long long prepTileFrames = (long long)ctx->prep_cb * kR;
     ctx->cp.prepTileShift = 0;
     while ((1ll << ctx->cp.prepTileShift) < prepTileFrames) ctx->cp.prepTileShift++;
+    // The reference keeps one ring of L frames across all files (impl/FeatureCorrelationImpl.scala:154): a file
+    // with fewer than L frames overwrites the first positions only and is scored once, over its own frames
+    // followed by whatever earlier files left in the rest of the ring (:190-195).  ring[p] = which frame of which
+    // file position p holds (file -1: never written, 0 after normalisation); such a file is given a private
+    // L-frame image assembled from those sources.
+    struct RingSrc {
+        int file;
+        long long frame;
+    };
+    std::vector<RingSrc> ring((size_t)L, RingSrc{-1, 0});
+    for (float *p : ctx->stale_images) SGZ_HIP(ctx, hipFree(p));
+    ctx->stale_images.clear();
     for (int f = 0; f < nf; f++) {
         FileDesc &fd = ctx->h_files[f];
         fd.raw = ctx->files[f].d_raw;
         fd.frames = ctx->files[f].frames;
+        const long long own = fd.frames;
+        if (own > 0 && own < L) {
+            const size_t rowBytes = sizeof(float) * (size_t)ctx->numCh;
+            float *img = nullptr;
+            SGZ_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&img), rowBytes * (size_t)L));
+            ctx->stale_images.push_back(img);
+            SGZ_HIP(ctx, hipMemcpyAsync(img, fd.raw, rowBytes * (size_t)own, hipMemcpyDeviceToDevice, ctx->stream));
+            for (long long p = own; p < L;) {
+                const RingSrc src = ring[(size_t)p];
+                long long q = p + 1;
+                while (q < L && ring[(size_t)q].file == src.file &&
+                       (src.file < 0 || ring[(size_t)q].frame == src.frame + (q - p)))
+                    q++;
+                if (src.file < 0) {  // raw values that normalise to exactly 0
+                    std::vector<float> fill((size_t)(q - p) * ctx->numCh);
+                    for (size_t k = 0; k < fill.size(); k++)
+                        fill[k] = ctx->norm.enabled ? ctx->norm.mn[k % (size_t)ctx->numCh] : 0.0f;
+                    SGZ_HIP(ctx, hipMemcpy(img + p * ctx->numCh, fill.data(), sizeof(float) * fill.size(),
+                                           hipMemcpyHostToDevice));
+                } else {
+                    SGZ_HIP(ctx, hipMemcpyAsync(img + p * ctx->numCh,
+                                                ctx->files[(size_t)src.file].d_raw + src.frame * ctx->numCh,
+                                                rowBytes * (size_t)(q - p), hipMemcpyDeviceToDevice, ctx->stream));
+                }
+                p = q;
+            }
+            fd.raw = img;
+            fd.frames = L;
+            for (long long p = 0; p < own; p++) ring[(size_t)p] = RingSrc{f, p};
+        } else if (own >= L) {
+            for (long long p = 0; p < L; p++) ring[(size_t)p] = RingSrc{f, ((own - 1 - p) / L) * L + p};
+        }
         fd.num_windows = fd.frames >= L ? fd.frames - L + 1 : 0;
         const long long ntiles = (fd.num_windows + kTileW - 1) / kTileW;
         long long M = ntiles * 64 + S + 8;  // slack: staging copies whole 16-byte vectors
@@ -1053,6 +1097,7 @@ int sgz_set_norms(sgz_context *ctx, const float *norms)
         }
     }
     ctx->have_target = false;  // target statistics depend on the norms
+    ctx->layout_dirty = true;  // so do the images of files shorter than the target
     SGZ_HIP(ctx, hipSetDevice(ctx->device));
     SGZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     int rc;
@@ -1167,7 +1212,8 @@ int64_t sgz_corr_num_windows(const sgz_context *ctx, int file)
 {
     if (!ctx || !ctx->have_target || file < 0 || file >= (int)ctx->files.size()) return -1;
     const long long n = ctx->files[file].frames;
-    return n >= ctx->cp.L ? n - ctx->cp.L + 1 : 0;
+    if (n >= ctx->cp.L) return n - ctx->cp.L + 1;
+    return n > 0 ? 1 : 0;  // the single window over the ring's stale contents
 }
 
 enum RunMode { kRunExact = 0, kRunScreenF32 = 1, kRunScreenF16 = 2 };

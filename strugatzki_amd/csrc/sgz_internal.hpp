@@ -113,6 +113,7 @@ struct sgz_context {
     std::vector<int> tile_begin;             // first tile of each file (+ sentinel)
     std::vector<sgz::PrepTile> h_ptiles;
     std::vector<int> ptile_begin;
+    std::vector<float *> stale_images;       // L-frame images of files shorter than the target (see build_layout)
     std::vector<sgz::TileDesc> h_tiles_h;    // tiles of the matrix-core screening kernel
     std::vector<int> tile_h_begin;
     sgz::TileDesc *d_tiles_h = nullptr;
