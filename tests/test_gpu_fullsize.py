@@ -1,0 +1,145 @@
+"""The GPU path at the full sizes of the benchmark configurations, checked through properties that do not
+need the CPU oracle to run at that size (it would take hours): known answers, agreement of independent GPU
+paths, locality, symmetry, and oracle checks on small samples of the big problem."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from common import NUM_CH, SEED, STEP, O, corr_config, norms_default
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config3_search_30s_target_vs_10h_database():
+    """120 files x 300 s, 30 s target, top-10 (the benchmark workload): the planted copies come back in noise
+    order at their offsets, through the search over bounds and through the general path; the bounds of the
+    matrix-core kernel bracket the exact kernel's similarities; a window picked by the search, re-scored, equals
+    the CPU oracle's value for that window."""
+    import bench as B
+    import strugatzki_amd as S
+    from strugatzki_amd import _native as N
+    L, frames, nf, nm = 2584, 25839, 120, 10
+    plant_files = [int(round(j * (nf - 1) / (nm - 1))) for j in range(nm)]
+    plants = B.plant_list(nm, L, plant_files, frames)
+    npl = [N.Plant(p["file"], p["offset"], p["src_file"], p["src_offset"], p["length"], p["amp"], p["gain"])
+           for p in plants]
+    with S.Context(0) as ctx:
+        ctx.db_reset(NUM_CH)
+        for g in range(nf):
+            ctx.db_add_synthetic(B.SEED, g, frames, npl)
+        ctx.set_norms(B.norms_default())
+        with S.Context(0) as c2:
+            c2.db_reset(NUM_CH)
+            c2.db_add_synthetic(B.SEED, B.TARGET_FILE, B.TARGET_START + L + 16, [])
+            tfile = c2.db_read_file(0)
+        target = tfile[B.TARGET_START:B.TARGET_START + L].copy()
+        ctx.corr_set_target(target, 0.5, 8.0)
+        assert ctx.screen_f16_available
+        want = [(p["file"], p["offset"]) for p in plants]
+        fast = S.search(ctx, S.SearchParams(nm, 1, 0, STEP))
+        assert [(m.file, m.start // STEP) for m in fast] == want
+        assert all(m.stop - m.start == L * STEP for m in fast)
+        assert [m.sim for m in fast] == sorted((m.sim for m in fast), reverse=True)
+        general = S.search(ctx, S.SearchParams(nm, 1, 0, STEP, screen_head=False))
+        assert [(m.file, m.start, m.stop, m.sim, m.boost_in) for m in general] == \
+               [(m.file, m.start, m.stop, m.sim, m.boost_in) for m in fast]
+        # bounds vs the exact kernel on three whole files
+        ctx.corr_run_screen_f16(0, 3)
+        up = [ctx.corr_read_dense(f)[0] for f in range(3)]
+        ctx.corr_run(0, 3)
+        for f in range(3):
+            ex = ctx.corr_read_dense(f)[0]
+            assert ex.shape[0] == frames - L + 1
+            d = up[f].astype(np.float64) - ex
+            assert d.min() >= 0.0 and d.max() < 5e-3
+        # one matched window against the oracle (a single window: file cut to L frames)
+        m = fast[3]
+        raw = ctx.db_read_file(m.file)[m.start // STEP:m.start // STEP + L]
+        cfg = corr_config(B.TARGET_START, L, num_matches=1)
+        one, _, _ = O.correlation_run(cfg, tfile, B.norms_default(), [raw], dense=False)
+        assert abs(one[0].sim - m.sim) <= 1.2e-7 and abs(one[0].boost_in - m.boost_in) <= 2e-6 * m.boost_in
+
+
+def test_config5_shape_60s_target():
+    """The 60 s target of the 8-GPU configuration (5168 frames: the staged channel of the matrix-core kernel is
+    twice as large, one workgroup per CU) on a slice of one rank's shard: known answer, and the search over
+    bounds equals the general path."""
+    import bench as B
+    import strugatzki_amd as S
+    from strugatzki_amd import _native as N
+    L, frames, nf, nm = 5168, 25839, 16, 4
+    plants = B.plant_list(nm, L, [1, 6, 11, 15], frames)
+    npl = [N.Plant(p["file"], p["offset"], p["src_file"], p["src_offset"], p["length"], p["amp"], p["gain"])
+           for p in plants]
+    with S.Context(0) as ctx:
+        ctx.db_reset(NUM_CH)
+        for g in range(nf):
+            ctx.db_add_synthetic(B.SEED, g, frames, npl)
+        ctx.set_norms(B.norms_default())
+        with S.Context(0) as c2:
+            c2.db_reset(NUM_CH)
+            c2.db_add_synthetic(B.SEED, B.TARGET_FILE, B.TARGET_START + L + 16, [])
+            target = c2.db_read_file(0)[B.TARGET_START:B.TARGET_START + L].copy()
+        ctx.corr_set_target(target, 0.5, 8.0)
+        assert ctx.screen_f16_available
+        fast = S.search(ctx, S.SearchParams(nm, 1, 0, STEP))
+        assert [(m.file, m.start // STEP) for m in fast] == [(p["file"], p["offset"]) for p in plants]
+        general = S.search(ctx, S.SearchParams(nm, 1, 0, STEP, screen_head=False))
+        exact = S.search(ctx, S.SearchParams(nm, 1, 0, STEP, screen=False))
+        key = lambda ms: [(m.file, m.start, m.stop) for m in ms]
+        assert key(general) == key(fast) == key(exact)
+        assert [m.sim for m in general] == [m.sim for m in fast]
+        assert all(abs(a.sim - b.sim) <= 1e-5 for a, b in zip(exact, fast))
+
+
+def test_config2_extraction_of_one_hour_mono():
+    """1 h of 44.1 kHz mono, fftSize 1024, hop 512, 13 MFCC + loudness: frame count of the reference's framing,
+    finite output, and locality -- the frames of a 20 s excerpt starting on a hop boundary equal the oracle's
+    frames for that excerpt (away from the excerpt's first frames, which see its start)."""
+    import strugatzki_amd as S
+    sr, n = 44100.0, 3600 * 44100
+    rng = np.random.default_rng(7)
+    t = np.arange(n, dtype=np.float32)
+    pcm = (0.25 * np.sin(t * np.float32(2 * np.pi * 220.0 / sr)) * (1.0 + 0.5 * np.sin(t * np.float32(2 * np.pi / sr)))
+           ).astype(np.float32)
+    pcm += (0.05 * rng.standard_normal(n)).astype(np.float32)
+    with S.Context(0) as ctx:
+        feat = ctx.extract(pcm, sr, 1024, 2, 13, 0)
+    assert feat.shape == (-(-n // 512) - 1, 14) and np.isfinite(feat).all()
+    h0, nh = 100_000, 20 * 44100 // 512
+    seg = pcm[h0 * 512:(h0 + nh + 2) * 512]
+    want = O.extract(seg, sr, 1024, 2, 13, 0)
+    k = 4  # frames of the excerpt that depend on samples before its start
+    np.testing.assert_allclose(feat[h0 + k:h0 + nh], want[k:nh], rtol=0, atol=2e-5)
+
+
+def test_config4_self_similarity_of_a_30_minute_file():
+    """30 min of features, full matrix (auto-decimated to at most 0xB504 columns as the reference does): the
+    raster is symmetric about the anti-diagonal layout the reference draws, its diagonal is white (a window
+    equals itself), and a 24 x 24 corner equals the oracle's pixels."""
+    import strugatzki_amd as S
+    frames = int(1800 * 44100 / 512)
+    x = O.synth_file(SEED, 21, frames, NUM_CH)
+    norms = norms_default()
+    cfg = O.SelfSimConfig(0, 0, 0, 0, 44100, 1, 0.5, 0, 1.0, 1.0, 0, 1, STEP, NUM_CH - 1)
+    ext, decim, af_start, num_corrs = O.selfsim_geometry(cfg, frames, frames)
+    assert ext > 30000 and decim >= 2
+    half = O.full_to_feat(44100, STEP)  # halfWinLen, impl/SelfSimilarityImpl.scala:61
+    with S.Context(0) as ctx:
+        _, img = ctx.selfsim(x, None, norms, af_start, half, decim, ext, 0.5, want_sim=False)
+    assert img.shape == (ext, ext)
+    diag = img[ext - 1 - np.arange(ext), np.arange(ext)]
+    assert np.all(diag == 0xFFFFFF)
+    sample = np.random.default_rng(3).integers(0, ext, size=(20000, 2))
+    px, py = sample[:, 0], sample[:, 1]
+    assert np.array_equal(img[ext - 1 - py, px], img[ext - 1 - px, py])
+    # a corner against the oracle: the same geometry cut to the first 24 columns
+    ncut = 24
+    cut = x[:af_start + (ncut - 1) * decim + 2 * half + 8]
+    with S.Context(0) as ctx:
+        _, small = ctx.selfsim(cut, None, norms, af_start, half, decim, ncut, 0.5, want_sim=False)
+    assert np.array_equal(img[ext - ncut:, :ncut], small)
