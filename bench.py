@@ -153,8 +153,8 @@ def main() -> int:
     L = int((int(args.target_seconds * sr + 0.5) + TARGET_START * STEP + STEP // 2) // STEP) - TARGET_START
     frames_per_file = -(-int(args.file_seconds * sr) // STEP) - 1  # ceil(S/step) - 1
     head_n = args.num_matches
-    total_files = head_n + (args.files_per_gpu - head_n) + (world - 1) * args.files_per_gpu if world > 1 \
-        else args.files_per_gpu
+    # weak scaling: every rank holds files_per_gpu files of the database, dealt round robin
+    total_files = world * args.files_per_gpu
     # plants: spread over the whole database, first one inside the head
     plant_files = [int(round(j * (total_files - 1) / max(args.num_matches - 1, 1))) for j in range(args.num_matches)]
     plants = plant_list(args.num_matches, L, plant_files, frames_per_file)
@@ -164,8 +164,9 @@ def main() -> int:
     ctx = S.Context(local_rank)
     ctx.db_reset(NUM_CH)
     if world > 1:
-        head_global = list(range(head_n))
-        tail_global = shard_files(total_files, head_n, rank, world)
+        # numPerFile = 1: no file needs to be replicated (every rank finds the exact maxima of its own files)
+        head_global = []
+        tail_global = [g for g in range(total_files) if g % world == rank]
     else:
         head_global = list(range(min(head_n, total_files)))
         tail_global = list(range(len(head_global), total_files))
@@ -268,7 +269,8 @@ def main() -> int:
                             f"normalize, maxBoost 8",
                 "windows": unique_windows,
                 "files": total_files,
-                "sharding": "by file, head files replicated" if world > 1 else "none",
+                "sharding": "by file, round robin, nothing replicated; one all-gather of per-file candidates"
+                            if world > 1 else "none",
             },
             "roofline": {
                 "bound": "mfma",

@@ -187,6 +187,8 @@ def exchange_candidates(rec, cnt, capacity: int, group=None) -> np.ndarray | Non
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
+    if rec.is_cuda and dist.get_backend(group) == "gloo":  # gloo gathers host tensors only
+        rec, cnt = rec.cpu(), cnt.cpu()
     recs = [torch.empty_like(rec) for _ in range(world)]
     cnts = [torch.empty_like(cnt) for _ in range(world)]
     dist.all_gather(cnts, cnt, group=group)
@@ -253,6 +255,41 @@ def _sharded_over_bounds(ctx: Context, p: SearchParams, local_to_global: Sequenc
         sel.close()
 
 
+def _sharded_exact_maxima(ctx: Context, p: SearchParams, local_to_global: Sequence[int], num_files_total: int,
+                           group=None) -> list[N.Match]:
+    """numPerFile = 1 without the half-precision kernel's help: every rank runs the exact kernel over its own
+    files, takes the first-occurrence maximum of each (dense read-back) and the ranks exchange those."""
+    import torch
+
+    nloc = ctx.num_files
+    ctx.corr_run(0, nloc)
+    dense = ctx.corr_read_dense_range(0, nloc) if nloc else []
+    rows = []
+    for f, (sim, boost) in enumerate(dense):
+        if len(sim) == 0:
+            continue
+        if np.isnan(sim).any():
+            raise RuntimeError("NaN similarities: the sharded search needs replicated head files for this database")
+        o = int(np.argmax(sim))  # first occurrence
+        rows.append((local_to_global[f], o, sim[o], boost[o]))
+    rec_h = np.zeros(max(p.capacity, 1), dtype=N.CANDIDATE_DTYPE)
+    rec_h[: len(rows)] = np.array(rows, dtype=N.CANDIDATE_DTYPE) if rows else rec_h[:0]
+    dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+    rec = torch.from_numpy(rec_h.view(np.int32).reshape(-1, 4).copy()).to(dev)
+    cnt = torch.tensor([len(rows)], dtype=torch.int64, device=dev)
+    cands = exchange_candidates(rec, cnt, p.capacity, group)
+    if cands is None:
+        raise RuntimeError(f"candidate buffer overflow (> {p.capacity}); raise SearchParams.capacity")
+    sel = Selector(p.num_matches, p.num_per_file, p.min_spacing, p.step_size, ctx.target_frames)
+    try:
+        # files without windows contribute nothing: feed file by file instead of sgz_sel_feed_screened
+        for g, part in iter_files(cands):
+            sel.feed_candidates(g, part["offset"], part["sim"], part["boost"])
+        return sel.result()
+    finally:
+        sel.close()
+
+
 def search_sharded(ctx: Context, p: SearchParams, head_global: Sequence[int], tail_global: Sequence[int],
                    group=None, num_files_total: int | None = None) -> list[N.Match]:
     """Multi-process search, one process per GPU.  The context holds the head
@@ -268,6 +305,11 @@ def search_sharded(ctx: Context, p: SearchParams, head_global: Sequence[int], ta
         out = _sharded_over_bounds(ctx, p, list(head_global) + list(tail_global), num_files_total, group)
         if out is not None:  # every rank holds the same candidates, so all ranks agree on this
             return out
+    if nh == 0 and num_files_total is not None and num_files_total > 0:
+        # no replicated head files to derive a common threshold from
+        if p.num_per_file != 1:
+            raise RuntimeError("a sharded search with numPerFile > 1 needs replicated head files")
+        return _sharded_exact_maxima(ctx, p, list(tail_global), num_files_total, group)
     sel = Selector(p.num_matches, p.num_per_file, p.min_spacing, p.step_size, ctx.target_frames)
     ctx.corr_run(0, nh)
     margin = p.margin if p.margin is not None or not p.screen else MARGIN[mode]

@@ -1,6 +1,8 @@
 """One rank of the sharded search on a real GPU (started by test_gpu_correlation.py as a child process:
 torch has to initialise the GPU before the library does, which a shared pytest process cannot guarantee).
-Prints the matches as JSON."""
+usage: sharded_rank.py PORT MODE RANK WORLD BACKEND
+MODE: "bounds" (search over bounds), "general" (replicated head files, screen_head off), "exact" (no
+replicated files, no screening).  Every rank prints the matches as one JSON line."""
 import json
 import os
 import sys
@@ -17,23 +19,30 @@ from common import STEP, make_plants, norms_default, synth_db, synth_target  # n
 
 import strugatzki_amd as S  # noqa: E402
 
+CASE = dict(L=96, ts=17, nf=14, frames=900, num_matches=4, nplants=5)
+
 
 def main() -> int:
-    port, screen_head = int(sys.argv[1]), sys.argv[2] == "1"
-    L, ts, nf, frames, num_matches = 96, 17, 14, 900, 4
-    db = synth_db(nf, frames, make_plants(5, L, nf, frames, ts))
-    tgt = synth_target(ts, L)
+    port, mode, rank, world, backend = int(sys.argv[1]), sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+    q = CASE
+    db = synth_db(q["nf"], q["frames"], make_plants(q["nplants"], q["L"], q["nf"], q["frames"], q["ts"]))
+    tgt = synth_target(q["ts"], q["L"])
+    if mode == "general":  # head files on every rank, the rest dealt round robin
+        head = list(range(q["num_matches"]))
+        tail = [g for g in range(q["num_matches"], q["nf"]) if (g - q["num_matches"]) % world == rank]
+    else:                  # nothing replicated
+        head, tail = [], [g for g in range(q["nf"]) if g % world == rank]
     ctx = S.Context(0)
     ctx.db_reset(db[0].shape[1])
-    for f in db:
-        ctx.db_add_file(f)
+    for g in head + tail:
+        ctx.db_add_file(db[g])
     ctx.set_norms(norms_default())
-    ctx.corr_set_target(tgt[ts:ts + L], 0.5, 8.0)
-    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
-                            device_id=torch.device("cuda", 0))
+    ctx.corr_set_target(tgt[q["ts"]:q["ts"] + q["L"]], 0.5, 8.0)
+    kw = dict(device_id=torch.device("cuda", 0)) if backend == "nccl" else {}
+    dist.init_process_group(backend, init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, **kw)
     try:
-        p = S.SearchParams(num_matches, 1, 0, STEP, screen_head=screen_head)
-        got = S.search_sharded(ctx, p, list(range(num_matches)), list(range(num_matches, nf)), num_files_total=nf)
+        p = S.SearchParams(q["num_matches"], 1, 0, STEP, screen=mode != "exact", screen_head=mode == "bounds")
+        got = S.search_sharded(ctx, p, head, tail, num_files_total=q["nf"])
     finally:
         dist.destroy_process_group()
     print(json.dumps([[m.file, m.start, m.stop, float(m.sim)] for m in got]))

@@ -234,32 +234,57 @@ def test_search_over_bounds_and_its_fallbacks(ctx, case):
         assert abs(g.sim - w.sim) <= 1.2e-7
 
 
-@pytest.mark.parametrize("screen_head", [True, False])
-def test_search_sharded_single_rank_rccl(screen_head):
-    """The multi-GPU entry point with a one-rank RCCL group: candidate buffers on the GPU, one all-gather.
-    Runs tests/sharded_rank.py as a child process (same workload as below)."""
+def _run_ranks(mode, world, backend):
     import json
     import os
     import socket
     import subprocess
     import sys
-    L, ts, nf, frames, num_matches = 96, 17, 14, 900, 4
-    db = synth_db(nf, frames, make_plants(5, L, nf, frames, ts))
-    tgt = synth_target(ts, L)
-    want, _, _ = O.correlation_run(corr_config(ts, L, num_matches=num_matches, num_per_file=1), tgt, norms_default(),
-                                   db, dense=False)
     sock = socket.socket()
     sock.bind(("127.0.0.1", 0))
     port = sock.getsockname()[1]
     sock.close()
     script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "sharded_rank.py")
-    res = subprocess.run([sys.executable, script, str(port), "1" if screen_head else "0"], capture_output=True,
-                         text=True, timeout=110)
-    assert res.returncode == 0, res.stderr[-2000:]
-    got = json.loads(res.stdout.strip().splitlines()[-1])
+    procs = [subprocess.Popen([sys.executable, script, str(port), mode, str(r), str(world), backend],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    outs = []
+    for pr in procs:
+        out, err = pr.communicate(timeout=110)
+        assert pr.returncode == 0, err[-2000:]
+        outs.append(json.loads(out.strip().splitlines()[-1]))
+    return outs
+
+
+def _sharded_want():
+    q = dict(L=96, ts=17, nf=14, frames=900, num_matches=4, nplants=5)  # CASE of tests/sharded_rank.py
+    db = synth_db(q["nf"], q["frames"], make_plants(q["nplants"], q["L"], q["nf"], q["frames"], q["ts"]))
+    tgt = synth_target(q["ts"], q["L"])
+    want, _, _ = O.correlation_run(corr_config(q["ts"], q["L"], num_matches=q["num_matches"], num_per_file=1), tgt,
+                                   norms_default(), db, dense=False)
+    return want
+
+
+@pytest.mark.parametrize("mode", ["bounds", "general"])
+def test_search_sharded_single_rank_rccl(mode):
+    """The multi-GPU entry point with a one-rank RCCL group: candidate buffers on the GPU, one all-gather.
+    Runs tests/sharded_rank.py as a child process."""
+    want = _sharded_want()
+    (got,) = _run_ranks(mode, 1, "nccl")
     assert [(g[0], g[1], g[2]) for g in got] == [(w.file, w.start, w.stop) for w in want]
     for g, w in zip(got, want):
         assert abs(g[3] - w.sim) <= 1.2e-7
+
+
+@pytest.mark.parametrize("mode", ["bounds", "general", "exact"])
+def test_search_sharded_two_ranks_on_one_gpu(mode):
+    """Two ranks (two processes sharing the one GPU of the box, gloo for the exchange): both end with the
+    single-process result, with and without replicated head files."""
+    want = _sharded_want()
+    outs = _run_ranks(mode, 2, "gloo")
+    assert outs[0] == outs[1]
+    assert [(g[0], g[1], g[2]) for g in outs[0]] == [(w.file, w.start, w.stop) for w in want]
+    for g, w in zip(outs[0], want):
+        assert abs(g[3] - w.sim) <= (1e-5 if mode == "exact" else 1.2e-7)
 
 
 @pytest.mark.parametrize("num_matches,num_per_file,min_spacing,min_punch,max_punch",
