@@ -124,6 +124,8 @@ def main() -> int:
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget; 0 disables")
     ap.add_argument("--exact-only", action="store_true",
                     help="fp64 kernel for every file (no screening + re-scoring)")
+    ap.add_argument("--sharded", action="store_true",
+                    help="take the multi-GPU code path (RCCL group, candidate exchange) even with one rank")
     ap.add_argument("--screen-mode", choices=["auto", "f16", "f32"], default="auto",
                     help="screening kernel: half-precision matrix-core kernel (f16) or fp32-product kernel (f32)")
     args = ap.parse_args()
@@ -146,7 +148,13 @@ def main() -> int:
         print("bench.py needs a GPU (no CPU fallback)", file=sys.stderr)
         return 2
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    sharded = world > 1 or args.sharded
+    if sharded:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     sr = 44100.0
@@ -163,7 +171,7 @@ def main() -> int:
 
     ctx = S.Context(local_rank)
     ctx.db_reset(NUM_CH)
-    if world > 1:
+    if sharded:
         # numPerFile = 1: no file needs to be replicated (every rank finds the exact maxima of its own files)
         head_global = []
         tail_global = [g for g in range(total_files) if g % world == rank]
@@ -187,12 +195,12 @@ def main() -> int:
     unique_windows = total_files * (frames_per_file - L + 1)
 
     def step():
-        if world > 1:
+        if sharded:
             return S.search_sharded(ctx, params, head_global, tail_global, num_files_total=total_files)
         return S.search(ctx, params)
 
     def sync():
-        if world > 1:
+        if sharded:
             dist.barrier()
         torch.cuda.synchronize()
         ctx.synchronize()
@@ -293,7 +301,7 @@ def main() -> int:
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     ctx.close()
-    if world > 1:
+    if sharded:
         dist.barrier()
         dist.destroy_process_group()
     return 0 if verified else 1

@@ -89,6 +89,9 @@ SGZ_API int sgz_create(int device, void *hip_stream, sgz_context **out);
 SGZ_API void sgz_destroy(sgz_context *ctx);
 SGZ_API const char *sgz_last_error(const sgz_context *ctx);
 SGZ_API const char *sgz_version(void);
+/* The HIP stream (hipStream_t) the context queues its kernels on, for callers that want to order their own
+ * device work (copies, collectives) after the library's without a host synchronisation. */
+SGZ_API void *sgz_get_stream(sgz_context *ctx);
 /* Blocks until everything queued on the context's stream has finished. */
 SGZ_API int sgz_synchronize(sgz_context *ctx);
 

@@ -79,6 +79,7 @@ SIGNATURES = {
     "sgz_corr_num_windows": (C.c_int64, [_vp, C.c_int]),
     "sgz_corr_run": (C.c_int, [_vp, C.c_int, C.c_int]),
     "sgz_corr_run_screen": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "sgz_get_stream": (C.c_void_p, [_vp]),
     "sgz_feature_stats": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
     "sgz_run_feature_stats": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int, _vp]),
     "sgz_write_norms_file": (C.c_int, [C.c_char_p, _vp, C.c_int]),

@@ -66,6 +66,8 @@ void sgz_destroy(sgz_context *ctx)
 
 const char *sgz_last_error(const sgz_context *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
+void *sgz_get_stream(sgz_context *ctx) { return ctx ? reinterpret_cast<void *>(ctx->stream) : nullptr; }
+
 int sgz_synchronize(sgz_context *ctx)
 {
     if (!ctx) return SGZ_E_ARG;

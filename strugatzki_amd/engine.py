@@ -186,6 +186,11 @@ class Context:
         self._check(lib.sgz_corr_last_work(self._h, C.byref(w), C.byref(f)))
         return w.value, f.value
 
+    @property
+    def stream_handle(self) -> int:
+        """hipStream_t of the context (0 = the null stream), e.g. for torch.cuda.ExternalStream."""
+        return int(lib.sgz_get_stream(self._h) or 0)
+
     def synchronize(self) -> None:
         self._check(lib.sgz_synchronize(self._h))
 

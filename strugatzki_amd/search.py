@@ -199,12 +199,7 @@ def exchange_candidates(rec, cnt, capacity: int, group=None) -> np.ndarray | Non
     parts = [recs[r][: counts[r]].cpu().numpy() for r in range(world)]
     allc = np.concatenate(parts, axis=0) if parts else np.zeros((0, 4), np.int32)
     cands = np.ascontiguousarray(allc, dtype=np.int32).view(N.CANDIDATE_DTYPE).reshape(-1)
-    order = np.lexsort((cands["offset"], cands["file"]))
-    cands = cands[order]
-    if len(cands) > 1:  # replicated files: every rank computed the same record
-        keep = np.ones(len(cands), dtype=bool)
-        keep[1:] = (cands["file"][1:] != cands["file"][:-1]) | (cands["offset"][1:] != cands["offset"][:-1])
-        cands = cands[keep]
+    cands = _sort_candidates(cands)
     return cands
 
 
@@ -233,21 +228,112 @@ def _to_global_ids(rec, cnt, cap: int, local_to_global: Sequence[int], dev) -> N
         rec[:n_local, 0] = lut[rec[:n_local, 0].long()]
 
 
+_EXCHANGE_ROWS = 4095  # candidate rows that travel in the first (usually only) all-gather, plus one header row
+
+
+def _sort_candidates(cands: np.ndarray) -> np.ndarray:
+    """(file, offset) order, records that several ranks hold (replicated files) once."""
+    if len(cands) > 1:
+        key = (cands["file"].astype(np.int64) << 32) | cands["offset"].astype(np.int64)
+        order = np.argsort(key, kind="stable")
+        cands, key = cands[order], key[order]
+        keep = np.ones(len(cands), dtype=bool)
+        keep[1:] = key[1:] != key[:-1]
+        if not keep.all():
+            cands = cands[keep]
+    return cands
+
+
+def _rank_maps(ctx: Context, local_to_global: Sequence[int], group) -> list[np.ndarray]:
+    """local index -> global file id of every rank (gathered once per placement, kept on the context)."""
+    import torch
+    import torch.distributed as dist
+
+    key = (tuple(local_to_global), id(group))
+    cache = ctx.__dict__.setdefault("_rank_maps", {})
+    if key not in cache:
+        world = dist.get_world_size(group)
+        on_gpu = dist.get_backend(group) != "gloo"
+        dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+        n = torch.tensor([len(local_to_global)], dtype=torch.int64, device=dev)
+        ns = [torch.empty_like(n) for _ in range(world)]
+        dist.all_gather(ns, n, group=group)
+        width = max(int(x.item()) for x in ns)
+        mine = torch.full((max(width, 1),), -1, dtype=torch.int32, device=dev)
+        mine[: len(local_to_global)] = torch.tensor(list(local_to_global), dtype=torch.int32, device=dev)
+        maps = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(maps, mine, group=group)
+        cache.clear()
+        cache[key] = [m.cpu().numpy()[: int(k.item())] for m, k in zip(maps, ns)]
+    return cache[key]
+
+
+def _exchange_buffers(ctx: Context, cap: int, world: int, on_gpu: bool):
+    """[header + cap records] of this rank and the gather target, kept on the context between searches."""
+    import torch
+
+    key = (cap, world, on_gpu)
+    cache = ctx.__dict__.setdefault("_exchange_buffers", {})
+    if key not in cache:
+        dev = torch.device("cuda", torch.cuda.current_device())
+        rec = torch.zeros((cap + 1, 4), dtype=torch.int32, device=dev)
+        rows = min(cap, _EXCHANGE_ROWS) + 1
+        gathered = torch.zeros((world * rows, 4), dtype=torch.int32, device=dev if on_gpu else torch.device("cpu"))
+        host = torch.zeros((world * rows, 4), dtype=torch.int32).pin_memory() if on_gpu else gathered
+        torch.cuda.current_stream().synchronize()
+        cache.clear()
+        cache[key] = dict(rec=rec, send=rec[:rows], gathered=gathered, host=host, rows=rows,
+                          count_ptr=rec.data_ptr(), rec_ptr=rec[1:].data_ptr(),
+                          view=host.numpy().reshape(world, rows, 4))
+    return cache[key]
+
+
 def _sharded_over_bounds(ctx: Context, p: SearchParams, local_to_global: Sequence[int], num_files_total: int,
                          group=None) -> list[N.Match] | None:
     """numPerFile = 1 (see _search_over_bounds): every rank finds the exact maxima of its own files, the
-    ranks exchange them and replay the selection over all files in global order."""
+    ranks exchange them (one all-gather of the first 4095 records + a header holding the count; a second,
+    full one only if some rank has more) and replay the selection over all files in global order."""
+    import torch
+    import torch.distributed as dist
+
     nloc = ctx.num_files
     cap = p.capacity
+    world = dist.get_world_size(group)
+    on_gpu = dist.get_backend(group) != "gloo"
+    maps = _rank_maps(ctx, local_to_global, group)
+    b = _exchange_buffers(ctx, cap, world, on_gpu)
+    rec, rows = b["rec"], b["rows"]
     ctx.corr_run_screen_f16(0, nloc)
-    rec, cnt, dev = _device_buffers(cap)
-    ctx.corr_compact_bounded_device(0, nloc, nloc, rec.data_ptr(), cap, cnt.data_ptr())
-    ctx.corr_rescore_device(rec.data_ptr(), cap, cnt.data_ptr())
+    # row 0 = header (the count, written by the library), rows 1.. = records
+    ctx.corr_compact_bounded_device(0, nloc, nloc, b["rec_ptr"], cap, b["count_ptr"])
+    ctx.corr_rescore_device(b["rec_ptr"], cap, b["count_ptr"])
+    # (The collective runs on torch's stream after a host-side wait for the library's stream.  Queuing it on the
+    # library's stream through torch.cuda.ExternalStream saves that wait, but leaves torch and RCCL holding a
+    # stream the context destroys: the process then crashes on exit.)
     ctx.synchronize()
-    _to_global_ids(rec, cnt, cap, local_to_global, dev)
-    cands = exchange_candidates(rec, cnt, cap, group)
-    if cands is None:
-        return None
+    if on_gpu:
+        dist.all_gather_into_tensor(b["gathered"], b["send"], group=group)
+        b["host"].copy_(b["gathered"], non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+    else:
+        dist.all_gather_into_tensor(b["gathered"], b["send"].cpu(), group=group)
+    h = b["view"]
+    counts = h[:, 0, :2].copy().view(np.int64).reshape(world)
+    if (counts > cap).any():
+        return None  # every rank sees the overflow
+    if (counts > rows - 1).any():  # rare: some rank has more records than the first exchange carries
+        full = [torch.empty_like(rec) for _ in range(world)] if on_gpu else [torch.empty((cap + 1, 4), dtype=torch.int32)
+                                                                             for _ in range(world)]
+        dist.all_gather(full, rec if on_gpu else rec.cpu(), group=group)
+        parts = [full[r][1: 1 + int(counts[r])].cpu().numpy() for r in range(world)]
+    else:
+        parts = [h[r, 1: 1 + int(counts[r])] for r in range(world)]
+    out = []
+    for r, part in enumerate(parts):
+        c = np.ascontiguousarray(part, dtype=np.int32).view(N.CANDIDATE_DTYPE).reshape(-1).copy()
+        c["file"] = maps[r][c["file"]]
+        out.append(c)
+    cands = _sort_candidates(np.concatenate(out) if out else np.zeros(0, N.CANDIDATE_DTYPE))
     sel = Selector(p.num_matches, p.num_per_file, p.min_spacing, p.step_size, ctx.target_frames)
     try:
         return sel.result() if sel.feed_screened(cands, num_files_total, num_files_total) else None
