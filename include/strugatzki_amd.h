@@ -265,6 +265,26 @@ SGZ_API int sgz_sel_feed_file_punch(sgz_selector *sel, int file, int64_t num_fra
  * file that occurs in it, in ascending file order (files without candidates
  * need no call: nothing of theirs could pass the gate). */
 SGZ_API int sgz_sel_feed_candidates(sgz_selector *sel, const sgz_candidate *cands, int64_t n);
+/* Screening modes of sgz_corr_search. */
+#define SGZ_SCREEN_NONE 0 /* exact fp64 kernel for every file */
+#define SGZ_SCREEN_F32 1  /* sgz_corr_run_screen for the tail files */
+#define SGZ_SCREEN_F16 2  /* sgz_corr_run_screen_f16 (SGZ_E_STATE where it is not available) */
+#define SGZ_SCREEN_AUTO 3 /* F16 where available, else F32 */
+
+/* One whole search over the files of the context with the current target (target_frames = its length):
+ * the loop over database files of impl/FeatureCorrelationImpl.scala:152-246 and the final ordering
+ * :399-411, without punch-out.  over_bounds != 0 lets numPerFile = 1 searches take the route of
+ * sgz_corr_compact_bounded / sgz_sel_feed_screened (all files through the matrix-core kernel); everything
+ * else, and every case that route cannot decide, goes: exact kernel + dense replay for the first
+ * numMatches files, screening + threshold compaction + exact re-scoring for the rest, dense exact replay on
+ * a candidate overflow.  matches_out receives at most min(out_capacity, num_matches) records in descending
+ * similarity; file = index in the context.  `capacity` = candidate records fetched from the GPU at most.
+ * `margin`: screened windows with sim > bound - margin are re-scored; negative = the default of the mode
+ * (1e-5 for F32, many times its largest observed error; 1e-6 for F16, whose kernel writes upper bounds). */
+SGZ_API int sgz_corr_search(sgz_context *ctx, int target_frames, int num_matches, int num_per_file,
+                            int64_t min_spacing, int step_size, int screen_mode, int over_bounds, int64_t capacity,
+                            float margin, sgz_match *matches_out, int out_capacity, int *count_out);
+
 /* Feeds the exactly re-scored candidates of sgz_corr_compact_bounded (sorted by
  * (file, offset), files 0 .. num_files-1, the first head_files of them head
  * files): per head file its largest similarity, first occurrence, then the

@@ -20,6 +20,7 @@ SGZ_E_STATE = -3
 SGZ_E_OVERFLOW = -4
 SGZ_E_IO = -5
 SGZ_MAX_CHANNELS = 64
+SGZ_SCREEN_NONE, SGZ_SCREEN_F32, SGZ_SCREEN_F16, SGZ_SCREEN_AUTO = 0, 1, 2, 3
 
 
 class Candidate(C.Structure):
@@ -80,6 +81,8 @@ SIGNATURES = {
     "sgz_corr_run": (C.c_int, [_vp, C.c_int, C.c_int]),
     "sgz_corr_run_screen": (C.c_int, [_vp, C.c_int, C.c_int]),
     "sgz_get_stream": (C.c_void_p, [_vp]),
+    "sgz_corr_search": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int64,
+                                  C.c_float, _vp, C.c_int, _vp]),
     "sgz_feature_stats": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
     "sgz_run_feature_stats": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int, _vp]),
     "sgz_write_norms_file": (C.c_int, [C.c_char_p, _vp, C.c_int]),

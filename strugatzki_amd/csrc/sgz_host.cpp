@@ -178,17 +178,15 @@ std::vector<Match> runFeatureCorrelation(sgz_context *ctx, const FeatureCorrelat
         sgz_selector *s;
         ~SelGuard() { sgz_sel_destroy(s); }
     } guard{sel};
-    auto collect = [&]() {
-        std::vector<sgz_match> raw((size_t)std::max(cfg.numMatches, 1));
-        const int n = sgz_sel_result(sel, raw.data(), cfg.numMatches);
+    auto toMatches = [&](const std::vector<sgz_match> &raw, int n) {
         std::vector<Match> out;
         for (int i = 0; i < n; i++) {
             Match m;
-            m.sim = raw[i].sim;
-            m.file = extrDBs[(size_t)dbIndex[(size_t)raw[i].file]].audioInput;  // :237
-            m.punch = Span::of(raw[i].start, raw[i].stop);
-            m.boostIn = raw[i].boost_in;
-            m.boostOut = raw[i].boost_out;
+            m.sim = raw[(size_t)i].sim;
+            m.file = extrDBs[(size_t)dbIndex[(size_t)raw[(size_t)i].file]].audioInput;  // :237
+            m.punch = Span::of(raw[(size_t)i].start, raw[(size_t)i].stop);
+            m.boostIn = raw[(size_t)i].boost_in;
+            m.boostOut = raw[(size_t)i].boost_out;
             out.push_back(m);
         }
         return out;
@@ -229,88 +227,19 @@ std::vector<Match> runFeatureCorrelation(sgz_context *ctx, const FeatureCorrelat
             if (rc != SGZ_OK) throw Error(rc, "selector rejected its input");
         }
         checkAborted(obs, 1.0);
-        return collect();
+        std::vector<sgz_match> raw((size_t)std::max(cfg.numMatches, 1));
+        const int n = sgz_sel_result(sel, raw.data(), cfg.numMatches);
+        return toMatches(raw, n);
     }
 
-    // GPU: all similarities; host: replay of the match bookkeeping in file order.
-    const bool f16 = sgz_corr_screen_f16_available(ctx) == 1;
-    const int64_t cap = 1 << 16;
-    std::vector<sgz_candidate> cands;
-    bool done = false;
-    if (f16 && cfg.numPerFile == 1 && cfg.numMatches >= 1 && nf > 0) {
-        // numPerFile = 1: a file can only contribute its largest similarity, first occurrence.  All files go
-        // through the half-precision kernel; per file the windows whose upper bound reaches the file's largest
-        // lower bound are re-scored exactly and the exact maxima are fed in file order.
-        cands.resize((size_t)cap);
-        int64_t count = 0;
-        check(ctx, sgz_corr_run_screen_f16(ctx, 0, nf));
-        const int rc = sgz_corr_compact_bounded(ctx, 0, nf, nf, cands.data(), cap, &count);
-        if (rc != SGZ_E_OVERFLOW) {
-            check(ctx, rc);
-            sgz_selector *quick = sgz_sel_create(cfg.numMatches, cfg.numPerFile, cfg.minSpacing, stepSize, L);
-            if (!quick) throw Error(SGZ_E_ARG, "illegal selection parameters");
-            const int frc = sgz_sel_feed_screened(quick, cands.data(), count, nf, nf);
-            if (frc == SGZ_OK) {
-                sgz_sel_destroy(guard.s);
-                guard.s = sel = quick;
-                done = true;
-            } else {
-                sgz_sel_destroy(quick);
-                if (frc != SGZ_E_STATE) throw Error(frc, "selector rejected its input");
-            }
-        }
-    }
-    // General case.  Head files: exact fp64 kernel, fed densely.  Tail files: a screening kernel (half-precision
-    // matrix-core kernel, which writes upper bounds, or fp32 products); the windows within `margin` of the bound
-    // are re-scored exactly on the GPU before they are fed.
-    const int head = done ? nf : std::min(nf, std::max(cfg.numMatches, 1));
-    const float margin = f16 ? 1e-6f : 1e-5f;
-    bool screened = head < nf;
-    if (!done) check(ctx, sgz_corr_run(ctx, 0, head));
-    if (head < nf) check(ctx, f16 ? sgz_corr_run_screen_f16(ctx, head, nf) : sgz_corr_run_screen(ctx, head, nf));
-    std::vector<float> sim, boost;
-    auto feedDense = [&](int f0, int f1) {
-        int64_t total = 0;
-        for (int f = f0; f < f1; f++) total += sgz_corr_num_windows(ctx, f);
-        sim.resize((size_t)total);
-        boost.resize((size_t)total);
-        check(ctx, sgz_corr_read_dense_range(ctx, f0, f1, sim.data(), boost.data()));
-        size_t pos = 0;
-        for (int f = f0; f < f1; f++) {
-            const int64_t n = sgz_corr_num_windows(ctx, f);
-            if (sgz_sel_feed_file(sel, f, n, nullptr, sim.data() + pos, boost.data() + pos) != SGZ_OK)
-                throw Error(SGZ_E_ARG, "selector rejected its input");
-            pos += (size_t)n;
-        }
-    };
-    if (!done) feedDense(0, head);
+    // GPU: all similarities; host: replay of the match bookkeeping in file order (sgz_search.cpp)
     checkAborted(obs, 0.6);
-    int f = head;
-    if (f < nf && !sgz_sel_is_full(sel) && screened) {  // dense feeding needs exact values
-        check(ctx, sgz_corr_run(ctx, f, nf));
-        screened = false;
-    }
-    while (f < nf && !sgz_sel_is_full(sel)) {
-        feedDense(f, f + 1);
-        f++;
-    }
-    if (f < nf) {
-        cands.resize((size_t)cap);
-        int64_t count = 0;
-        const int rc = screened ? sgz_corr_compact_rescored(ctx, f, nf, sgz_sel_threshold(sel) - margin, cands.data(),
-                                                            cap, &count)
-                                : sgz_corr_compact(ctx, f, nf, sgz_sel_threshold(sel), cands.data(), cap, &count);
-        if (rc == SGZ_E_OVERFLOW) {
-            if (screened) check(ctx, sgz_corr_run(ctx, f, nf));
-            for (int g = f; g < nf; g++) feedDense(g, g + 1);
-        } else {
-            check(ctx, rc);
-            if (sgz_sel_feed_candidates(sel, cands.data(), count) != SGZ_OK)
-                throw Error(SGZ_E_ARG, "selector rejected its input");
-        }
-    }
+    std::vector<sgz_match> raw((size_t)std::max(cfg.numMatches, 1));
+    int n = 0;
+    check(ctx, sgz_corr_search(ctx, L, cfg.numMatches, cfg.numPerFile, cfg.minSpacing, stepSize, SGZ_SCREEN_AUTO, 1,
+                               1 << 16, -1.0f, raw.data(), cfg.numMatches, &n));
     checkAborted(obs, 1.0);
-    return collect();
+    return toMatches(raw, n);
 }
 
 // -----------------------------------------------------------------------------

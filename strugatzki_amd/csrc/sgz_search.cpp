@@ -1,0 +1,118 @@
+// sgz_corr_search: one database search over all files of a context -- GPU similarities, then the host-side
+// replay of the reference's match bookkeeping in file order (impl/FeatureCorrelationImpl.scala:113-150, 234,
+// 399-411) -- as one call through the fine-grained entry points of strugatzki_amd.h.
+#include <algorithm>
+#include <cstdint>
+#include <vector>
+
+#include "strugatzki_amd.h"
+
+namespace {
+
+struct SelGuard {
+    sgz_selector *s;
+    ~SelGuard() { sgz_sel_destroy(s); }
+};
+
+}  // namespace
+
+extern "C" int sgz_corr_search(sgz_context *ctx, int target_frames, int num_matches, int num_per_file,
+                               int64_t min_spacing, int step_size, int screen_mode, int over_bounds, int64_t capacity,
+                               float margin, sgz_match *matches_out, int out_capacity, int *count_out)
+{
+    if (!ctx || !count_out || out_capacity < 0 || (out_capacity > 0 && !matches_out) || capacity < 1) return SGZ_E_ARG;
+    if (screen_mode < SGZ_SCREEN_NONE || screen_mode > SGZ_SCREEN_AUTO) return SGZ_E_ARG;
+    *count_out = 0;
+    const int nf = sgz_db_num_files(ctx);
+    bool f16 = false;
+    if (screen_mode == SGZ_SCREEN_F16 || screen_mode == SGZ_SCREEN_AUTO) f16 = sgz_corr_screen_f16_available(ctx) == 1;
+    if (screen_mode == SGZ_SCREEN_F16 && !f16) return SGZ_E_STATE;
+    const bool screen = screen_mode != SGZ_SCREEN_NONE;
+    int rc;
+    // candidate records fetched from the GPU; kept between calls (a fresh megabyte per search costs more
+    // in page faults than the replay itself)
+    static thread_local std::vector<sgz_candidate> cands;
+
+    // numPerFile = 1: a file can only contribute its largest similarity, first occurrence.  All files go through
+    // the half-precision kernel; per file the windows whose upper bound reaches the file's largest lower bound
+    // are re-scored exactly and the exact maxima are fed in file order.
+    if (over_bounds && f16 && num_per_file == 1 && num_matches >= 1 && nf > 0) {
+        if (cands.size() < (size_t)capacity) cands.resize((size_t)capacity);
+        int64_t n = 0;
+        if ((rc = sgz_corr_run_screen_f16(ctx, 0, nf))) return rc;
+        rc = sgz_corr_compact_bounded(ctx, 0, nf, nf, cands.data(), capacity, &n);
+        if (rc != SGZ_OK && rc != SGZ_E_OVERFLOW) return rc;
+        if (rc == SGZ_OK) {
+            SelGuard q{sgz_sel_create(num_matches, num_per_file, min_spacing, step_size, target_frames)};
+            if (!q.s) return SGZ_E_ARG;
+            rc = sgz_sel_feed_screened(q.s, cands.data(), n, nf, nf);
+            if (rc == SGZ_OK) {
+                *count_out = sgz_sel_result(q.s, matches_out, std::min(out_capacity, num_matches));
+                return *count_out < 0 ? *count_out : SGZ_OK;
+            }
+            if (rc != SGZ_E_STATE) return rc;  // SGZ_E_STATE: the shortcut does not apply
+        }
+    }
+
+    // General case.  Head files: exact fp64 kernel, fed densely.  Tail files: a screening kernel (half-precision
+    // matrix-core kernel, which writes upper bounds, or fp32 products); the windows within `margin` of the bound
+    // are re-scored exactly on the GPU before they are fed.
+    SelGuard g{sgz_sel_create(num_matches, num_per_file, min_spacing, step_size, target_frames)};
+    if (!g.s) return SGZ_E_ARG;
+    sgz_selector *sel = g.s;
+    const int head = std::min(nf, std::max(num_matches, 1));
+    if (!(margin >= 0.0f)) margin = f16 ? 1e-6f : 1e-5f;
+    bool screened = screen && head < nf;
+    if ((rc = sgz_corr_run(ctx, 0, head))) return rc;
+    if (head < nf) {
+        rc = !screened ? sgz_corr_run(ctx, head, nf)
+                       : (f16 ? sgz_corr_run_screen_f16(ctx, head, nf) : sgz_corr_run_screen(ctx, head, nf));
+        if (rc) return rc;
+    }
+    std::vector<float> sim, boost;
+    auto feedDense = [&](int f0, int f1) -> int {
+        int64_t total = 0;
+        for (int f = f0; f < f1; f++) total += sgz_corr_num_windows(ctx, f);
+        sim.resize((size_t)std::max<int64_t>(total, 1));
+        boost.resize(sim.size());
+        if (f1 > f0) {
+            const int r = sgz_corr_read_dense_range(ctx, f0, f1, sim.data(), boost.data());
+            if (r) return r;
+        }
+        size_t pos = 0;
+        for (int f = f0; f < f1; f++) {
+            const int64_t n = sgz_corr_num_windows(ctx, f);
+            const int r = sgz_sel_feed_file(sel, f, n, nullptr, sim.data() + pos, boost.data() + pos);
+            if (r) return r;
+            pos += (size_t)n;
+        }
+        return SGZ_OK;
+    };
+    if ((rc = feedDense(0, head))) return rc;
+    int f = head;
+    if (f < nf && !sgz_sel_is_full(sel) && screened) {  // dense feeding needs exact values
+        if ((rc = sgz_corr_run(ctx, f, nf))) return rc;
+        screened = false;
+    }
+    // rare: equal sims collapsed entries, the set is not full yet -> keep feeding densely
+    while (f < nf && !sgz_sel_is_full(sel)) {
+        if ((rc = feedDense(f, f + 1))) return rc;
+        f++;
+    }
+    if (f < nf) {
+        if (cands.size() < (size_t)capacity) cands.resize((size_t)capacity);
+        int64_t n = 0;
+        rc = screened ? sgz_corr_compact_rescored(ctx, f, nf, sgz_sel_threshold(sel) - margin, cands.data(), capacity, &n)
+                      : sgz_corr_compact(ctx, f, nf, sgz_sel_threshold(sel), cands.data(), capacity, &n);
+        if (rc == SGZ_E_OVERFLOW) {  // more candidates than the buffer holds: dense replay of the tail
+            if (screened && (rc = sgz_corr_run(ctx, f, nf))) return rc;
+            for (int k = f; k < nf; k++)
+                if ((rc = feedDense(k, k + 1))) return rc;
+        } else {
+            if (rc) return rc;
+            if ((rc = sgz_sel_feed_candidates(sel, cands.data(), n))) return rc;
+        }
+    }
+    *count_out = sgz_sel_result(sel, matches_out, std::min(out_capacity, num_matches));
+    return *count_out < 0 ? *count_out : SGZ_OK;
+}

@@ -164,6 +164,17 @@ class Context:
                                                  C.byref(cnt)))
         return out[: cnt.value]
 
+    def corr_search(self, num_matches: int, num_per_file: int, min_spacing: int, step_size: int,
+                    screen_mode: int = N.SGZ_SCREEN_AUTO, over_bounds: bool = True, capacity: int = 1 << 16,
+                    margin: float = -1.0) -> list[N.Match]:
+        """One whole search over the files of the context with the current target (sgz_corr_search)."""
+        arr = (N.Match * max(num_matches, 1))()
+        cnt = C.c_int(0)
+        self._check(lib.sgz_corr_search(self._h, self.target_frames, num_matches, num_per_file, min_spacing,
+                                        step_size, screen_mode, int(over_bounds), capacity, margin, arr,
+                                        num_matches, C.byref(cnt)))
+        return [arr[i] for i in range(cnt.value)]
+
     def corr_compact_bounded_device(self, file_begin: int, file_end: int, head_end: int, out_ptr: int,
                                     capacity: int, count_ptr: int) -> None:
         self._check(lib.sgz_corr_compact_bounded_device(self._h, file_begin, file_end, head_end,

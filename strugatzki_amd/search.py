@@ -76,75 +76,18 @@ def _feed_dense_head(ctx: Context, sel: Selector, files: Sequence[int], global_i
     return len(files)
 
 
-def _search_over_bounds(ctx: Context, p: SearchParams) -> list[N.Match] | None:
-    """numPerFile = 1: the sliding loop keeps, per file, a running strict maximum of the similarities that
-    exceed the worst global entry (impl/FeatureCorrelationImpl.scala:124-150, :234-239), so a file can only
-    contribute its largest similarity, first occurrence.  All files go through the half-precision kernel;
-    per file, the windows whose upper bound reaches the file's largest lower bound are re-scored exactly
-    (Context.corr_compact_bounded with every file a "head" file), and the exact per-file maxima are fed to
-    the selection in file order.  None: the shortcut does not apply (see sgz_sel_feed_screened)."""
-    nf = ctx.num_files
-    ctx.corr_run_screen_f16(0, nf)
-    try:
-        cands = ctx.corr_compact_bounded(0, nf, nf, p.capacity)
-    except N.NativeError as e:
-        if e.code != N.SGZ_E_OVERFLOW:
-            raise
-        return None
-    sel = Selector(p.num_matches, p.num_per_file, p.min_spacing, p.step_size, ctx.target_frames)
-    try:
-        return sel.result() if sel.feed_screened(cands, nf, nf) else None
-    finally:
-        sel.close()
+_SCREEN_CODES = {"f32": N.SGZ_SCREEN_F32, "f16": N.SGZ_SCREEN_F16, "auto": N.SGZ_SCREEN_AUTO}
 
 
 def search(ctx: Context, p: SearchParams) -> list[N.Match]:
-    """Single-GPU search over all files of the context, in their index order."""
-    nf = ctx.num_files
-    if (p.screen and p.screen_head and p.num_per_file == 1 and p.num_matches >= 1 and nf > 0
-            and _screen_mode(ctx, p) == "f16"):
-        out = _search_over_bounds(ctx, p)
-        if out is not None:
-            return out
-    sel = Selector(p.num_matches, p.num_per_file, p.min_spacing, p.step_size, ctx.target_frames)
-    head = min(nf, max(p.num_matches, 1))
-    ctx.corr_run(0, head)
-    screened = p.screen and head < nf
-    mode = _screen_mode(ctx, p) if screened else None
-    margin = p.margin if p.margin is not None or not screened else MARGIN[mode]
-    if head < nf:
-        if screened:
-            _run_screen(ctx, mode, head, nf)
-        else:
-            ctx.corr_run(head, nf)
-    f = _feed_dense_head(ctx, sel, range(head), range(head))
-    if f < nf and not sel.is_full and screened:  # dense feeding needs exact values
-        ctx.corr_run(f, nf)
-        screened = False
-    # rare: equal sims collapsed entries, the set is not full yet -> keep feeding densely
-    while f < nf and not sel.is_full:
-        sim, boost = ctx.corr_read_dense(f)
-        sel.feed_dense(f, sim, boost)
-        f += 1
-    if f < nf:
-        try:
-            thr = sel.threshold - margin if screened else sel.threshold
-            cands = ctx.corr_compact(f, nf, thr, p.capacity, rescore=screened)
-        except N.NativeError as e:
-            if e.code != N.SGZ_E_OVERFLOW:
-                raise
-            cands = None
-        if cands is None:  # more candidates than the buffer holds: dense replay of the tail
-            if screened:
-                ctx.corr_run(f, nf)
-            for g in range(f, nf):
-                sim, boost = ctx.corr_read_dense(g)
-                sel.feed_dense(g, sim, boost)
-        else:
-            sel.feed_candidate_list(cands)
-    out = sel.result()
-    sel.close()
-    return out
+    """Single-GPU search over all files of the context, in their index order: one native call
+    (sgz_corr_search) that runs the kernels and replays the selection."""
+    if p.screen_mode not in _SCREEN_CODES:
+        raise ValueError(f"unknown screen_mode {p.screen_mode!r}")
+    mode = _SCREEN_CODES[p.screen_mode] if p.screen else N.SGZ_SCREEN_NONE
+    return ctx.corr_search(p.num_matches, p.num_per_file, p.min_spacing, p.step_size, mode,
+                           over_bounds=p.screen and p.screen_head, capacity=p.capacity,
+                           margin=-1.0 if p.margin is None else p.margin)
 
 
 def search_punch(ctx: Context, p: SearchParams, target_in: np.ndarray, weight_in: float, target_out: np.ndarray,
