@@ -308,6 +308,179 @@ __global__ __launch_bounds__(256) void prep_kernel(const FileDesc *__restrict__ 
 }
 
 // ---------------------------------------------------------------------------
+// prep_half_kernel: the half-precision preparation (same outputs as prep_kernel<_Float16>) for a channel
+// count known at compile time.  A workgroup takes 512 frames: coalesced 16-byte loads into a linear LDS
+// copy, then every thread owns two consecutive frames in registers -- normalisation, centring, the
+// frame moments and the half conversion need no further LDS traffic or address arithmetic, the norms are
+// scalar operands, and the 256-thread scan of the moments runs on the cross-lane data path.
+// ---------------------------------------------------------------------------
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ double dpp_add(double v)
+{
+    // lanes without a source (and rows switched off by the mask) add 0
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), kCtrl, kRowMask, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), kCtrl, kRowMask, 0xf, false);
+    return v + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_inclusive_scan(double v)
+{
+    v = dpp_add<0x111, 0xf>(v);  // row_shr:1
+    v = dpp_add<0x112, 0xf>(v);  // row_shr:2
+    v = dpp_add<0x114, 0xf>(v);  // row_shr:4
+    v = dpp_add<0x118, 0xf>(v);  // row_shr:8
+    v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 -> rows 1 and 3
+    v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 -> rows 2 and 3
+    return v;
+}
+
+constexpr int kPrepHalfFrames = 512;  // frames per workgroup of prep_half_kernel: two per thread
+
+template <int NCH>
+__global__ __launch_bounds__(256) void prep_half_kernel(const FileDesc *__restrict__ files,
+                                                        const PrepTile *__restrict__ ptiles,
+                                                        _Float16 *__restrict__ planar, double *__restrict__ prefix,
+                                                        double *__restrict__ tbase, NormParams nrm, double kT,
+                                                        double kS, int *__restrict__ hflags, int *__restrict__ lokey)
+{
+    static_assert((2 * NCH) % 4 == 0, "two frames must be whole 16-byte vectors");
+    constexpr int kVecPerThread = 2 * NCH / 4;
+    __shared__ __attribute__((aligned(16))) float raw[kPrepHalfFrames * NCH];
+    __shared__ double wtot[4][4];
+    const PrepTile pt = ptiles[blockIdx.x];
+    const FileDesc fd = files[pt.file];
+    const long long f0 = (long long)pt.chunk0 * kR;
+    const int tid = threadIdx.x;
+    const float *src = fd.raw + f0 * NCH;
+    const long long validElems = (fd.frames - f0) * NCH;  // may be <= 0 for padding tiles
+
+    // phase 1: the tile's frames as they lie in memory
+    {
+        float4 x[kVecPerThread];
+        if (validElems >= (long long)kPrepHalfFrames * NCH) {
+#pragma unroll
+            for (int u = 0; u < kVecPerThread; u++)
+                x[u] = *reinterpret_cast<const float4 *>(src + 4 * (tid + 256 * u));
+        } else {  // the file ends inside this tile
+#pragma unroll
+            for (int u = 0; u < kVecPerThread; u++) {
+                const long long e0 = 4ll * (tid + 256 * u);
+                x[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (e0 + 3 < validElems) {
+                    x[u] = *reinterpret_cast<const float4 *>(src + e0);
+                } else {
+                    if (e0 < validElems) x[u].x = src[e0];
+                    if (e0 + 1 < validElems) x[u].y = src[e0 + 1];
+                    if (e0 + 2 < validElems) x[u].z = src[e0 + 2];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kVecPerThread; u++) *reinterpret_cast<float4 *>(raw + 4 * (tid + 256 * u)) = x[u];
+    }
+    __syncthreads();
+
+    // phase 2: frames 2 tid and 2 tid + 1 of the tile
+    float v[2 * NCH];
+#pragma unroll
+    for (int u = 0; u < kVecPerThread; u++) {
+        const float4 q = *reinterpret_cast<const float4 *>(raw + 2 * NCH * tid + 4 * u);
+        v[4 * u] = q.x;
+        v[4 * u + 1] = q.y;
+        v[4 * u + 2] = q.z;
+        v[4 * u + 3] = q.w;
+    }
+    const long long gf0 = f0 + 2 * tid;
+    const bool ok[2] = {gf0 < fd.frames, gf0 + 1 < fd.frames};
+    const float kTf = (float)kT, kSf = (float)kS;
+    float peak = 0.0f;
+    float mom[2][4];
+    // the half-precision image and its bounds do not need the reference's exact fp32 quotient (re-scoring
+    // recomputes it): reciprocal multiply; (x - 0) * 1 leaves x as it is where normalisation is off
+    float mn[NCH], rc[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        mn[c] = nrm.enabled ? nrm.mn[c] : 0.0f;
+        rc[c] = nrm.enabled ? __builtin_amdgcn_rcpf(nrm.d[c]) : 1.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        float f1 = 0.0f, f2 = 0.0f;
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            float val = (v[k * NCH + c] - mn[c]) * rc[c];
+            val = ok[k] ? val - (c == 0 ? kTf : kSf) : 0.0f;  // frames past the end are 0
+            peak = fmaxf(peak, fabsf(val));                   // NaN stays NaN, as in the exact path
+            if (c > 0) {
+                f1 += val;
+                f2 = fmaf(val, val, f2);
+            }
+            v[k * NCH + c] = val;
+        }
+        mom[k][0] = v[k * NCH];
+        mom[k][2] = f1;
+        mom[k][3] = f2;
+    }
+    const long long rowLen = fd.M * kR;
+    if (gf0 < rowLen) {
+        using half2v = __attribute__((ext_vector_type(2))) _Float16;
+        _Float16 *dst = planar + fd.planar_off + gf0;
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            half2v h;
+            h[0] = (_Float16)v[c];
+            h[1] = (_Float16)v[NCH + c];
+            *reinterpret_cast<half2v *>(dst + (long long)c * rowLen) = h;
+        }
+    }
+    if (peak > 60000.0f) hflags[pt.file] = 1;
+    // the matrix-core kernel that follows folds its lower bounds into this per-file maximum
+    if (pt.chunk0 == 0 && tid == 0) lokey[pt.file] = bound_key(-INFINITY);
+
+    // phase 3: frame moments (loudness: x, x^2; MFCC rows: sum x, sum x^2, all centred; the 13-term sums of
+    // one frame in fp32, the running sums in fp64), inclusive prefix sums inside this tile; the tile totals go
+    // to tbase for the cross-tile scan.
+    if (f0 < fd.frames) {
+        double m[2][4], run[4], inc[4];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const double t = (double)mom[k][0];
+            m[k][0] = t;
+            m[k][1] = t * t;
+            m[k][2] = (double)mom[k][2];
+            m[k][3] = (double)mom[k][3];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            run[q] = m[0][q] + m[1][q];
+            inc[q] = wave_inclusive_scan(run[q]);
+        }
+        if ((tid & 63) == 63) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) wtot[tid >> 6][q] = inc[q];
+        }
+        __syncthreads();
+        double *pre = prefix + fd.prefix_off;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            double base = 0.0;
+            for (int wv = 0; wv < (tid >> 6); wv++) base += wtot[wv][q];
+            base += inc[q] - run[q];
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                base += m[k][q];
+                if (ok[k]) pre[q * fd.frames + gf0 + k] = base;
+            }
+        }
+        if (tid == 255) {
+            const int tileIdx = pt.chunk0 / (kPrepHalfFrames / kR);
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                tbase[fd.tbase_off + (long long)q * fd.nptiles + tileIdx] = wtot[0][q] + wtot[1][q] + wtot[2][q] + inc[q];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // tile_scan_kernel: per file and moment, turns the tile totals into exclusive
 // tile bases (one wave per moment).
 // ---------------------------------------------------------------------------
@@ -1286,6 +1459,10 @@ static int corr_run_impl(sgz_context *ctx, int file_begin, int file_end, int mod
         hipLaunchKernelGGL(prep_kernel<double>, dim3(pt1 - pt0), dim3(256), prepLds, stream, ctx->d_files,
                            ctx->d_ptiles + pt0, ctx->d_planar, ctx->d_prefix, ctx->d_tbase, ctx->norm, ctx->numCh, cb,
                            ctx->cp.kT, ctx->cp.kS, ctx->d_hflags, ctx->d_lokey);
+    else if (half && ctx->numCh == 14 && cb * kR == kPrepHalfFrames)  // the reference's default: 13 MFCC + loudness
+        hipLaunchKernelGGL(prep_half_kernel<14>, dim3(pt1 - pt0), dim3(256), 0, stream, ctx->d_files,
+                           ctx->d_ptiles + pt0, reinterpret_cast<_Float16 *>(ctx->d_planar_h), ctx->d_prefix,
+                           ctx->d_tbase, ctx->norm, ctx->cp.kT, ctx->cp.kS, ctx->d_hflags, ctx->d_lokey);
     else if (half)
         hipLaunchKernelGGL(prep_kernel<_Float16>, dim3(pt1 - pt0), dim3(256), prepLds, stream, ctx->d_files,
                            ctx->d_ptiles + pt0, reinterpret_cast<_Float16 *>(ctx->d_planar_h), ctx->d_prefix,
