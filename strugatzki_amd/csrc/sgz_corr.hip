@@ -292,9 +292,14 @@ __global__ __launch_bounds__(256) void prep_kernel(const FileDesc *__restrict__ 
             const long long gf = f0 + fr;
             if (k < per && fr < tileFrames && gf < fd.frames) {
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    base[q] += m[k][q];
-                    pre[q * fd.frames + gf] = base[q];
+                for (int q = 0; q < 4; q++) base[q] += m[k][q];
+                if constexpr (std::is_same<T, _Float16>::value) {
+                    // screening: one fp32 record per frame (its bounds account for that rounding)
+                    reinterpret_cast<float4 *>(pre)[gf] =
+                        make_float4((float)base[0], (float)base[1], (float)base[2], (float)base[3]);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) pre[q * fd.frames + gf] = base[q];
                 }
             }
         }
@@ -459,17 +464,20 @@ __global__ __launch_bounds__(256) void prep_half_kernel(const FileDesc *__restri
             for (int q = 0; q < 4; q++) wtot[tid >> 6][q] = inc[q];
         }
         __syncthreads();
-        double *pre = prefix + fd.prefix_off;
+        // one fp32 record of the four running sums per frame (the screening bounds account for that rounding)
+        float4 *pre = reinterpret_cast<float4 *>(prefix + fd.prefix_off);
+        double base[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            double base = 0.0;
-            for (int wv = 0; wv < (tid >> 6); wv++) base += wtot[wv][q];
-            base += inc[q] - run[q];
+            base[q] = 0.0;
+            for (int wv = 0; wv < (tid >> 6); wv++) base[q] += wtot[wv][q];
+            base[q] += inc[q] - run[q];
+        }
 #pragma unroll
-            for (int k = 0; k < 2; k++) {
-                base += m[k][q];
-                if (ok[k]) pre[q * fd.frames + gf0 + k] = base;
-            }
+        for (int k = 0; k < 2; k++) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) base[q] += m[k][q];
+            if (ok[k]) pre[gf0 + k] = make_float4((float)base[0], (float)base[1], (float)base[2], (float)base[3]);
         }
         if (tid == 255) {
             const int tileIdx = pt.chunk0 / (kPrepHalfFrames / kR);

@@ -66,44 +66,98 @@ __device__ __forceinline__ void window_result(const CorrParams &cp, const Epilog
 // Screening variant for cross terms formed from reduced-precision products of relative error <= relErr:
 // an upper and a lower bound of the similarity window_result would give, and the boost to about 1e-6.
 // By Cauchy-Schwarz the error of a normalised cross term is at most relErr * sqrt(1 + (dm / sd)^2), dm the
-// offset of the window mean from the centring constant, sd the window std-dev.  Differences of prefix sums
-// and the variance are taken in fp64, everything after them in fp32: that adds a few 1e-7, covered by the
-// absolute slack of 1e-5.  A window without spread gets (-inf, +inf); a boost within 1e-5 of the gate makes
-// the bounds include 0, the value of a gated window.
+// offset of the window mean from the centring constant, sd the window std-dev.
+//
+// The screening preparation stores the in-tile prefix sums of the four frame moments as one fp32 record per
+// frame (HalfPrefix: 16 bytes fetched per window end instead of four doubles); the tile bases stay fp64.  A
+// stored value p differs from the fp64 sum by at most 2^-24 |p|, so a window sum is off by at most
+// E = 2^-24 (|p_hi| + |p_lo|): that moves the mean by E1 / n and the variance by dv = E2 / n + 2 |dm| E1 / n,
+// hence 1 / sd by a relative rho <= dv / var (for dv <= var / 2; beyond that the window counts as having no
+// spread).  Both go into the error bound, next to the few 1e-7 of the fp32 arithmetic after the sums (one-ulp
+// hardware reciprocal, square root, log2, exp2), which the absolute slack of 1e-5 covers.
+// A window without spread gets (-inf, +inf); a boost within 1e-5 of the gate makes the bounds include 0, the
+// value of a gated window.
 // The part that does not depend on the cross terms is evaluated ahead of them (window_coeffs) and folded into
 // four numbers: sim ~ a * crossT + b * crossS - c, error bound |e|; e < 0 marks a boost next to the gate.
 struct WindowCoeffs {
     float a, b, c, e;
 };
 
-__device__ __forceinline__ WindowCoeffs window_coeffs(const CorrParams &cp, const Epilogue &ep, long long o,
-                                                      float relErr, float &boostOut)
+struct HalfPrefix {
+    const float4 *pre;    // per frame: in-tile inclusive sums of (t, t^2, sum s, sum s^2)
+    const double *tbase;  // 4 arrays of `nptiles` tile bases
+    long long nptiles;
+    int tileShift;
+};
+
+// The two prefix records of window o (no branch around the loads; fetched ahead of their use).
+struct WindowRecords {
+    float4 hi, lo;
+};
+__device__ __forceinline__ WindowRecords window_records(const HalfPrefix &hp, unsigned o, int L)
+{
+    return WindowRecords{hp.pre[o + (unsigned)L - 1], hp.pre[o > 0 ? o - 1 : 0]};
+}
+
+__device__ __forceinline__ WindowCoeffs window_coeffs(const CorrParams &cp, const HalfPrefix &hp, unsigned o,
+                                                      const WindowRecords &rec, float relErr, float &boostOut)
 {
     const double nTd = (double)cp.L, nSd = (double)cp.L * (double)(cp.numCh - 1);
     const double rnT = 1.0 / nTd, rnS = 1.0 / nSd;  // wave-uniform: one division each, not one per window
-    const double dmTd = (ep.P(0, o + cp.L) - ep.P(0, o)) * rnT;
-    const double varT = (ep.P(1, o + cp.L) - ep.P(1, o)) * rnT - dmTd * dmTd;
-    const double dmSd = (ep.P(2, o + cp.L) - ep.P(2, o)) * rnS;
-    const double varS = (ep.P(3, o + cp.L) - ep.P(3, o)) * rnS - dmSd * dmSd;
+    const unsigned l1 = o > 0 ? o - 1 : 0, h1 = o + (unsigned)cp.L - 1;
+    const float4 ph = rec.hi, pl = rec.lo;
+    const unsigned th = h1 >> hp.tileShift, tl = l1 >> hp.tileShift;
+    double bh[4], bl[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        bh[q] = hp.tbase[q * hp.nptiles + th];
+        bl[q] = hp.tbase[q * hp.nptiles + tl];
+    }
+    const bool first = o == 0;  // nothing to subtract
+    const float phv[4] = {ph.x, ph.y, ph.z, ph.w}, plv[4] = {pl.x, pl.y, pl.z, pl.w};
+    double d[4];
+    float E[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        d[q] = ((double)phv[q] + bh[q]) - (first ? 0.0 : (double)plv[q] + bl[q]);
+        E[q] = 6.0e-8f * (fabsf(phv[q]) + (first ? 0.0f : fabsf(plv[q])));  // 2^-24 = 5.96e-8
+    }
+    const double dmTd = d[0] * rnT;
+    const double varT = d[1] * rnT - dmTd * dmTd;
+    const double dmSd = d[2] * rnS;
+    const double varS = d[3] * rnS - dmSd * dmSd;
     const float avgF = (float)(cp.kT + dmTd);
-    const float boost = expf(((float)cp.lnAvgIn - logf(avgF)) * (1.0f / 0.6f));
+    const float kLn2 = 0.6931471805599453f, kLog2e = 1.4426950408889634f;
+    const float lnAvg = __builtin_amdgcn_logf(avgF) * kLn2;  // avg <= 0: NaN / -inf, the window reads as gated
+    const float boost = __builtin_amdgcn_exp2f(((float)cp.lnAvgIn - lnAvg) * (kLog2e / 0.6f));
     boostOut = boost;
     WindowCoeffs wc = {0.0f, 0.0f, 0.0f, 0.0f};  // a gated window: sim = 0 exactly
     if (boost <= cp.maxBoost * 1.00001f) {
         float errT = 0.0f, errS = 0.0f;
         if (cp.w > 0.0f) {
-            const float dm = (float)dmTd, sd = sqrtf(fmaxf((float)varT, 0.0f));
-            const float r = dm / sd;
-            wc.a = cp.w / ((float)cp.aStdT * sd * (float)nTd);
+            const float rn = (float)rnT, dm = (float)dmTd, var = fmaxf((float)varT, 0.0f);
+            const float sd = __builtin_amdgcn_sqrtf(var);
+            const float rsd = __builtin_amdgcn_rcpf(sd);  // sd = 0: inf, and the error bound below says so
+            const float r = dm * rsd;
+            const float dv = (E[1] + 2.0f * fabsf(dm) * E[0]) * rn;
+            wc.a = (cp.w / ((float)cp.aStdT * (float)nTd)) * rsd;
             wc.c = wc.a * dm * (float)cp.sumAT;
-            errT = sd > 0.0f ? relErr * sqrtf(1.0f + r * r) : INFINITY;
+            const float eh = relErr * __builtin_amdgcn_sqrtf(1.0f + r * r);
+            errT = var > 0.0f && 2.0f * dv <= var ? eh + (1.0f + eh) * dv * (rsd * rsd) + fabsf(wc.a * (float)cp.sumAT) * E[0] * rn / cp.w
+                                    : INFINITY;
         }
         if (cp.w < 1.0f) {
-            const float dm = (float)dmSd, sd = sqrtf(fmaxf((float)varS, 0.0f));
-            const float r = dm / sd;
-            wc.b = (1.0f - cp.w) / ((float)cp.aStdS * sd * (float)nSd);
+            const float rn = (float)rnS, dm = (float)dmSd, var = fmaxf((float)varS, 0.0f);
+            const float sd = __builtin_amdgcn_sqrtf(var);
+            const float rsd = __builtin_amdgcn_rcpf(sd);
+            const float r = dm * rsd;
+            const float dv = (E[3] + 2.0f * fabsf(dm) * E[2]) * rn;
+            wc.b = ((1.0f - cp.w) / ((float)cp.aStdS * (float)nSd)) * rsd;
             wc.c += wc.b * dm * (float)cp.sumAS;
-            errS = sd > 0.0f ? relErr * sqrtf(1.0f + r * r) : INFINITY;
+            const float eh = relErr * __builtin_amdgcn_sqrtf(1.0f + r * r);
+            errS = var > 0.0f && 2.0f * dv <= var
+                       ? eh + (1.0f + eh) * dv * (rsd * rsd) + fabsf(wc.b * (float)cp.sumAS) * E[2] * rn / (1.0f - cp.w)
+                       : INFINITY;
         }
         wc.e = errT * cp.w + errS * (1.0f - cp.w) + 1e-5f;
         if (boost > cp.maxBoost * 0.99999f) wc.e = -wc.e;  // the exact path may gate this window

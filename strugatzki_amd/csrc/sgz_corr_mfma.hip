@@ -43,24 +43,28 @@ constexpr int kHThreads = kHWaves * 64;
 // fp32 summation.
 constexpr float kHalfRelErr = 1.0e-3f;
 
-// One staged channel: XU 16-byte units of database frames, then the two target copies (LAd dwords each);
-// rounded up to whole 1 KiB pieces, the unit one wave-wide direct-to-LDS load fills.
+// One staged channel: XU 16-byte units of database frames, then the two target copies (LAd dwords each),
+// each part rounded up to whole 1 KiB pieces, the unit one wave-wide direct-to-LDS load fills
+// (+1 KiB: the operand requests of the step past the last one stay inside the buffer).
+__host__ __device__ constexpr int half_x_pieces(int XU) { return (XU + 63) >> 6; }
+__host__ __device__ constexpr int half_a_pieces(int LAd) { return (LAd / 2 + 63) >> 6; }
 __host__ __device__ constexpr size_t half_buf_bytes(int XU, int LAd)
 {
-    return (((size_t)XU * 16 + (size_t)LAd * 8) + 1023) & ~(size_t)1023;
+    const size_t bytes = (size_t)1024 * (half_x_pieces(XU) + half_a_pieces(LAd) + 1);
+    // once a buffer's channel is consumed it holds one array of partial sums (kHTileW floats) and a few words
+    return bytes > (kHTileW * sizeof(float) + 1024) ? bytes : kHTileW * sizeof(float) + 1024;
 }
 
 typedef __attribute__((address_space(3))) void lds_void;
-typedef __attribute__((address_space(1))) const void gbl_void;
 
-size_t half_lds_bytes(const HalfGeom &hg) { return 2 * half_buf_bytes(hg.XU, hg.LAd) + 2 * kHTileW * sizeof(float); }
+size_t half_lds_bytes(const HalfGeom &hg) { return 2 * half_buf_bytes(hg.XU, hg.LAd); }
 
 // Workgroup = 8 waves, one tile of kHTileW consecutive windows of one file.
 // Per channel the workgroup stages (double buffered) the frames
 // [o0, o0 + 8 XU) of the file in natural order and the two dword-aligned
 // copies of the target channel (even shifts read copy 0, odd shifts copy 1,
 // which is stored one element further left).  Staging uses direct-to-LDS loads
-// (global_load_lds_dwordx4: per-lane source address, destination = wave-uniform
+// (buffer_load_dwordx4 ... lds: per-lane source offset, destination = wave-uniform
 // base + 16 * lane), issued a phase ahead and retired by the barrier that ends
 // the phase, so no registers hold data in flight.
 __global__ __launch_bounds__(kHThreads, 4) void corr_mfma_kernel(
@@ -77,29 +81,39 @@ __global__ __launch_bounds__(kHThreads, 4) void corr_mfma_kernel(
     const TileDesc td = tiles[blockIdx.x];
     const FileDesc fd = files[td.file];
     const size_t bufBytes = half_buf_bytes(hg.XU, hg.LAd);
-    const int nV = hg.XU + hg.LAd / 2;  // 16-byte vectors per staged channel
     const long long rowLen = fd.M * kR;
     const _Float16 *fplanar = planarH + fd.planar_off + td.o0;
 
-    const int nPieces = (nV + 63) >> 6;  // 1 KiB pieces per staged channel
+    // Staging through buffer loads with the LDS as destination: the descriptor carries the wave-uniform row
+    // base and the valid length (lanes past it fill padding with zeros), the lane its 16-byte offset.  (The
+    // flat-addressed form of these loads makes the compiler drain every LDS read completely while one is
+    // in flight, which the loop below cannot afford.)
+    const int nXP = half_x_pieces(hg.XU), nAP = half_a_pieces(hg.LAd);
     auto stage = [&](int c, int buf) {
-        const uint4 *xsrc = reinterpret_cast<const uint4 *>(fplanar + (long long)c * rowLen);
-        const uint4 *asrc = reinterpret_cast<const uint4 *>(aimg + (size_t)c * 2 * hg.LAd);
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<_Float16 *>(fplanar + (long long)c * rowLen), 0, hg.XU * 16, 0x00020000);
+        const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint32_t *>(aimg + (size_t)c * 2 * hg.LAd), 0, hg.LAd * 8, 0x00020000);
         unsigned char *dst = lds + buf * bufBytes;
-        for (int piece = q; piece < nPieces; piece += kHWaves) {
-            const int v = min(piece * 64 + lane, nV - 1);  // surplus lanes of the last piece fill padding
-            const uint4 *src = v < hg.XU ? xsrc + v : asrc + (v - hg.XU);
-            __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)(dst + (size_t)piece * 1024), 16, 0, 0);
+        for (int piece = q; piece < nXP + nAP; piece += kHWaves) {
+            lds_void *to = (lds_void *)(dst + (size_t)piece * 1024);
+            if (piece < nXP)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, to, 16, (piece * 64 + lane) * 16, 0, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ar, to, 16, ((piece - nXP) * 64 + lane) * 16, 0, 0, 0);
         }
     };
 
     const int m = lane & 15, g = lane >> 4;
     const int hBase = 2 * m + g + 4 * q;                                              // 16-byte units
     const int aBase = (m & 1) * hg.LAd + 4 * g + 8 - ((m + 1) >> 1) + 16 * q;          // dwords
-    const int P = (hg.S2 - q + 7) >> 3;                                               // steps of this wave
+    const int Pmax = (hg.S2 + 7) >> 3;  // steps per wave: wave q takes s = q, q + 8, ...
 
-    float4 *redS4 = reinterpret_cast<float4 *>(lds + 2 * bufBytes);
-    float4 *redT4 = redS4 + kHTileW / 4;
+    // The cross-wave sums take the place of staged channels that have been consumed: the MFCC sum goes where
+    // the last MFCC channel was (the loudness channel sits in the other buffer by then), the loudness sum
+    // where the loudness channel was.
+    float4 *redS4 = reinterpret_cast<float4 *>(lds + ((cp.numCh - 2) & 1) * bufBytes);
+    float4 *redT4 = reinterpret_cast<float4 *>(lds + ((cp.numCh - 1) & 1) * bufBytes);
     auto reduce = [&](float4 *red, const f32x4 (&acc)[NB]) {
         for (int wv = 0; wv < kHWaves; wv++) {
             if (q == wv) {
@@ -127,26 +141,7 @@ __global__ __launch_bounds__(kHThreads, 4) void corr_mfma_kernel(
 
     stage(channel_of(0), 0);
 
-    // window statistics of this thread's windows: their loads are in flight while the first channel lands
-    Epilogue ep;
-    ep.pre = prefix + fd.prefix_off;
-    ep.tbase = tbase + fd.tbase_off;
-    ep.frames = fd.frames;
-    ep.nptiles = fd.nptiles;
-    ep.tileShift = cp.prepTileShift;
-    CorrParams cph = cp;
-    cph.sumAT = hg.sumAT;
-    cph.sumAS = hg.sumAS;
     constexpr int kPerThread = kHTileW / kHThreads;
-    WindowCoeffs wc[kPerThread];
-#pragma unroll
-    for (int k = 0; k < kPerThread; k++) {
-        const long long o = (long long)td.o0 + tid + k * kHThreads;
-        float boost;
-        wc[k] = window_coeffs(cph, ep, o < fd.num_windows ? o : 0, kHalfRelErr, boost);
-        if (o < fd.num_windows) boostOut[fd.win_off + o] = boost;
-        if (k & 1) asm volatile("" ::: "memory");  // two windows' loads in flight at a time
-    }
     __syncthreads();
 
     f32x4 acc[NB];
@@ -156,7 +151,7 @@ __global__ __launch_bounds__(kHThreads, 4) void corr_mfma_kernel(
     for (int ph = 0; ph < numCh; ph++) {
         if (ph + 1 < numCh) stage(channel_of(ph + 1), (ph + 1) & 1);
         const uint4 *Xu = reinterpret_cast<const uint4 *>(lds + (ph & 1) * bufBytes) + hBase;
-        const uint32_t *Ad = reinterpret_cast<const uint32_t *>(lds + (ph & 1) * bufBytes + (size_t)hg.XU * 16) + aBase;
+        const uint32_t *Ad = reinterpret_cast<const uint32_t *>(lds + (ph & 1) * bufBytes + (size_t)nXP * 1024) + aBase;
 
         half8 h[NB];
 #pragma unroll
@@ -170,20 +165,39 @@ __global__ __launch_bounds__(kHThreads, 4) void corr_mfma_kernel(
             av.w = ap[3];
             return __builtin_bit_cast(half8, av);
         };
-        half8 aNext = load_a(0);  // in range for any P: the image has room for one step
-        for (int pb = 0; pb < P; pb += NB) {
+        // Every wave runs Pmax steps (the target image is zero past its end, so surplus steps add nothing and
+        // cost no time: the other waves of the workgroup are still busy).  Straight-line blocks of NB steps:
+        // the target operand of the next step is requested before, the freed slot of the operand window
+        // right after this step's first matrix instruction, so each wait covers exactly the reads it needs.
+        half8 a[2];
+        a[0] = load_a(0);
+        int pb = 0;
+        for (; pb + NB <= Pmax; pb += NB) {
 #pragma unroll
             for (int u = 0; u < NB; u++) {
-                const int p = pb + u;
-                if (p < P) {
-                    const half8 a = aNext;
-                    if (p + 1 < P) aNext = load_a(p + 1);
+                a[(u + 1) & 1] = load_a(pb + u + 1);  // the image has room for one step past the last
+                __builtin_amdgcn_sched_barrier(0);    // (keeps the requests ahead of the matrix instructions)
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u & 1], h[u], acc[0], 0, 0, 0);
+                h[u] = __builtin_bit_cast(half8, Xu[32 * (pb + u + NB)]);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int t = 0; t < NB; t++)
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, h[(u + t) % NB], acc[t], 0, 0, 0);
-                    if (p + 1 < P) h[u] = __builtin_bit_cast(half8, Xu[32 * (p + NB)]);
-                }
+                for (int t = 1; t < NB; t++)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u & 1], h[(u + t) % NB], acc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
+        }
+#pragma unroll
+        for (int u = 0; u < NB - 1; u++) {
+            if (pb + u >= Pmax) break;
+            a[(u + 1) & 1] = load_a(pb + u + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u & 1], h[u], acc[0], 0, 0, 0);
+            h[u] = __builtin_bit_cast(half8, Xu[32 * (pb + u + NB)]);  // for the steps that follow, if any
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 1; t < NB; t++)
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u & 1], h[(u + t) % NB], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
 
         __syncthreads();  // also retires the loads staged above
@@ -193,7 +207,24 @@ __global__ __launch_bounds__(kHThreads, 4) void corr_mfma_kernel(
             for (int t = 0; t < NB; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
+    // The prefix records of this thread's windows are requested before the last reduction and arrive during it;
+    // the part of the bounds that does not depend on the cross terms is evaluated here, after the matrix work,
+    // so that it holds no registers during it.
+    HalfPrefix hp;
+    hp.pre = reinterpret_cast<const float4 *>(prefix + fd.prefix_off);
+    hp.tbase = tbase + fd.tbase_off;
+    hp.nptiles = fd.nptiles;
+    hp.tileShift = cp.prepTileShift;
+    WindowRecords rec[kPerThread];
+#pragma unroll
+    for (int k = 0; k < kPerThread; k++) {
+        const long long o = (long long)td.o0 + tid + k * kHThreads;
+        rec[k] = window_records(hp, o < fd.num_windows ? (unsigned)o : 0u, cp.L);
+    }
     reduce(redT4, acc);
+    CorrParams cph = cp;  // the statistics of the half-precision target image
+    cph.sumAT = hg.sumAT;
+    cph.sumAS = hg.sumAS;
 
     const float *redS = reinterpret_cast<const float *>(redS4);
     const float *redT = reinterpret_cast<const float *>(redT4);
@@ -205,7 +236,10 @@ __global__ __launch_bounds__(kHThreads, 4) void corr_mfma_kernel(
         const long long o = (long long)td.o0 + wdw;
         if (o < fd.num_windows) {
             float sim, lo;
-            window_bounds(wc[k], redT[wdw], redS[wdw], sim, lo);
+            float boost;
+            const WindowCoeffs wc = window_coeffs(cph, hp, (unsigned)o, rec[k], kHalfRelErr, boost);
+            window_bounds(wc, redT[wdw], redS[wdw], sim, lo);
+            boostOut[fd.win_off + o] = boost;
             simOut[fd.win_off + o] = sim;
             loOut[fd.win_off + o] = lo;
             best = fmaxf(best, lo);
@@ -219,8 +253,8 @@ __global__ __launch_bounds__(kHThreads, 4) void corr_mfma_kernel(
         best = fmaxf(best, __shfl_xor(best, off, 64));
         bad |= __shfl_xor(bad, off, 64);
     }
-    float *wbest = reinterpret_cast<float *>(lds);  // the staging buffers are free now
-    int *wbad = reinterpret_cast<int *>(lds) + kHWaves;
+    float *wbest = reinterpret_cast<float *>(lds + kHTileW * sizeof(float));  // behind the sums of buffer 0
+    int *wbad = reinterpret_cast<int *>(wbest) + kHWaves;
     if (lane == 0) {
         wbest[q] = best;
         wbad[q] = bad;
@@ -245,9 +279,8 @@ namespace sgz {
 static bool half_geom(int L, HalfGeom &hg)
 {
     const int S2 = (L + 15 + 31) / 32;
-    int LAd = 16 * S2 + 16;
-    if ((LAd & 31) != 16) LAd += 16;
     const int Pmax = (S2 + 7) / 8;
+    const int LAd = 128 * Pmax + 16;  // all 8 Pmax steps of 16 dwords + the shift room; = 16 mod 32
     const int XU = 32 * (Pmax + kHNB);
     hg.S2 = S2;
     hg.LAd = LAd;
