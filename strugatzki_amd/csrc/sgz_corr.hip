@@ -200,6 +200,7 @@ __global__ __launch_bounds__(256) void prep_kernel(const FileDesc *__restrict__ 
         // the matrix-core kernel that follows folds its lower bounds into this per-file maximum
         if (pt.chunk0 == 0 && tid == 0) lokey[pt.file] = bound_key(-INFINITY);
     } else {
+        if (pt.chunk0 == 0 && tid == 0) hflags[pt.file] = 0;  // exact values follow: no range flag
         // idx = tid + 256*k over [rows][cb]; cb is a power of two
         const int cbShift = 31 - __clz(cb);
         for (int idx = tid; idx < rows * cb; idx += 256) {
@@ -750,10 +751,13 @@ __global__ __launch_bounds__(256) void compact_kernel(const FileDesc *__restrict
                                                       const float *__restrict__ boost, float threshold,
                                                       sgz_candidate *__restrict__ out, long long capacity,
                                                       unsigned long long *__restrict__ count,
-                                                      const int *__restrict__ hflags)
+                                                      const int *__restrict__ hflags,
+                                                      unsigned long long *__restrict__ zeroOther)
 {
     const TileDesc td = tiles[blockIdx.x];
     const FileDesc fd = files[td.file];
+    // the counter of the next call (callers that alternate between two counters need no separate clear)
+    if (zeroOther && blockIdx.x == 0 && threadIdx.x == 0) *zeroOther = 0ull;
     // A file whose half-precision image overflowed has no usable screening values: report it as a
     // candidate overflow, which sends the caller to the exact dense path.
     if (hflags[td.file] && td.o0 == 0 && threadIdx.x == 0) atomicAdd(count, (unsigned long long)capacity + 1ull);
@@ -807,10 +811,12 @@ __global__ __launch_bounds__(256) void compact_bounded_kernel(const FileDesc *__
                                                               const float *__restrict__ tailThr, int headEnd,
                                                               sgz_candidate *__restrict__ out, long long capacity,
                                                               unsigned long long *__restrict__ count,
-                                                              const int *__restrict__ hflags)
+                                                              const int *__restrict__ hflags,
+                                                              unsigned long long *__restrict__ zeroOther)
 {
     const TileDesc td = tiles[blockIdx.x];
     const FileDesc fd = files[td.file];
+    if (zeroOther && blockIdx.x == 0 && threadIdx.x == 0) *zeroOther = 0ull;
     if (hflags[td.file] && td.o0 == 0 && threadIdx.x == 0) atomicAdd(count, (unsigned long long)capacity + 1ull);
     const bool headFile = td.file < headEnd;
     const float t = headFile ? bound_from_key(lokey[td.file]) : tailThr[0];
@@ -1386,6 +1392,10 @@ int sgz_corr_set_target(sgz_context *ctx, const float *frames, int num_frames, f
     const bool hadHalf = ctx->hg.S2 > 0;
     if ((rc = half_screen_set_target(ctx, ap, Lpad))) return rc;
     if (oldL != L || hadHalf != (ctx->hg.S2 > 0)) ctx->layout_dirty = true;
+    // the range flags of half-precision runs belong to the previous target
+    // (a pending layout rebuild clears them itself, for the files of the new layout)
+    if (ctx->d_hflags && !ctx->layout_dirty && !ctx->files.empty())
+        SGZ_HIP(ctx, hipMemsetAsync(ctx->d_hflags, 0, sizeof(int) * ctx->files.size(), ctx->stream));
     return SGZ_OK;
 }
 
@@ -1461,8 +1471,8 @@ static int corr_run_impl(sgz_context *ctx, int file_begin, int file_end, int mod
     // an earlier run over some of these files (possibly on the other stream) writes the same outputs
     for (const auto &run : ctx->runs)
         if (run.fb < file_end && run.fe > file_begin) SGZ_HIP(ctx, hipStreamWaitEvent(stream, run.done, 0));
-    // range flags of these files: only a half-precision prep sets them
-    SGZ_HIP(ctx, hipMemsetAsync(ctx->d_hflags + file_begin, 0, sizeof(int) * (file_end - file_begin), stream));
+    // Range flags of these files: a half-precision run sets them and never clears them (they depend on the
+    // frames, the norms and the target only: cleared when one of those changes), any other run clears them.
     if (exact)
         hipLaunchKernelGGL(prep_kernel<double>, dim3(pt1 - pt0), dim3(256), prepLds, stream, ctx->d_files,
                            ctx->d_ptiles + pt0, ctx->d_planar, ctx->d_prefix, ctx->d_tbase, ctx->norm, ctx->numCh, cb,
@@ -1484,9 +1494,11 @@ static int corr_run_impl(sgz_context *ctx, int file_begin, int file_end, int mod
                        file_begin, ctx->d_tbase);
     SGZ_HIP(ctx, hipGetLastError());
     const size_t corrLds = exact ? corr_lds_bytes<double>() : corr_lds_bytes<float>();
-    SGZ_HIP(ctx, hipEventRecord(ctx->ev0, stream));
+    // kernel time for sgz_corr_last_kernel_ms: the matrix-core kernel carries the two events in its own
+    // dispatch (no separate marker packets, which would each cost a few idle microseconds on the stream)
+    if (!half) SGZ_HIP(ctx, hipEventRecord(ctx->ev0, stream));
     if (half) {
-        if ((rc = half_screen_launch(ctx, t0, t1, stream))) return rc;
+        if ((rc = half_screen_launch(ctx, t0, t1, stream, ctx->ev0, ctx->ev1))) return rc;
     } else if (exact)
         hipLaunchKernelGGL(corr_kernel<double>, dim3(t1 - t0), dim3(kThreads), corrLds, stream, ctx->d_files,
                            ctx->d_tiles + t0, ctx->d_planar, ctx->d_prefix, ctx->d_tbase, ctx->d_aprime, ctx->cp,
@@ -1496,7 +1508,7 @@ static int corr_run_impl(sgz_context *ctx, int file_begin, int file_end, int mod
                            ctx->d_tiles + t0, planarF, ctx->d_prefix, ctx->d_tbase, ctx->d_aprime_f, ctx->cp,
                            ctx->d_sim, ctx->d_boost);
     SGZ_HIP(ctx, hipGetLastError());
-    SGZ_HIP(ctx, hipEventRecord(ctx->ev1, stream));
+    if (!half) SGZ_HIP(ctx, hipEventRecord(ctx->ev1, stream));
     ctx->ev_valid = true;
     if (half) {
         ctx->lo_begin = file_begin;
@@ -1566,8 +1578,11 @@ int sgz_corr_read_dense(sgz_context *ctx, int file, float *sim_out, float *boost
     return sgz_corr_read_dense_range(ctx, file, file + 1, sim_out, boost_out);
 }
 
-int sgz_corr_compact_device(sgz_context *ctx, int file_begin, int file_end, float threshold,
-                            sgz_candidate *device_out, int64_t capacity, unsigned long long *device_count)
+// `zero_other`: a second counter the kernel clears for the caller's next call; with `count_is_zero` the
+// caller vouches that device_count was cleared that way.  *launched: whether a kernel ran (and cleared it).
+static int compact_device_impl(sgz_context *ctx, int file_begin, int file_end, float threshold,
+                               sgz_candidate *device_out, int64_t capacity, unsigned long long *device_count,
+                               bool count_is_zero, unsigned long long *zero_other, bool *launched)
 {
     if (!ctx) return SGZ_E_ARG;
     if (ctx->layout_dirty || !ctx->have_target) return ctx->fail(SGZ_E_STATE, "no correlation results");
@@ -1578,19 +1593,29 @@ int sgz_corr_compact_device(sgz_context *ctx, int file_begin, int file_end, floa
     SGZ_HIP(ctx, hipSetDevice(ctx->device));
     for (const auto &run : ctx->runs)
         if (run.fb < file_end && run.fe > file_begin) SGZ_HIP(ctx, hipStreamWaitEvent(ctx->stream, run.done, 0));
-    SGZ_HIP(ctx, hipMemsetAsync(device_count, 0, sizeof(unsigned long long), ctx->stream));
+    if (!count_is_zero) SGZ_HIP(ctx, hipMemsetAsync(device_count, 0, sizeof(unsigned long long), ctx->stream));
     const int t0 = ctx->tile_begin[file_begin], t1 = ctx->tile_begin[file_end];
+    if (launched) *launched = t1 > t0;
     if (t1 > t0) {
         hipLaunchKernelGGL(compact_kernel, dim3(t1 - t0), dim3(256), 0, ctx->stream, ctx->d_files,
                            ctx->d_tiles + t0, ctx->d_sim, ctx->d_boost, threshold, device_out,
-                           (long long)capacity, device_count, ctx->d_hflags);
+                           (long long)capacity, device_count, ctx->d_hflags, zero_other);
         SGZ_HIP(ctx, hipGetLastError());
     }
     return SGZ_OK;
 }
 
-int sgz_corr_compact_bounded_device(sgz_context *ctx, int file_begin, int file_end, int head_end,
-                                    sgz_candidate *device_out, int64_t capacity, unsigned long long *device_count)
+int sgz_corr_compact_device(sgz_context *ctx, int file_begin, int file_end, float threshold,
+                            sgz_candidate *device_out, int64_t capacity, unsigned long long *device_count)
+{
+    return compact_device_impl(ctx, file_begin, file_end, threshold, device_out, capacity, device_count, false,
+                               nullptr, nullptr);
+}
+
+static int compact_bounded_device_impl(sgz_context *ctx, int file_begin, int file_end, int head_end,
+                                       sgz_candidate *device_out, int64_t capacity,
+                                       unsigned long long *device_count, bool count_is_zero,
+                                       unsigned long long *zero_other, bool *launched)
 {
     if (!ctx) return SGZ_E_ARG;
     if (ctx->layout_dirty || !ctx->have_target) return ctx->fail(SGZ_E_STATE, "no correlation results");
@@ -1605,7 +1630,7 @@ int sgz_corr_compact_bounded_device(sgz_context *ctx, int file_begin, int file_e
     SGZ_HIP(ctx, hipSetDevice(ctx->device));
     int rc;
     if ((rc = ensure(ctx, ctx->d_thr, ctx->thr_cap, (size_t)1))) return rc;
-    SGZ_HIP(ctx, hipMemsetAsync(device_count, 0, sizeof(unsigned long long), ctx->stream));
+    if (!count_is_zero) SGZ_HIP(ctx, hipMemsetAsync(device_count, 0, sizeof(unsigned long long), ctx->stream));
     for (const auto &run : ctx->runs)
         if (run.fb < need_end) SGZ_HIP(ctx, hipStreamWaitEvent(ctx->stream, run.done, 0));
     if (head_end < file_end) {  // tail files present: they are filtered by the smallest head bound
@@ -1613,13 +1638,21 @@ int sgz_corr_compact_bounded_device(sgz_context *ctx, int file_begin, int file_e
         SGZ_HIP(ctx, hipGetLastError());
     }
     const int t0 = ctx->tile_begin[file_begin], t1 = ctx->tile_begin[file_end];
+    if (launched) *launched = t1 > t0;
     if (t1 > t0) {
         hipLaunchKernelGGL(compact_bounded_kernel, dim3(t1 - t0), dim3(256), 0, ctx->stream, ctx->d_files,
                            ctx->d_tiles + t0, ctx->d_sim, ctx->d_boost, ctx->d_lokey, ctx->d_thr, head_end, device_out,
-                           (long long)capacity, device_count, ctx->d_hflags);
+                           (long long)capacity, device_count, ctx->d_hflags, zero_other);
         SGZ_HIP(ctx, hipGetLastError());
     }
     return SGZ_OK;
+}
+
+int sgz_corr_compact_bounded_device(sgz_context *ctx, int file_begin, int file_end, int head_end,
+                                    sgz_candidate *device_out, int64_t capacity, unsigned long long *device_count)
+{
+    return compact_bounded_device_impl(ctx, file_begin, file_end, head_end, device_out, capacity, device_count, false,
+                                       nullptr, nullptr);
 }
 
 int sgz_corr_rescore_device(sgz_context *ctx, sgz_candidate *device_cands, int64_t capacity,
@@ -1691,29 +1724,43 @@ static int compact_host(sgz_context *ctx, int file_begin, int file_end, float th
     if (!count || capacity < 0 || (capacity > 0 && !out)) return ctx->fail(SGZ_E_ARG, "bad output buffers");
     SGZ_HIP(ctx, hipSetDevice(ctx->device));
     int rc;
-    // device buffer = [one record-sized header holding the count][capacity records]
-    if ((rc = ensure(ctx, ctx->d_cand, ctx->cand_cap, (size_t)capacity + 1))) return rc;
-    unsigned long long *d_count = reinterpret_cast<unsigned long long *>(ctx->d_cand);
+    // device buffer = [two record-sized headers, each holding a count][capacity records].  Calls alternate
+    // between the two counters; the compaction kernel of one call clears the counter of the next, which
+    // saves a clear (and its idle time on the stream) per call.
+    const sgz_candidate *before = ctx->d_cand;
+    if ((rc = ensure(ctx, ctx->d_cand, ctx->cand_cap, (size_t)capacity + 2))) return rc;
+    if (ctx->d_cand != before) ctx->cand_clean = false;
+    unsigned long long *d_count = reinterpret_cast<unsigned long long *>(ctx->d_cand + ctx->cand_parity);
+    unsigned long long *d_other = reinterpret_cast<unsigned long long *>(ctx->d_cand + (1 - ctx->cand_parity));
+    sgz_candidate *d_rec = ctx->d_cand + 2;
+    const bool clean = ctx->cand_clean;
+    ctx->cand_clean = false;  // until this call has got as far as its kernel
+    bool launched = false;
     if (head_end > 0)
-        rc = sgz_corr_compact_bounded_device(ctx, file_begin, file_end, head_end, ctx->d_cand + 1, capacity, d_count);
+        rc = compact_bounded_device_impl(ctx, file_begin, file_end, head_end, d_rec, capacity, d_count, clean, d_other,
+                                         &launched);
     else
-        rc = sgz_corr_compact_device(ctx, file_begin, file_end, threshold, ctx->d_cand + 1, capacity, d_count);
+        rc = compact_device_impl(ctx, file_begin, file_end, threshold, d_rec, capacity, d_count, clean, d_other,
+                                 &launched);
     if (rc) return rc;
-    if (rescore && (rc = sgz_corr_rescore_device(ctx, ctx->d_cand + 1, capacity, d_count))) return rc;
-    // first transfer: header + as many records as usually suffice
-    const size_t first = (size_t)std::min<int64_t>(capacity, 1023);
+    const int parity = ctx->cand_parity;
+    ctx->cand_parity = 1 - parity;
+    ctx->cand_clean = launched;
+    if (rescore && (rc = sgz_corr_rescore_device(ctx, d_rec, capacity, d_count))) return rc;
+    // first transfer: headers + as many records as usually suffice
+    const size_t first = (size_t)std::min<int64_t>(capacity, 1022);
     if (!ctx->h_pinned) SGZ_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_pinned), sizeof(sgz_candidate) * 1024));
-    SGZ_HIP(ctx, hipMemcpyAsync(ctx->h_pinned, ctx->d_cand, sizeof(sgz_candidate) * (first + 1),
+    SGZ_HIP(ctx, hipMemcpyAsync(ctx->h_pinned, ctx->d_cand, sizeof(sgz_candidate) * (first + 2),
                                 hipMemcpyDeviceToHost, ctx->stream));
     SGZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     unsigned long long n = 0;
-    std::memcpy(&n, ctx->h_pinned, sizeof n);
+    std::memcpy(&n, ctx->h_pinned + parity, sizeof n);
     *count = (int64_t)n;
     const size_t got = (size_t)std::min<unsigned long long>(n, (unsigned long long)capacity);
     const size_t inFirst = std::min(got, first);
-    if (inFirst) std::memcpy(out, ctx->h_pinned + 1, sizeof(sgz_candidate) * inFirst);
+    if (inFirst) std::memcpy(out, ctx->h_pinned + 2, sizeof(sgz_candidate) * inFirst);
     if (got > first)
-        SGZ_HIP(ctx, hipMemcpy(out + first, ctx->d_cand + 1 + first, sizeof(sgz_candidate) * (got - first),
+        SGZ_HIP(ctx, hipMemcpy(out + first, d_rec + first, sizeof(sgz_candidate) * (got - first),
                                hipMemcpyDeviceToHost));
     std::sort(out, out + got, [](const sgz_candidate &a, const sgz_candidate &b) {
         return a.file != b.file ? a.file < b.file : a.offset < b.offset;

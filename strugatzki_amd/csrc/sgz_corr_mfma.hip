@@ -22,6 +22,7 @@
 // kernel stores is an upper bound of the similarity (window_bounds): the
 // half-precision value plus the largest error the roundings can cause for that
 // window, so a threshold test on it never loses a window.
+#include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -39,6 +40,7 @@ using half8 = __attribute__((ext_vector_type(8))) _Float16;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int kHThreads = kHWaves * 64;
+constexpr int kHSlabFloats = kHTileW + kHTileW / 8;  // one partial sum per window of a tile, skewed (see reduce)
 // Two half-precision roundings (target and database value, 2^-11 each) per product, with some room for the
 // fp32 summation.
 constexpr float kHalfRelErr = 1.0e-3f;
@@ -51,8 +53,9 @@ __host__ __device__ constexpr int half_a_pieces(int LAd) { return (LAd / 2 + 63)
 __host__ __device__ constexpr size_t half_buf_bytes(int XU, int LAd)
 {
     const size_t bytes = (size_t)1024 * (half_x_pieces(XU) + half_a_pieces(LAd) + 1);
-    // once a buffer's channel is consumed it holds one array of partial sums (kHTileW floats) and a few words
-    return bytes > (kHTileW * sizeof(float) + 1024) ? bytes : kHTileW * sizeof(float) + 1024;
+    // once a buffer's channel is consumed it holds two slabs of partial sums and a few words
+    const size_t sums = 2 * kHSlabFloats * sizeof(float) + 1024;
+    return bytes > sums ? bytes : sums;
 }
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -114,25 +117,35 @@ __global__ __launch_bounds__(kHThreads, 4) void corr_mfma_kernel(
     // where the loudness channel was.
     float4 *redS4 = reinterpret_cast<float4 *>(lds + ((cp.numCh - 2) & 1) * bufBytes);
     float4 *redT4 = reinterpret_cast<float4 *>(lds + ((cp.numCh - 1) & 1) * bufBytes);
+    // Cross-wave sum in a fixed order (results are reproducible): even waves add into one slab, odd waves into
+    // a second one, a pair per barrier round; readers add the two slabs.  Units of four windows are skewed by
+    // one unit in eight, which keeps the 16-byte accesses of eight neighbouring lanes on distinct banks.
+    auto red_unit = [](int u) { return u + (u >> 3); };
     auto reduce = [&](float4 *red, const f32x4 (&acc)[NB]) {
-        for (int wv = 0; wv < kHWaves; wv++) {
-            if (q == wv) {
+        float4 *slab = red + (q & 1) * (kHSlabFloats / 4);
+        for (int round = 0; round < kHWaves / 2; round++) {
+            if ((q >> 1) == round) {
 #pragma unroll
                 for (int t = 0; t < NB; t++) {
-                    const int idx = 64 * t + 4 * m + g;  // window 256 t + 16 m + 4 g + reg
+                    const int idx = red_unit(64 * t + 4 * m + g);  // windows 256 t + 16 m + 4 g + (0..3)
                     float4 v = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
-                    if (wv) {
-                        const float4 pv = red[idx];
+                    if (round) {
+                        const float4 pv = slab[idx];
                         v.x += pv.x;
                         v.y += pv.y;
                         v.z += pv.z;
                         v.w += pv.w;
                     }
-                    red[idx] = v;
+                    slab[idx] = v;
                 }
             }
             __syncthreads();
         }
+    };
+    auto red_read = [&](const float4 *red, int wdw) {
+        const float *f = reinterpret_cast<const float *>(red);
+        const int pos = 4 * red_unit(wdw >> 2) + (wdw & 3);
+        return f[pos] + f[kHSlabFloats + pos];
     };
 
     // phase order: the MFCC channels 1 .. numCh-1 first (one sum), the loudness channel last
@@ -226,8 +239,6 @@ __global__ __launch_bounds__(kHThreads, 4) void corr_mfma_kernel(
     cph.sumAT = hg.sumAT;
     cph.sumAS = hg.sumAS;
 
-    const float *redS = reinterpret_cast<const float *>(redS4);
-    const float *redT = reinterpret_cast<const float *>(redT4);
     float best = -INFINITY;
     int bad = 0;
 #pragma unroll
@@ -238,7 +249,7 @@ __global__ __launch_bounds__(kHThreads, 4) void corr_mfma_kernel(
             float sim, lo;
             float boost;
             const WindowCoeffs wc = window_coeffs(cph, hp, (unsigned)o, rec[k], kHalfRelErr, boost);
-            window_bounds(wc, redT[wdw], redS[wdw], sim, lo);
+            window_bounds(wc, red_read(redT4, wdw), red_read(redS4, wdw), sim, lo);
             boostOut[fd.win_off + o] = boost;
             simOut[fd.win_off + o] = sim;
             loOut[fd.win_off + o] = lo;
@@ -253,7 +264,7 @@ __global__ __launch_bounds__(kHThreads, 4) void corr_mfma_kernel(
         best = fmaxf(best, __shfl_xor(best, off, 64));
         bad |= __shfl_xor(bad, off, 64);
     }
-    float *wbest = reinterpret_cast<float *>(lds + kHTileW * sizeof(float));  // behind the sums of buffer 0
+    float *wbest = reinterpret_cast<float *>(lds) + 2 * kHSlabFloats;  // behind the sums of buffer 0
     int *wbad = reinterpret_cast<int *>(wbest) + kHWaves;
     if (lane == 0) {
         wbest[q] = best;
@@ -330,7 +341,8 @@ int half_screen_set_target(sgz_context *ctx, const std::vector<double> &aprime, 
     return SGZ_OK;
 }
 
-int half_screen_launch(sgz_context *ctx, int tile_begin, int tile_end, hipStream_t stream)
+int half_screen_launch(sgz_context *ctx, int tile_begin, int tile_end, hipStream_t stream, hipEvent_t start,
+                       hipEvent_t stop)
 {
     const HalfGeom &hg = ctx->hg;
     if (hg.S2 <= 0) return ctx->fail(SGZ_E_STATE, "half-precision screening is not available for this target");
@@ -341,9 +353,9 @@ int half_screen_launch(sgz_context *ctx, int tile_begin, int tile_end, hipStream
     if (ldsBytes > 64 * 1024)
         SGZ_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
-    hipLaunchKernelGGL(kern, dim3(tile_end - tile_begin), dim3(kHThreads), ldsBytes, stream, ctx->d_files,
-                       ctx->d_tiles_h + tile_begin, planarH, ctx->d_prefix, ctx->d_tbase, aimg, ctx->cp, hg,
-                       ctx->d_sim, ctx->d_boost, ctx->d_lo, ctx->d_lokey, ctx->d_hflags);
+    hipExtLaunchKernelGGL(kern, dim3(tile_end - tile_begin), dim3(kHThreads), ldsBytes, stream, start, stop, 0,
+                          ctx->d_files, ctx->d_tiles_h + tile_begin, planarH, ctx->d_prefix, ctx->d_tbase, aimg, ctx->cp,
+                          hg, ctx->d_sim, ctx->d_boost, ctx->d_lo, ctx->d_lokey, ctx->d_hflags);
     SGZ_HIP(ctx, hipGetLastError());
     return SGZ_OK;
 }

@@ -153,7 +153,9 @@ struct sgz_context {
     double *d_rs_part = nullptr;             // partial sums of the exact re-scoring [window][slice][6]
     size_t rs_part_cap = 0;
 
-    sgz_candidate *d_cand = nullptr;         // [count header][records]
+    sgz_candidate *d_cand = nullptr;         // [two count headers][records]
+    int cand_parity = 0;                     // which header the next compaction counts in
+    bool cand_clean = false;                 // that header is known to be zero
     size_t cand_cap = 0;
     std::vector<sgz_candidate> h_cand;
 
@@ -190,7 +192,8 @@ namespace sgz {
 // sgz_corr_mfma.hip
 bool half_screen_fits(const sgz_context *ctx);
 int half_screen_set_target(sgz_context *ctx, const std::vector<double> &aprime, size_t Lpad);
-int half_screen_launch(sgz_context *ctx, int tile_begin, int tile_end, hipStream_t stream);
+int half_screen_launch(sgz_context *ctx, int tile_begin, int tile_end, hipStream_t stream, hipEvent_t start,
+                       hipEvent_t stop);
 
 // Grows a device buffer to at least `count` elements (contents are not kept).
 template <typename T>
