@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -882,7 +883,7 @@ __global__ __launch_bounds__(kRsThreads) void rescore_pass_kernel(
     const sgz_candidate *__restrict__ cands, const unsigned long long *__restrict__ count, long long capacity,
     double *__restrict__ part /* [window][slice][kRsParts] */)
 {
-    constexpr int U = 6;
+    constexpr int U = 16;  // a slice of about 4 K values gives a thread 16: one batch
     __shared__ double scratch[4];
     const long long n = min((long long)*count, capacity);
     const long long work = n * rg.slices;
@@ -917,35 +918,27 @@ __global__ __launch_bounds__(kRsThreads) void rescore_pass_kernel(
         }
         const float *tn = tframes + (long long)f0 * numCh + tid;
         double s = 0.0, q = 0.0, x = 0.0;
-        int k = 0;
-        for (; k + U <= K; k += U) {
+        // batches of U loads in flight; the last batch repeats the thread's final value and skips it in the
+        // sums (no one-at-a-time tail: each of its loads would cost a full memory round trip)
+        for (int k = 0; k < K; k += U) {
             float v[U], af[U];
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                v[u] = raw[(k + u) * stride];
-                if (kCross) af[u] = tn[(k + u) * stride];
+                const int kk = min(k + u, K - 1);
+                v[u] = raw[kk * stride];
+                if (kCross) af[u] = tn[kk * stride];
             }
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 if (normEnabled) v[u] = (v[u] - mn) / dv;
+                const bool live = k + u < K;
                 if (kCross) {
-                    const double d = (double)v[u] - bMean;
+                    const double d = live ? (double)v[u] - bMean : 0.0;
                     q += d * d;
                     x += ((double)af[u] - aMean) * d;
                 } else {
-                    s += (double)v[u];
+                    s += live ? (double)v[u] : 0.0;
                 }
-            }
-        }
-        for (; k < K; k++) {
-            float v = raw[k * stride];
-            if (normEnabled) v = (v - mn) / dv;
-            if (kCross) {
-                const double d = (double)v - bMean;
-                q += d * d;
-                x += ((double)tn[k * stride] - aMean) * d;
-            } else {
-                s += (double)v;
             }
         }
         double *out = part + w * kRsParts;
@@ -971,10 +964,22 @@ __global__ __launch_bounds__(kRsThreads) void rescore_pass_kernel(
     }
 }
 
+// Where the last workgroup of rescore_final_kernel leaves a copy of the result for the host: pinned memory
+// the host polls, which saves a copy command and the wake-up of a blocking stream wait per search.
+struct HostReport {
+    unsigned long long *host;       // pinned: headers and records as in the device buffer; word maxWords = sequence
+    const unsigned long long *dev;  // device buffer: [two count headers][records]
+    unsigned int *done;             // device: workgroups that have finished (reset by the last one)
+    int headWords;                  // words of the headers
+    int maxWords;                   // capacity of the pinned buffer in words (headers included)
+    unsigned long long seq;         // value the host waits for
+};
+
 __global__ __launch_bounds__(256) void rescore_final_kernel(CorrParams cp, RescoreGeom rg,
                                                             sgz_candidate *__restrict__ cands,
                                                             const unsigned long long *__restrict__ count,
-                                                            long long capacity, const double *__restrict__ part)
+                                                            long long capacity, const double *__restrict__ part,
+                                                            HostReport hr)
 {
     const long long n = min((long long)*count, capacity);
     const double nT = (double)cp.L, nS = (double)cp.L * (double)(cp.numCh - 1);
@@ -995,8 +1000,27 @@ __global__ __launch_bounds__(256) void rescore_final_kernel(CorrParams cp, Resco
             if (cp.w < 1.0f) spectral = (float)(t[5] / (cp.aStdS * sqrt(t[3] / nS) * nS));
             sim = temporal * cp.w + spectral * (1.0f - cp.w);
         }
-        cands[ci].sim = sim;
-        cands[ci].boost = boost;
+        sgz_candidate c = cands[ci];
+        c.sim = sim;
+        c.boost = boost;
+        cands[ci] = c;
+        if (hr.host && hr.headWords + 2 * ci + 1 < hr.maxWords)  // every workgroup reports its own records
+            reinterpret_cast<sgz_candidate *>(hr.host + hr.headWords)[ci] = c;
+    }
+    if (!hr.host) return;
+    __shared__ int isLast;
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) isLast = atomicAdd(hr.done, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (!isLast) return;
+    // the last workgroup adds the headers and then the sequence number the host polls for
+    if ((int)threadIdx.x < hr.headWords) hr.host[threadIdx.x] = hr.dev[threadIdx.x];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        *hr.done = 0u;
+        __hip_atomic_store(hr.host + hr.maxWords, hr.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -1655,8 +1679,8 @@ int sgz_corr_compact_bounded_device(sgz_context *ctx, int file_begin, int file_e
                                        nullptr, nullptr);
 }
 
-int sgz_corr_rescore_device(sgz_context *ctx, sgz_candidate *device_cands, int64_t capacity,
-                            const unsigned long long *device_count)
+static int rescore_device_impl(sgz_context *ctx, sgz_candidate *device_cands, int64_t capacity,
+                               const unsigned long long *device_count, const HostReport &hr)
 {
     if (!ctx) return SGZ_E_ARG;
     if (ctx->layout_dirty || !ctx->have_target) return ctx->fail(SGZ_E_STATE, "no correlation results");
@@ -1689,9 +1713,16 @@ int sgz_corr_rescore_device(sgz_context *ctx, sgz_candidate *device_cands, int64
                        (long long)capacity, ctx->d_rs_part);
     SGZ_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(rescore_final_kernel, dim3((int)std::min<int64_t>((capacity + 255) / 256, 64)), dim3(256), 0,
-                       ctx->stream, ctx->cp, rg, device_cands, device_count, (long long)capacity, ctx->d_rs_part);
+                       ctx->stream, ctx->cp, rg, device_cands, device_count, (long long)capacity, ctx->d_rs_part, hr);
     SGZ_HIP(ctx, hipGetLastError());
     return SGZ_OK;
+}
+
+int sgz_corr_rescore_device(sgz_context *ctx, sgz_candidate *device_cands, int64_t capacity,
+                            const unsigned long long *device_count)
+{
+    if (!ctx) return SGZ_E_ARG;
+    return rescore_device_impl(ctx, device_cands, capacity, device_count, HostReport{});
 }
 
 static int compact_host(sgz_context *ctx, int file_begin, int file_end, float threshold, bool rescore,
@@ -1746,13 +1777,47 @@ static int compact_host(sgz_context *ctx, int file_begin, int file_end, float th
     const int parity = ctx->cand_parity;
     ctx->cand_parity = 1 - parity;
     ctx->cand_clean = launched;
-    if (rescore && (rc = sgz_corr_rescore_device(ctx, d_rec, capacity, d_count))) return rc;
     // first transfer: headers + as many records as usually suffice
-    const size_t first = (size_t)std::min<int64_t>(capacity, 1022);
-    if (!ctx->h_pinned) SGZ_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_pinned), sizeof(sgz_candidate) * 1024));
-    SGZ_HIP(ctx, hipMemcpyAsync(ctx->h_pinned, ctx->d_cand, sizeof(sgz_candidate) * (first + 2),
-                                hipMemcpyDeviceToHost, ctx->stream));
-    SGZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    constexpr size_t kPinned = 16384;  // records in the pinned buffer, the two headers included
+    const size_t first = (size_t)std::min<int64_t>(capacity, (int64_t)kPinned - 2);
+    if (!ctx->h_pinned) {  // + the sequence word of a host report
+        SGZ_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_pinned), sizeof(sgz_candidate) * (kPinned + 1)));
+        std::memset(ctx->h_pinned, 0, sizeof(sgz_candidate) * (kPinned + 1));
+    }
+    bool reported = false;
+    if (rescore && capacity > 0) {
+        // the last workgroup of the re-scoring writes headers and records to the pinned buffer and then the
+        // sequence number the host polls for
+        if ((rc = ensure(ctx, ctx->d_done, ctx->done_cap, (size_t)1))) return rc;
+        if (!ctx->done_init) {
+            SGZ_HIP(ctx, hipMemsetAsync(ctx->d_done, 0, sizeof(unsigned int), ctx->stream));
+            ctx->done_init = true;
+        }
+        HostReport hr;
+        hr.host = reinterpret_cast<unsigned long long *>(ctx->h_pinned);
+        hr.dev = reinterpret_cast<const unsigned long long *>(ctx->d_cand);
+        hr.done = ctx->d_done;
+        hr.headWords = 4;
+        hr.maxWords = 2 * (int)kPinned;
+        hr.seq = ++ctx->report_seq;
+        if ((rc = rescore_device_impl(ctx, d_rec, capacity, d_count, hr))) return rc;
+        const unsigned long long *flag = hr.host + hr.maxWords;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned long long spins = 0;; spins++) {
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == hr.seq) {
+                reported = true;
+                break;
+            }
+            if ((spins & 0xffff) == 0xffff &&
+                std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10))
+                break;  // something is wrong on the device: let the stream wait below report it
+        }
+    }
+    if (!reported) {
+        SGZ_HIP(ctx, hipMemcpyAsync(ctx->h_pinned, ctx->d_cand, sizeof(sgz_candidate) * (first + 2),
+                                    hipMemcpyDeviceToHost, ctx->stream));
+        SGZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
     unsigned long long n = 0;
     std::memcpy(&n, ctx->h_pinned + parity, sizeof n);
     *count = (int64_t)n;

@@ -154,6 +154,10 @@ struct sgz_context {
     size_t rs_part_cap = 0;
 
     sgz_candidate *d_cand = nullptr;         // [two count headers][records]
+    unsigned int *d_done = nullptr;          // workgroup counter of the host report (rescore_final_kernel)
+    size_t done_cap = 0;
+    bool done_init = false;
+    unsigned long long report_seq = 0;       // sequence number of the latest host report
     int cand_parity = 0;                     // which header the next compaction counts in
     bool cand_clean = false;                 // that header is known to be zero
     size_t cand_cap = 0;
