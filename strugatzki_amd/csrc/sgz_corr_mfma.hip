@@ -110,7 +110,7 @@ __global__ __launch_bounds__(kHThreads, 4) void corr_mfma_kernel(
     const int m = lane & 15, g = lane >> 4;
     const int hBase = 2 * m + g + 4 * q;                                              // 16-byte units
     const int aBase = (m & 1) * hg.LAd + 4 * g + 8 - ((m + 1) >> 1) + 16 * q;          // dwords
-    const int Pmax = (hg.S2 + 7) >> 3;  // steps per wave: wave q takes s = q, q + 8, ...
+    const int P = (hg.S2 - q + 7) >> 3;  // steps of this wave: s = q, q + 8, ... < S2
 
     // The cross-wave sums take the place of staged channels that have been consumed: the MFCC sum goes where
     // the last MFCC channel was (the loudness channel sits in the other buffer by then), the loudness sum
@@ -178,14 +178,14 @@ __global__ __launch_bounds__(kHThreads, 4) void corr_mfma_kernel(
             av.w = ap[3];
             return __builtin_bit_cast(half8, av);
         };
-        // Every wave runs Pmax steps (the target image is zero past its end, so surplus steps add nothing and
-        // cost no time: the other waves of the workgroup are still busy).  Straight-line blocks of NB steps:
+        // Wave q runs its P steps (the image has room for whole blocks: a request past the wave's last step
+        // reads zeros or padding and is not used).  Straight-line blocks of NB steps:
         // the target operand of the next step is requested before, the freed slot of the operand window
         // right after this step's first matrix instruction, so each wait covers exactly the reads it needs.
         half8 a[2];
         a[0] = load_a(0);
         int pb = 0;
-        for (; pb + NB <= Pmax; pb += NB) {
+        for (; pb + NB <= P; pb += NB) {
 #pragma unroll
             for (int u = 0; u < NB; u++) {
                 a[(u + 1) & 1] = load_a(pb + u + 1);  // the image has room for one step past the last
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(kHThreads, 4) void corr_mfma_kernel(
         }
 #pragma unroll
         for (int u = 0; u < NB - 1; u++) {
-            if (pb + u >= Pmax) break;
+            if (pb + u >= P) break;
             a[(u + 1) & 1] = load_a(pb + u + 1);
             __builtin_amdgcn_sched_barrier(0);
             acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u & 1], h[u], acc[0], 0, 0, 0);
