@@ -149,6 +149,10 @@ def main() -> int:
         return 2
     torch.cuda.set_device(local_rank)
     sharded = world > 1 or args.sharded
+    # stdout carries the one JSON line: RCCL prints a version banner there when it starts
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     if sharded:
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -169,7 +173,8 @@ def main() -> int:
     nplants = [N.Plant(p["file"], p["offset"], p["src_file"], p["src_offset"], p["length"], p["amp"], p["gain"])
                for p in plants]
 
-    ctx = S.Context(local_rank)
+    # sharded: the library's kernels and the RCCL exchange share one stream (no host wait between them)
+    ctx = S.Context.on_torch_stream(local_rank) if sharded else S.Context(local_rank)
     ctx.db_reset(NUM_CH)
     if sharded:
         # numPerFile = 1: no file needs to be replicated (every rank finds the exact maxima of its own files)
@@ -299,7 +304,9 @@ def main() -> int:
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(L, frames_per_file, args.cpu_seconds)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(json_fd, 1)
+        print(json.dumps(out), flush=True)
     ctx.close()
     if sharded:
         dist.barrier()

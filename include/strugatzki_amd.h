@@ -265,6 +265,14 @@ SGZ_API int sgz_sel_feed_file_punch(sgz_selector *sel, int file, int64_t num_fra
  * file that occurs in it, in ascending file order (files without candidates
  * need no call: nothing of theirs could pass the gate). */
 SGZ_API int sgz_sel_feed_candidates(sgz_selector *sel, const sgz_candidate *cands, int64_t n);
+/* sgz_sel_feed_screened over the candidate blocks several GPUs exchanged (one process per GPU, every rank
+ * holding its own files: the reference's single loop over all files, impl/FeatureCorrelationImpl.scala:152-246,
+ * cut by file).  `blocks`: world x rows records in host memory; row 0 of a block holds that rank's record
+ * count in its first 8 bytes, rows 1.. its records with rank-local file indices.  maps[map_offsets[r] + i] =
+ * global index of rank r's local file i.  SGZ_E_OVERFLOW when a rank has more records than a block holds. */
+SGZ_API int sgz_sel_feed_gathered(sgz_selector *sel, const sgz_candidate *blocks, int world, int64_t rows,
+                                  const int32_t *maps, const int64_t *map_offsets, int head_files, int num_files);
+
 /* Screening modes of sgz_corr_search. */
 #define SGZ_SCREEN_NONE 0 /* exact fp64 kernel for every file */
 #define SGZ_SCREEN_F32 1  /* sgz_corr_run_screen for the tail files */

@@ -81,6 +81,7 @@ SIGNATURES = {
     "sgz_corr_run": (C.c_int, [_vp, C.c_int, C.c_int]),
     "sgz_corr_run_screen": (C.c_int, [_vp, C.c_int, C.c_int]),
     "sgz_get_stream": (C.c_void_p, [_vp]),
+    "sgz_sel_feed_gathered": (C.c_int, [_vp, _vp, C.c_int, C.c_int64, _vp, _vp, C.c_int, C.c_int]),
     "sgz_corr_search": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int64,
                                   C.c_float, _vp, C.c_int, _vp]),
     "sgz_feature_stats": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),

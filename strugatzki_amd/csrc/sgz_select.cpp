@@ -287,6 +287,31 @@ int sgz_sel_feed_screened(sgz_selector *sel, const sgz_candidate *cands, int64_t
     return sgz_sel_feed_candidates(sel, cands + i, n - i);
 }
 
+int sgz_sel_feed_gathered(sgz_selector *sel, const sgz_candidate *blocks, int world, int64_t rows,
+                          const int32_t *maps, const int64_t *map_offsets, int head_files, int num_files)
+{
+    if (!sel || !blocks || world < 1 || rows < 1 || !maps || !map_offsets) return SGZ_E_ARG;
+    static thread_local std::vector<sgz_candidate> all;
+    all.clear();
+    for (int r = 0; r < world; r++) {
+        const sgz_candidate *blk = blocks + (size_t)r * (size_t)rows;
+        unsigned long long cnt = 0;
+        std::memcpy(&cnt, blk, sizeof cnt);  // the header row holds the count
+        if (cnt > (unsigned long long)(rows - 1)) return SGZ_E_OVERFLOW;
+        const int64_t nmap = map_offsets[r + 1] - map_offsets[r];
+        for (unsigned long long i = 0; i < cnt; i++) {
+            sgz_candidate c = blk[1 + i];
+            if (c.file < 0 || c.file >= nmap) return SGZ_E_ARG;
+            c.file = maps[map_offsets[r] + c.file];
+            all.push_back(c);
+        }
+    }
+    std::sort(all.begin(), all.end(), [](const sgz_candidate &a, const sgz_candidate &b) {
+        return a.file != b.file ? a.file < b.file : a.offset < b.offset;
+    });
+    return sgz_sel_feed_screened(sel, all.data(), (int64_t)all.size(), head_files, num_files);
+}
+
 int sgz_sel_is_full(const sgz_selector *sel)
 {
     return sel && (int)sel->all.size() >= sel->num_matches ? 1 : 0;

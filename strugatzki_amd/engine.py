@@ -24,6 +24,9 @@ def _as_frames(a: np.ndarray, num_ch: int | None = None) -> np.ndarray:
     return a
 
 
+_KEEP_STREAMS: list = []  # torch streams handed to contexts: never collected before the process ends
+
+
 class Context:
     """Owns one sgz_context (GPU `device`, optional existing HIP stream handle)."""
 
@@ -34,6 +37,20 @@ class Context:
             raise N.NativeError(rc, "sgz_create failed (no usable GPU?)")
         self._h = h
         self.num_channels = 0
+        self.torch_stream = None
+
+    @classmethod
+    def on_torch_stream(cls, device: int = 0) -> "Context":
+        """A context whose kernels run on a stream torch owns (and that stays alive until the process ends).
+        Work torch queues under `torch.cuda.stream(ctx.torch_stream)` -- an RCCL collective, a copy -- is then
+        ordered after the library's kernels on the device, without a host-side wait in between."""
+        import torch
+
+        ts = torch.cuda.Stream(device=device)
+        ctx = cls(device, ts.cuda_stream)
+        ctx.torch_stream = ts
+        _KEEP_STREAMS.append(ts)
+        return ctx
 
     def close(self) -> None:
         if self._h:
@@ -331,6 +348,20 @@ class Selector:
     @property
     def threshold(self) -> float:
         return float(lib.sgz_sel_threshold(self._h))
+
+    def feed_gathered(self, blocks: np.ndarray, world: int, rows: int, maps: np.ndarray, map_offsets: np.ndarray,
+                      head_files: int, num_files: int) -> bool | None:
+        """feed_screened over the blocks of a candidate exchange (sgz_sel_feed_gathered).  None: some rank has
+        more records than a block holds; False: the shortcut does not apply."""
+        rc = lib.sgz_sel_feed_gathered(self._h, N.ptr(blocks), world, rows, N.ptr(maps), N.ptr(map_offsets),
+                                       head_files, num_files)
+        if rc == N.SGZ_E_OVERFLOW:
+            return None
+        if rc == N.SGZ_E_STATE:
+            return False
+        if rc != N.SGZ_OK:
+            raise N.NativeError(rc, "sgz_sel_feed_gathered")
+        return True
 
     def result(self) -> list[N.Match]:
         arr = (N.Match * max(self.num_matches, 1))()

@@ -187,7 +187,7 @@ def _sort_candidates(cands: np.ndarray) -> np.ndarray:
     return cands
 
 
-def _rank_maps(ctx: Context, local_to_global: Sequence[int], group) -> list[np.ndarray]:
+def _rank_maps(ctx: Context, local_to_global: Sequence[int], group) -> dict:
     """local index -> global file id of every rank (gathered once per placement, kept on the context)."""
     import torch
     import torch.distributed as dist
@@ -206,8 +206,12 @@ def _rank_maps(ctx: Context, local_to_global: Sequence[int], group) -> list[np.n
         mine[: len(local_to_global)] = torch.tensor(list(local_to_global), dtype=torch.int32, device=dev)
         maps = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(maps, mine, group=group)
+        per_rank = [m.cpu().numpy()[: int(k.item())] for m, k in zip(maps, ns)]
+        offsets = np.zeros(world + 1, dtype=np.int64)
+        offsets[1:] = np.cumsum([len(m) for m in per_rank])
+        flat = np.ascontiguousarray(np.concatenate(per_rank) if per_rank else np.zeros(0), dtype=np.int32)
         cache.clear()
-        cache[key] = [m.cpu().numpy()[: int(k.item())] for m, k in zip(maps, ns)]
+        cache[key] = dict(per_rank=per_rank, flat=flat, offsets=offsets)
     return cache[key]
 
 
@@ -250,36 +254,48 @@ def _sharded_over_bounds(ctx: Context, p: SearchParams, local_to_global: Sequenc
     # row 0 = header (the count, written by the library), rows 1.. = records
     ctx.corr_compact_bounded_device(0, nloc, nloc, b["rec_ptr"], cap, b["count_ptr"])
     ctx.corr_rescore_device(b["rec_ptr"], cap, b["count_ptr"])
-    # (The collective runs on torch's stream after a host-side wait for the library's stream.  Queuing it on the
-    # library's stream through torch.cuda.ExternalStream saves that wait, but leaves torch and RCCL holding a
-    # stream the context destroys: the process then crashes on exit.)
-    ctx.synchronize()
-    if on_gpu:
+    ts = ctx.torch_stream
+    if on_gpu and ts is not None:
+        # the context runs on a stream torch owns (Context.on_torch_stream): collective and copy are queued
+        # behind the kernels on the device, one host-side wait at the end
+        with torch.cuda.stream(ts):
+            dist.all_gather_into_tensor(b["gathered"], b["send"], group=group)
+            b["host"].copy_(b["gathered"], non_blocking=True)
+        ts.synchronize()
+    elif on_gpu:
+        # the context owns its stream: a host-side wait, then the collective on torch's stream.  (Wrapping the
+        # library's stream in torch.cuda.ExternalStream leaves torch and RCCL holding a stream the context
+        # destroys: the process then crashes on exit.)
+        ctx.synchronize()
         dist.all_gather_into_tensor(b["gathered"], b["send"], group=group)
         b["host"].copy_(b["gathered"], non_blocking=True)
         torch.cuda.current_stream().synchronize()
     else:
+        ctx.synchronize()
         dist.all_gather_into_tensor(b["gathered"], b["send"].cpu(), group=group)
     h = b["view"]
-    counts = h[:, 0, :2].copy().view(np.int64).reshape(world)
-    if (counts > cap).any():
-        return None  # every rank sees the overflow
-    if (counts > rows - 1).any():  # rare: some rank has more records than the first exchange carries
-        full = [torch.empty_like(rec) for _ in range(world)] if on_gpu else [torch.empty((cap + 1, 4), dtype=torch.int32)
-                                                                             for _ in range(world)]
-        dist.all_gather(full, rec if on_gpu else rec.cpu(), group=group)
-        parts = [full[r][1: 1 + int(counts[r])].cpu().numpy() for r in range(world)]
-    else:
-        parts = [h[r, 1: 1 + int(counts[r])] for r in range(world)]
-    out = []
-    for r, part in enumerate(parts):
-        c = np.ascontiguousarray(part, dtype=np.int32).view(N.CANDIDATE_DTYPE).reshape(-1).copy()
-        c["file"] = maps[r][c["file"]]
-        out.append(c)
-    cands = _sort_candidates(np.concatenate(out) if out else np.zeros(0, N.CANDIDATE_DTYPE))
     sel = Selector(p.num_matches, p.num_per_file, p.min_spacing, p.step_size, ctx.target_frames)
     try:
-        return sel.result() if sel.feed_screened(cands, num_files_total, num_files_total) else None
+        # translation to global file ids, merge, sort and replay in one native call
+        ok = sel.feed_gathered(h, world, rows, maps["flat"], maps["offsets"], num_files_total, num_files_total)
+        if ok is None:  # rare: some rank has more records than the first exchange carries
+            counts = h[:, 0, :2].copy().view(np.int64).reshape(world)
+            if (counts > cap).any():
+                return None  # every rank sees the overflow
+            full = [torch.empty_like(rec) for _ in range(world)] if on_gpu else [
+                torch.empty((cap + 1, 4), dtype=torch.int32) for _ in range(world)]
+            if ts is not None:
+                ts.synchronize()
+            dist.all_gather(full, rec if on_gpu else rec.cpu(), group=group)
+            out = []
+            for r in range(world):
+                part = full[r][1: 1 + int(counts[r])].cpu().numpy()
+                c = np.ascontiguousarray(part, dtype=np.int32).view(N.CANDIDATE_DTYPE).reshape(-1).copy()
+                c["file"] = maps["per_rank"][r][c["file"]]
+                out.append(c)
+            cands = _sort_candidates(np.concatenate(out) if out else np.zeros(0, N.CANDIDATE_DTYPE))
+            ok = sel.feed_screened(cands, num_files_total, num_files_total)
+        return sel.result() if ok else None
     finally:
         sel.close()
 
