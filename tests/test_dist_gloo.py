@@ -163,6 +163,41 @@ def test_feed_screened_matches_dense_feeding():
     sel.close()
 
 
+def test_feed_gathered_equals_feed_screened_on_the_merged_list():
+    """Blocks of three ranks (files dealt round robin, rank-local file indices, unsorted records) give the
+    list the merged, sorted candidates give; a rank with more records than a block holds is reported."""
+    from strugatzki_amd import _native as N
+    from strugatzki_amd.engine import Selector, match_tuple
+    L, ts, nf, frames, world = 48, 5, 10, 300, 3
+    db = synth_db(nf, frames, make_plants(3, L, nf, frames, ts))
+    tgt = synth_target(ts, L)
+    cfg = corr_config(ts, L, num_matches=4, num_per_file=1)
+    want, sims, boosts = O.correlation_run(cfg, tgt, norms_default(), db)
+    rows = 64
+    blocks = np.zeros((world, rows, 4), dtype=np.int32)
+    per_rank = [[g for g in range(nf) if g % world == r] for r in range(world)]
+    rng = np.random.default_rng(3)
+    for r in range(world):
+        rec = []
+        for loc, g in enumerate(per_rank[r]):
+            for o in np.flatnonzero(sims[g] >= sims[g].max() - np.float32(1e-3)):
+                rec.append((loc, o, sims[g][o], boosts[g][o]))
+        rec = np.array(rec, dtype=N.CANDIDATE_DTYPE)[rng.permutation(len(rec))]
+        assert len(rec) < rows
+        blocks[r, 0, :2] = np.array([len(rec)], dtype=np.int64).view(np.int32)
+        blocks[r, 1:1 + len(rec)] = rec.view(np.int32).reshape(-1, 4)
+    flat = np.array(sum(per_rank, []), dtype=np.int32)
+    offsets = np.concatenate([[0], np.cumsum([len(x) for x in per_rank])]).astype(np.int64)
+    sel = Selector(4, 1, 0, STEP, L)
+    assert sel.feed_gathered(blocks, world, rows, flat, offsets, nf, nf) is True
+    assert [match_tuple(m) for m in sel.result()] == [O.match_tuple(w) for w in want]
+    sel.close()
+    blocks[1, 0, :2] = np.array([rows], dtype=np.int64).view(np.int32)  # more than rows - 1
+    sel = Selector(4, 1, 0, STEP, L)
+    assert sel.feed_gathered(blocks, world, rows, flat, offsets, nf, nf) is None
+    sel.close()
+
+
 def test_shard_files_partitions_the_tail():
     from strugatzki_amd.search import shard_files
     parts = [shard_files(37, 5, r, 4) for r in range(4)]
