@@ -115,8 +115,10 @@ def pmc_traffic_bytes(kernel: str):
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # a step is a third of a millisecond: the defaults run long enough for the clocks to settle (the first
+    # few dozen steps after an idle period run 5-10 % slower) and still finish in a fraction of a second
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--files-per-gpu", type=int, default=120)
     ap.add_argument("--file-seconds", type=float, default=300.0)
     ap.add_argument("--target-seconds", type=float, default=30.0)
@@ -228,11 +230,16 @@ def main() -> int:
         ts = time.perf_counter()
         matches = step()
         step_ms.append((time.perf_counter() - ts) * 1e3)
-        kernel_ms.append(ctx.corr_last_kernel_ms())
+        if mode != "f16":  # several runs per step: the tail launch is the last one
+            kernel_ms.append(ctx.corr_last_kernel_ms())
     if os.environ.get("SGZ_DEBUG"):
         print("step ms:", " ".join(f"{x:.2f}" for x in step_ms), file=sys.stderr)
     sync()
     elapsed = time.perf_counter() - t0
+    # HIP events travel with every launch of the dominant kernel in the timed region; they are read here, after
+    # it (a host-side wait on them between steps would sit inside the timed region)
+    if mode == "f16":  # one run per step
+        kernel_ms = [float(x) for x in ctx.kernel_ms_history(args.steps) if x > 0]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -227,6 +227,10 @@ SGZ_API float sgz_corr_last_kernel_ms(sgz_context *ctx);
 /* Same clock for whichever timed kernel ran last on the context (correlation or
  * extraction). */
 SGZ_API float sgz_last_kernel_ms(sgz_context *ctx);
+/* The kernel times (ms) of the latest runs that record one (sgz_corr_run*, sgz_extract), oldest first: at most n,
+ * at most 256; returns how many.  Lets a measuring caller read the events of many runs after its timed
+ * region instead of waiting on them between runs.  No counterpart in the reference (instrumentation). */
+SGZ_API int sgz_kernel_ms_history(sgz_context *ctx, float *out, int n);
 /* Algorithmic work of the last sgz_corr_run: windows and floating point
  * operations (2 * numCh * L per window for the cross term). */
 SGZ_API int sgz_corr_last_work(const sgz_context *ctx, int64_t *windows, double *flops);

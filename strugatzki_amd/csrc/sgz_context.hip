@@ -58,11 +58,48 @@ void sgz_destroy(sgz_context *ctx)
     for (auto &e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->screen_stream) (void)hipStreamDestroy(ctx->screen_stream);
-    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
-    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    for (auto &pr : ctx->ev_ring) {
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
+
+}  // extern "C"
+
+int sgz_context::next_event_pair()
+{
+    constexpr size_t kRing = 256;
+    if (ev_ring.empty()) {
+        ev_ring.reserve(kRing);
+        for (size_t i = 0; i < kRing; i++) {
+            hipEvent_t a = nullptr, b = nullptr;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess)
+                return fail(SGZ_E_HIP, "hipEventCreate");
+            ev_ring.emplace_back(a, b);
+        }
+        ev_pos = kRing - 1;
+    }
+    ev_pos = (ev_pos + 1) % ev_ring.size();
+    ev0 = ev_ring[ev_pos].first;
+    ev1 = ev_ring[ev_pos].second;
+    ev_valid = false;
+    return SGZ_OK;
+}
+
+int sgz_context::wait_for_run(Run &run, hipStream_t consumer)
+{
+    if (run.stream == consumer) return SGZ_OK;
+    if (!run.recorded) {  // recorded now, it also covers what the run's stream was given since: still correct
+        if (hipEventRecord(run.done, run.stream) != hipSuccess) return fail(SGZ_E_HIP, "hipEventRecord");
+        run.recorded = true;
+    }
+    if (hipStreamWaitEvent(consumer, run.done, 0) != hipSuccess) return fail(SGZ_E_HIP, "hipStreamWaitEvent");
+    return SGZ_OK;
+}
+
+extern "C" {
 
 const char *sgz_last_error(const sgz_context *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 

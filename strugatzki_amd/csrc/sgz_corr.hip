@@ -1465,10 +1465,6 @@ static int corr_run_impl(sgz_context *ctx, int file_begin, int file_end, int mod
     SGZ_HIP(ctx, hipSetDevice(ctx->device));
     int rc;
     if (ctx->layout_dirty && (rc = build_layout(ctx))) return rc;
-    if (!ctx->ev0) {
-        SGZ_HIP(ctx, hipEventCreate(&ctx->ev0));
-        SGZ_HIP(ctx, hipEventCreate(&ctx->ev1));
-    }
     ctx->ev_valid = false;
     ctx->last_windows = 0;
     ctx->last_flops = 0.0;
@@ -1484,6 +1480,7 @@ static int corr_run_impl(sgz_context *ctx, int file_begin, int file_end, int mod
     ctx->last_flops = (double)wins * 2.0 * ctx->cp.numCh * ctx->cp.L;
     if (t1 == t0) return SGZ_OK;
 
+    if ((rc = ctx->next_event_pair())) return rc;
     const int cb = ctx->prep_cb;
     const size_t prepLds = (size_t)ctx->numCh * (kR * (cb + 1) + 1) * sizeof(float);
     // The screening path has its own planar image (fp32) and its own stream, so that a screening run
@@ -1493,8 +1490,8 @@ static int corr_run_impl(sgz_context *ctx, int file_begin, int file_end, int mod
     // stream, and its consumers on ctx->stream then need no cross-stream wait)
     hipStream_t stream = mode == kRunScreenF32 ? ctx->screen_stream : ctx->stream;
     // an earlier run over some of these files (possibly on the other stream) writes the same outputs
-    for (const auto &run : ctx->runs)
-        if (run.fb < file_end && run.fe > file_begin) SGZ_HIP(ctx, hipStreamWaitEvent(stream, run.done, 0));
+    for (auto &run : ctx->runs)
+        if (run.fb < file_end && run.fe > file_begin && (rc = ctx->wait_for_run(run, stream))) return rc;
     // Range flags of these files: a half-precision run sets them and never clears them (they depend on the
     // frames, the norms and the target only: cleared when one of those changes), any other run clears them.
     if (exact)
@@ -1534,6 +1531,7 @@ static int corr_run_impl(sgz_context *ctx, int file_begin, int file_end, int mod
     SGZ_HIP(ctx, hipGetLastError());
     if (!half) SGZ_HIP(ctx, hipEventRecord(ctx->ev1, stream));
     ctx->ev_valid = true;
+    ctx->ev_runs++;
     if (half) {
         ctx->lo_begin = file_begin;
         ctx->lo_end = file_end;
@@ -1552,7 +1550,8 @@ static int corr_run_impl(sgz_context *ctx, int file_begin, int file_end, int mod
         } else {
             SGZ_HIP(ctx, hipEventCreateWithFlags(&run.done, hipEventDisableTiming));
         }
-        SGZ_HIP(ctx, hipEventRecord(run.done, stream));
+        run.stream = stream;
+        run.recorded = false;
         // a newer run over the same files supersedes older markers
         for (size_t i = 0; i < ctx->runs.size();) {
             if (ctx->runs[i].fb >= file_begin && ctx->runs[i].fe <= file_end) {
@@ -1577,9 +1576,10 @@ int sgz_corr_read_dense_range(sgz_context *ctx, int file_begin, int file_end, fl
     SGZ_HIP(ctx, hipSetDevice(ctx->device));
     // wait (on the copy stream only) for the runs that produced these files
     bool covered = false;
-    for (const auto &run : ctx->runs) {
+    for (auto &run : ctx->runs) {
         if (run.fb < file_end && run.fe > file_begin) {
-            SGZ_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, run.done, 0));
+            const int wrc = ctx->wait_for_run(run, ctx->copy_stream);
+            if (wrc) return wrc;
             covered = true;
         }
     }
@@ -1615,8 +1615,11 @@ static int compact_device_impl(sgz_context *ctx, int file_begin, int file_end, f
     if (!device_count || capacity < 0 || (capacity > 0 && !device_out))
         return ctx->fail(SGZ_E_ARG, "bad output buffers");
     SGZ_HIP(ctx, hipSetDevice(ctx->device));
-    for (const auto &run : ctx->runs)
-        if (run.fb < file_end && run.fe > file_begin) SGZ_HIP(ctx, hipStreamWaitEvent(ctx->stream, run.done, 0));
+    for (auto &run : ctx->runs)
+        if (run.fb < file_end && run.fe > file_begin) {
+            const int wrc = ctx->wait_for_run(run, ctx->stream);
+            if (wrc) return wrc;
+        }
     if (!count_is_zero) SGZ_HIP(ctx, hipMemsetAsync(device_count, 0, sizeof(unsigned long long), ctx->stream));
     const int t0 = ctx->tile_begin[file_begin], t1 = ctx->tile_begin[file_end];
     if (launched) *launched = t1 > t0;
@@ -1655,8 +1658,8 @@ static int compact_bounded_device_impl(sgz_context *ctx, int file_begin, int fil
     int rc;
     if ((rc = ensure(ctx, ctx->d_thr, ctx->thr_cap, (size_t)1))) return rc;
     if (!count_is_zero) SGZ_HIP(ctx, hipMemsetAsync(device_count, 0, sizeof(unsigned long long), ctx->stream));
-    for (const auto &run : ctx->runs)
-        if (run.fb < need_end) SGZ_HIP(ctx, hipStreamWaitEvent(ctx->stream, run.done, 0));
+    for (auto &run : ctx->runs)
+        if (run.fb < need_end && (rc = ctx->wait_for_run(run, ctx->stream))) return rc;
     if (head_end < file_end) {  // tail files present: they are filtered by the smallest head bound
         hipLaunchKernelGGL(bound_min_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->d_lokey, head_end, ctx->d_thr);
         SGZ_HIP(ctx, hipGetLastError());
@@ -1845,6 +1848,22 @@ float sgz_corr_last_kernel_ms(sgz_context *ctx)
 }
 
 float sgz_last_kernel_ms(sgz_context *ctx) { return sgz_corr_last_kernel_ms(ctx); }
+
+int sgz_kernel_ms_history(sgz_context *ctx, float *out, int n)
+{
+    if (!ctx || n < 0 || (n > 0 && !out)) return SGZ_E_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return SGZ_E_HIP;
+    const size_t ring = ctx->ev_ring.size();
+    const size_t have = std::min<size_t>({(size_t)n, ctx->ev_runs, ring});
+    for (size_t k = 0; k < have; k++) {  // oldest first
+        const auto &pr = ctx->ev_ring[(ctx->ev_pos + ring - (have - 1 - k)) % ring];
+        float ms = -1.0f;
+        if (hipEventSynchronize(pr.second) != hipSuccess || hipEventElapsedTime(&ms, pr.first, pr.second) != hipSuccess)
+            ms = -1.0f;
+        out[k] = ms;
+    }
+    return (int)have;
+}
 
 int sgz_corr_last_work(const sgz_context *ctx, int64_t *windows, double *flops)
 {

@@ -275,9 +275,9 @@ int sgz_extract(sgz_context *ctx, const float *pcm, int64_t num_frames, int num_
     SGZ_HIP(ctx, hipMemcpyAsync(dTw.p, tw.data(), sizeof(float2) * tw.size(), hipMemcpyHostToDevice, ctx->stream));
     SGZ_HIP(ctx, hipMemcpyAsync(dHann.p, hann.data(), sizeof(float) * hann.size(), hipMemcpyHostToDevice, ctx->stream));
     SGZ_HIP(ctx, hipMemcpyAsync(dDct.p, dct.data(), sizeof(float) * dct.size(), hipMemcpyHostToDevice, ctx->stream));
-    if (!ctx->ev0) {
-        SGZ_HIP(ctx, hipEventCreate(&ctx->ev0));
-        SGZ_HIP(ctx, hipEventCreate(&ctx->ev1));
+    {
+        const int erc = ctx->next_event_pair();
+        if (erc) return erc;
     }
     const size_t lds = sizeof(float2) * (size_t)kFramesPerBlock * (M + 8);
     const unsigned grid = (unsigned)((nOut + kFramesPerBlock - 1) / kFramesPerBlock);
@@ -288,6 +288,7 @@ int sgz_extract(sgz_context *ctx, const float *pcm, int64_t num_frames, int num_
     SGZ_HIP(ctx, hipGetLastError());
     SGZ_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     ctx->ev_valid = true;
+    ctx->ev_runs++;
     SGZ_HIP(ctx, hipMemcpyAsync(features_out, dOut.p, outBytes, hipMemcpyDeviceToHost, ctx->stream));
     SGZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return SGZ_OK;

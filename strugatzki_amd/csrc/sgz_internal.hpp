@@ -5,6 +5,7 @@
 
 #include <cstdint>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "strugatzki_amd.h"
@@ -167,14 +168,22 @@ struct sgz_context {
     struct Run {
         int fb, fe;
         hipEvent_t done;
+        hipStream_t stream;  // where it ran: later work on the same stream needs no wait
+        bool recorded;       // `done` is recorded only when work on another stream first asks for it
     };
+    int wait_for_run(Run &run, hipStream_t consumer);  // makes `consumer` wait for the run (no-op on its stream)
     std::vector<Run> runs;
     std::vector<hipEvent_t> event_pool;
     hipStream_t copy_stream = nullptr;       // device-to-host result copies
     hipStream_t screen_stream = nullptr;     // screening runs (overlap with exact runs on `stream`)
 
+    // Kernel timing: a ring of event pairs, one pair per run (ev0 / ev1 = the pair of the latest run), so that
+    // a caller can read the times of many runs after the fact instead of waiting on events between them.
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_ring;
+    size_t ev_pos = 0, ev_runs = 0;          // ring slot of the latest run; runs recorded since creation
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
+    int next_event_pair();                   // advances the ring (created on first use); SGZ_* code
     long long last_windows = 0;
     double last_flops = 0.0;
 

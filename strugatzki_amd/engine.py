@@ -208,6 +208,14 @@ class Context:
     def corr_last_kernel_ms(self) -> float:
         return float(lib.sgz_corr_last_kernel_ms(self._h))
 
+    def kernel_ms_history(self, n: int) -> np.ndarray:
+        """Kernel times (ms) of the latest n runs, oldest first (HIP events recorded with each run)."""
+        out = np.zeros(max(n, 1), dtype=np.float32)
+        got = lib.sgz_kernel_ms_history(self._h, N.ptr(out), n)
+        if got < 0:
+            self._check(got)
+        return out[:got]
+
     def corr_last_work(self) -> tuple[int, float]:
         w = C.c_int64(0)
         f = C.c_double(0.0)
