@@ -32,7 +32,8 @@ def main() -> int:
         tail = [g for g in range(q["num_matches"], q["nf"]) if (g - q["num_matches"]) % world == rank]
     else:                  # nothing replicated
         head, tail = [], [g for g in range(q["nf"]) if g % world == rank]
-    ctx = S.Context(0)
+    # the RCCL runs use a context on a torch-owned stream (what bench.py does), the gloo runs one with its own
+    ctx = S.Context.on_torch_stream(0) if backend == "nccl" else S.Context(0)
     ctx.db_reset(db[0].shape[1])
     for g in head + tail:
         ctx.db_add_file(db[g])
