@@ -206,6 +206,50 @@ def test_search_screened_equals_exact(ctx, screen):
         assert abs(g.sim - w.sim) <= 1.2e-7
 
 
+@pytest.mark.parametrize("case", ["flat_stretches", "large_values", "offset_channels", "steps"])
+def test_bounds_hold_on_awkward_data(ctx, case):
+    """The half-precision bounds on data built to stress them: stretches with almost no spread (the variance
+    term of the bound), normalised values in the hundreds (half-precision range, large prefix sums in the fp32
+    records), channel means far from the target's (the dm / sd term), level steps.  The upper bound stays
+    above the oracle's similarity everywhere the boost gate is open, and the search over bounds returns the
+    exact search's list."""
+    import strugatzki_amd as S
+    L, ts, nf, frames = 200, 11, 6, 3000
+    rng = np.random.default_rng(99)
+    db = synth_db(nf, frames, make_plants(3, L, nf, frames, ts))
+    norms = norms_default()
+    for f in range(nf):
+        x = db[f]
+        if case == "flat_stretches":
+            for a in range(100, frames - 600, 700):
+                x[a:a + 450] = x[a] + (rng.random((450, x.shape[1])) * 1e-4).astype(np.float32)
+        elif case == "large_values":
+            x *= np.float32(300.0)
+            x[:, 0] = np.abs(x[:, 0]) + np.float32(1.0)
+        elif case == "offset_channels":
+            x[:, 1:] += np.linspace(0.0, 5.0, x.shape[1] - 1, dtype=np.float32)
+        elif case == "steps":
+            x[frames // 3:] += np.float32(2.0)
+            x[2 * frames // 3:] -= np.float32(3.5)
+            x[:, 0] = np.abs(x[:, 0]) + np.float32(0.05)
+    tgt = synth_target(ts, L)
+    cfg = corr_config(ts, L, num_matches=4, num_per_file=1)
+    want, sims, boosts = O.correlation_run(cfg, tgt, norms, db)
+    _load(ctx, db, norms)
+    ctx.corr_set_target(tgt[ts:ts + L], 0.5, 8.0)
+    assert ctx.screen_f16_available
+    ctx.corr_run_screen_f16(0, nf)
+    for f in range(nf):
+        gs, _ = ctx.corr_read_dense(f)
+        ok = np.isfinite(sims[f]) & (boosts[f] <= 8.0 * (1 - 1e-4))
+        assert np.all(gs[ok].astype(np.float64) >= sims[f][ok])
+    got = S.search(ctx, S.SearchParams(4, 1, 0, STEP))
+    exact = S.search(ctx, S.SearchParams(4, 1, 0, STEP, screen=False))
+    from strugatzki_amd.engine import match_tuple
+    assert [match_tuple(g) for g in got] == [match_tuple(e) for e in exact]
+    assert [(g.file, g.start, g.stop) for g in got] == [(w.file, w.start, w.stop) for w in want]
+
+
 @pytest.mark.parametrize("case", ["duplicate_head_files", "short_head_file", "single_file", "fewer_files_than_matches"])
 def test_search_over_bounds_and_its_fallbacks(ctx, case):
     """numPerFile = 1 with f16 screening searches over bounds; cases it cannot decide go to the exact path."""
