@@ -206,6 +206,34 @@ def test_search_screened_equals_exact(ctx, screen):
         assert abs(g.sim - w.sim) <= 1.2e-7
 
 
+@pytest.mark.parametrize("num_ch", [2, 9, 21, 41])
+def test_other_channel_counts(ctx, num_ch):
+    """numCoeffs other than the default 13: the general preparation kernels (exact and half precision), dense
+    parity, the upper bound, and the search over bounds against the oracle."""
+    import strugatzki_amd as S
+    L, ts, nf, frames = 120, 9, 5, 1500
+    db = synth_db(nf, frames, make_plants(3, L, nf, frames, ts), num_ch=num_ch)
+    tgt = synth_target(ts, L, num_ch=num_ch)
+    norms = norms_default(num_ch)
+    cfg = corr_config(ts, L, num_matches=3, num_per_file=1, num_ch=num_ch)
+    want, sims, boosts = O.correlation_run(cfg, tgt, norms, db)
+    _load(ctx, db, norms)
+    ctx.corr_set_target(tgt[ts:ts + L], 0.5, 8.0)
+    for f, (gs, gb) in enumerate(_gpu_dense(ctx, nf)):
+        assert float(np.max(np.abs(gs - sims[f]))) < 1e-5
+    assert ctx.screen_f16_available
+    ctx.corr_run_screen_f16(0, nf)
+    for f in range(nf):
+        gs, gb = ctx.corr_read_dense(f)
+        open_ = boosts[f] <= 8.0 * (1 - 1e-4)
+        assert np.all(gs[open_].astype(np.float64) >= sims[f][open_])
+        np.testing.assert_allclose(gb, boosts[f], rtol=1e-5, atol=0)
+    got = S.search(ctx, S.SearchParams(3, 1, 0, STEP))
+    assert [(g.file, g.start, g.stop) for g in got] == [(w.file, w.start, w.stop) for w in want]
+    for g, w in zip(got, want):
+        assert abs(g.sim - w.sim) <= 1.2e-7
+
+
 @pytest.mark.parametrize("case", ["flat_stretches", "large_values", "offset_channels", "steps"])
 def test_bounds_hold_on_awkward_data(ctx, case):
     """The half-precision bounds on data built to stress them: stretches with almost no spread (the variance
