@@ -88,7 +88,12 @@ struct HalfPrefix {
     const double *tbase;  // 4 arrays of `nptiles` tile bases
     long long nptiles;
     int tileShift;
+    // optional: the tile bases a workgroup's windows can touch, staged in LDS by the caller --
+    // tab[(2 q + e) * kHalfTabTiles + j] = base of moment q of tile (e ? hi0 : lo0) + j
+    const double *tab;
+    unsigned lo0, hi0;
 };
+constexpr int kHalfTabTiles = 6;
 
 // The two prefix records of window o (no branch around the loads; fetched ahead of their use).
 struct WindowRecords {
@@ -110,8 +115,13 @@ __device__ __forceinline__ WindowCoeffs window_coeffs(const CorrParams &cp, cons
     double bh[4], bl[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        bh[q] = hp.tbase[q * hp.nptiles + th];
-        bl[q] = hp.tbase[q * hp.nptiles + tl];
+        if (hp.tab) {
+            bh[q] = hp.tab[(2 * q + 1) * kHalfTabTiles + (th - hp.hi0)];
+            bl[q] = hp.tab[(2 * q) * kHalfTabTiles + (tl - hp.lo0)];
+        } else {
+            bh[q] = hp.tbase[q * hp.nptiles + th];
+            bl[q] = hp.tbase[q * hp.nptiles + tl];
+        }
     }
     const bool first = o == 0;  // nothing to subtract
     const float phv[4] = {ph.x, ph.y, ph.z, ph.w}, plv[4] = {pl.x, pl.y, pl.z, pl.w};

@@ -228,6 +228,18 @@ __global__ __launch_bounds__(kHThreads, 4) void corr_mfma_kernel(
     hp.tbase = tbase + fd.tbase_off;
     hp.nptiles = fd.nptiles;
     hp.tileShift = cp.prepTileShift;
+    hp.tab = nullptr;
+    // The tile bases this tile's windows can touch (a handful per moment and window end) go through LDS: one
+    // fetch per workgroup, in flight during the reduction, instead of eight per window.
+    const bool useTab = (kHTileW >> cp.prepTileShift) + 2 <= kHalfTabTiles;
+    hp.lo0 = (unsigned)(td.o0 > 0 ? td.o0 - 1 : 0) >> cp.prepTileShift;
+    hp.hi0 = (unsigned)(td.o0 + cp.L - 1) >> cp.prepTileShift;
+    double tabValue = 0.0;
+    if (useTab && tid < 8 * kHalfTabTiles) {
+        const int mq = tid / (2 * kHalfTabTiles), e = (tid / kHalfTabTiles) & 1, j = tid % kHalfTabTiles;
+        const long long tile = min((long long)(e ? hp.hi0 : hp.lo0) + j, (long long)fd.nptiles - 1);
+        tabValue = hp.tbase[mq * fd.nptiles + tile];
+    }
     WindowRecords rec[kPerThread];
 #pragma unroll
     for (int k = 0; k < kPerThread; k++) {
@@ -235,6 +247,12 @@ __global__ __launch_bounds__(kHThreads, 4) void corr_mfma_kernel(
         rec[k] = window_records(hp, o < fd.num_windows ? (unsigned)o : 0u, cp.L);
     }
     reduce(redT4, acc);
+    if (useTab) {  // behind the two slabs of the loudness sums
+        double *tab = reinterpret_cast<double *>(redT4) + kHSlabFloats;
+        if (tid < 8 * kHalfTabTiles) tab[tid] = tabValue;
+        __syncthreads();
+        hp.tab = tab;
+    }
     CorrParams cph = cp;  // the statistics of the half-precision target image
     cph.sumAT = hg.sumAT;
     cph.sumAS = hg.sumAS;
@@ -264,7 +282,7 @@ __global__ __launch_bounds__(kHThreads, 4) void corr_mfma_kernel(
         best = fmaxf(best, __shfl_xor(best, off, 64));
         bad |= __shfl_xor(bad, off, 64);
     }
-    float *wbest = reinterpret_cast<float *>(lds) + 2 * kHSlabFloats;  // behind the sums of buffer 0
+    float *wbest = reinterpret_cast<float *>(lds) + 2 * kHSlabFloats + 128;  // behind the sums (and a table) of buffer 0
     int *wbad = reinterpret_cast<int *>(wbest) + kHWaves;
     if (lane == 0) {
         wbest[q] = best;
