@@ -171,7 +171,8 @@ def _to_global_ids(rec, cnt, cap: int, local_to_global: Sequence[int], dev) -> N
         rec[:n_local, 0] = lut[rec[:n_local, 0].long()]
 
 
-_EXCHANGE_ROWS = 4095  # candidate rows that travel in the first (usually only) all-gather, plus one header row
+_EXCHANGE_ROWS = 1023  # candidate rows that travel in the first (usually only) all-gather, plus one header row:
+# 16 KiB per rank (a search over bounds yields 2-3 records per file)
 
 
 def _sort_candidates(cands: np.ndarray) -> np.ndarray:
@@ -238,7 +239,7 @@ def _exchange_buffers(ctx: Context, cap: int, world: int, on_gpu: bool):
 def _sharded_over_bounds(ctx: Context, p: SearchParams, local_to_global: Sequence[int], num_files_total: int,
                          group=None) -> list[N.Match] | None:
     """numPerFile = 1 (see _search_over_bounds): every rank finds the exact maxima of its own files, the
-    ranks exchange them (one all-gather of the first 4095 records + a header holding the count; a second,
+    ranks exchange them (one all-gather of the first 1023 records + a header holding the count; a second,
     full one only if some rank has more) and replay the selection over all files in global order."""
     import torch
     import torch.distributed as dist
