@@ -1009,9 +1009,12 @@ __global__ __launch_bounds__(256) void rescore_final_kernel(CorrParams cp, Resco
     }
     if (!hr.host) return;
     __shared__ int isLast;
-    __threadfence_system();
     __syncthreads();
-    if (threadIdx.x == 0) isLast = atomicAdd(hr.done, 1u) == gridDim.x - 1;
+    if (threadIdx.x == 0) {
+        __threadfence_system();  // one release for the workgroup's records (a fence per thread costs a cache
+                                 // write-back each)
+        isLast = atomicAdd(hr.done, 1u) == gridDim.x - 1;
+    }
     __syncthreads();
     if (!isLast) return;
     // the last workgroup adds the headers and then the sequence number the host polls for
