@@ -1018,8 +1018,10 @@ __global__ __launch_bounds__(256) void rescore_final_kernel(CorrParams cp, Resco
     __syncthreads();
     if (!isLast) return;
     // the last workgroup adds the headers and then the sequence number the host polls for
-    if ((int)threadIdx.x < hr.headWords) hr.host[threadIdx.x] = hr.dev[threadIdx.x];
-    __threadfence_system();
+    if ((int)threadIdx.x < hr.headWords) {
+        hr.host[threadIdx.x] = hr.dev[threadIdx.x];
+        __threadfence_system();
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         *hr.done = 0u;
