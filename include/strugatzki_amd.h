@@ -227,6 +227,10 @@ SGZ_API float sgz_corr_last_kernel_ms(sgz_context *ctx);
 /* Same clock for whichever timed kernel ran last on the context (correlation or
  * extraction). */
 SGZ_API float sgz_last_kernel_ms(sgz_context *ctx);
+/* Which sgz_corr_run* calls carry a pair of timing events: every call (every = 1, the default), every n-th
+ * call (every = n), none (every = 0).  The events of the matrix-core kernel travel with its dispatch, but
+ * still cost a few microseconds of a 0.3 ms search.  No counterpart in the reference (instrumentation). */
+SGZ_API int sgz_set_kernel_timing(sgz_context *ctx, int every);
 /* The kernel times (ms) of the latest runs that record one (sgz_corr_run*, sgz_extract), oldest first: at most n,
  * at most 256; returns how many.  Lets a measuring caller read the events of many runs after its timed
  * region instead of waiting on them between runs.  No counterpart in the reference (instrumentation). */

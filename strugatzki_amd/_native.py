@@ -100,6 +100,7 @@ SIGNATURES = {
     "sgz_corr_last_kernel_ms": (C.c_float, [_vp]),
     "sgz_last_kernel_ms": (C.c_float, [_vp]),
     "sgz_kernel_ms_history": (C.c_int, [_vp, _vp, C.c_int]),
+    "sgz_set_kernel_timing": (C.c_int, [_vp, C.c_int]),
     "sgz_corr_last_work": (C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "sgz_sel_create": (_vp, [C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int]),
     "sgz_sel_destroy": (None, [_vp]),

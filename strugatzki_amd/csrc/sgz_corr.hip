@@ -1485,7 +1485,9 @@ static int corr_run_impl(sgz_context *ctx, int file_begin, int file_end, int mod
     ctx->last_flops = (double)wins * 2.0 * ctx->cp.numCh * ctx->cp.L;
     if (t1 == t0) return SGZ_OK;
 
-    if ((rc = ctx->next_event_pair())) return rc;
+    // kernel timing: every run, or one run in timing_every (sgz_set_kernel_timing)
+    const bool timed = ctx->timing_every > 0 && (ctx->timing_count++ % ctx->timing_every) == 0;
+    if (timed && (rc = ctx->next_event_pair())) return rc;
     const int cb = ctx->prep_cb;
     const size_t prepLds = (size_t)ctx->numCh * (kR * (cb + 1) + 1) * sizeof(float);
     // The screening path has its own planar image (fp32) and its own stream, so that a screening run
@@ -1522,9 +1524,10 @@ static int corr_run_impl(sgz_context *ctx, int file_begin, int file_end, int mod
     const size_t corrLds = exact ? corr_lds_bytes<double>() : corr_lds_bytes<float>();
     // kernel time for sgz_corr_last_kernel_ms: the matrix-core kernel carries the two events in its own
     // dispatch (no separate marker packets, which would each cost a few idle microseconds on the stream)
-    if (!half) SGZ_HIP(ctx, hipEventRecord(ctx->ev0, stream));
+    if (!half && timed) SGZ_HIP(ctx, hipEventRecord(ctx->ev0, stream));
     if (half) {
-        if ((rc = half_screen_launch(ctx, t0, t1, stream, ctx->ev0, ctx->ev1))) return rc;
+        if ((rc = half_screen_launch(ctx, t0, t1, stream, timed ? ctx->ev0 : nullptr, timed ? ctx->ev1 : nullptr)))
+            return rc;
     } else if (exact)
         hipLaunchKernelGGL(corr_kernel<double>, dim3(t1 - t0), dim3(kThreads), corrLds, stream, ctx->d_files,
                            ctx->d_tiles + t0, ctx->d_planar, ctx->d_prefix, ctx->d_tbase, ctx->d_aprime, ctx->cp,
@@ -1534,9 +1537,11 @@ static int corr_run_impl(sgz_context *ctx, int file_begin, int file_end, int mod
                            ctx->d_tiles + t0, planarF, ctx->d_prefix, ctx->d_tbase, ctx->d_aprime_f, ctx->cp,
                            ctx->d_sim, ctx->d_boost);
     SGZ_HIP(ctx, hipGetLastError());
-    if (!half) SGZ_HIP(ctx, hipEventRecord(ctx->ev1, stream));
-    ctx->ev_valid = true;
-    ctx->ev_runs++;
+    if (!half && timed) SGZ_HIP(ctx, hipEventRecord(ctx->ev1, stream));
+    if (timed) {
+        ctx->ev_valid = true;
+        ctx->ev_runs++;
+    }
     if (half) {
         ctx->lo_begin = file_begin;
         ctx->lo_end = file_end;
@@ -1854,6 +1859,14 @@ float sgz_corr_last_kernel_ms(sgz_context *ctx)
 }
 
 float sgz_last_kernel_ms(sgz_context *ctx) { return sgz_corr_last_kernel_ms(ctx); }
+
+int sgz_set_kernel_timing(sgz_context *ctx, int every)
+{
+    if (!ctx || every < 0) return SGZ_E_ARG;
+    ctx->timing_every = every;
+    ctx->timing_count = 0;
+    return SGZ_OK;
+}
 
 int sgz_kernel_ms_history(sgz_context *ctx, float *out, int n)
 {

@@ -183,6 +183,8 @@ struct sgz_context {
     size_t ev_pos = 0, ev_runs = 0;          // ring slot of the latest run; runs recorded since creation
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
+    int timing_every = 1;                    // 0: runs record no events; n: every n-th run does
+    unsigned long long timing_count = 0;
     int next_event_pair();                   // advances the ring (created on first use); SGZ_* code
     long long last_windows = 0;
     double last_flops = 0.0;

@@ -208,6 +208,10 @@ class Context:
     def corr_last_kernel_ms(self) -> float:
         return float(lib.sgz_corr_last_kernel_ms(self._h))
 
+    def set_kernel_timing(self, every: int) -> None:
+        """Timing events with every run (1, the default), every n-th run (n) or none (0)."""
+        self._check(lib.sgz_set_kernel_timing(self._h, every))
+
     def kernel_ms_history(self, n: int) -> np.ndarray:
         """Kernel times (ms) of the latest n runs, oldest first (HIP events recorded with each run)."""
         out = np.zeros(max(n, 1), dtype=np.float32)
