@@ -1814,6 +1814,11 @@ static int compact_host(sgz_context *ctx, int file_begin, int file_end, float th
         hr.headWords = 4;
         hr.maxWords = 2 * (int)kPinned;
         hr.seq = ++ctx->report_seq;
+        // Safety net: the slots the previous report filled are set to an impossible file index (-1) before the
+        // kernels start; a record that has not arrived when the sequence word has is recognised below.
+        if (ctx->report_prev_n)
+            std::memset(ctx->h_pinned + 2, 0xff, sizeof(sgz_candidate) * ctx->report_prev_n);
+        ctx->report_prev_n = 0;
         if ((rc = rescore_device_impl(ctx, d_rec, capacity, d_count, hr))) return rc;
         const unsigned long long *flag = hr.host + hr.maxWords;
         const auto t0 = std::chrono::steady_clock::now();
@@ -1826,6 +1831,14 @@ static int compact_host(sgz_context *ctx, int file_begin, int file_end, float th
                 std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10))
                 break;  // something is wrong on the device: let the stream wait below report it
         }
+    }
+    if (reported) {
+        unsigned long long nr = 0;
+        std::memcpy(&nr, ctx->h_pinned + parity, sizeof nr);
+        const size_t inRep = (size_t)std::min<unsigned long long>({nr, (unsigned long long)capacity, (unsigned long long)first});
+        for (size_t i = 0; i < inRep; i++)
+            if (ctx->h_pinned[2 + i].file < 0) reported = false;  // not all there: fetch the list the plain way
+        ctx->report_prev_n = inRep;
     }
     if (!reported) {
         SGZ_HIP(ctx, hipMemcpyAsync(ctx->h_pinned, ctx->d_cand, sizeof(sgz_candidate) * (first + 2),

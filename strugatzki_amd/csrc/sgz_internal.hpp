@@ -159,6 +159,7 @@ struct sgz_context {
     size_t done_cap = 0;
     bool done_init = false;
     unsigned long long report_seq = 0;       // sequence number of the latest host report
+    size_t report_prev_n = 0;                // records the latest host report filled in the pinned buffer
     int cand_parity = 0;                     // which header the next compaction counts in
     bool cand_clean = false;                 // that header is known to be zero
     size_t cand_cap = 0;
