@@ -425,3 +425,28 @@ def test_identity_window_scores_one(ctx):
     sim, boost = ctx.corr_read_dense(0)
     assert abs(sim[300] - 1.0) <= 1e-6 and abs(boost[300] - 1.0) <= 1e-6
     assert int(np.argmax(sim)) == 300
+
+
+def test_kernel_time_history_and_sampling(ctx):
+    """Every run carries timing events by default; sgz_set_kernel_timing thins them out or turns them off."""
+    L, ts, nf, frames = 96, 17, 4, 3000
+    db = synth_db(nf, frames, make_plants(2, L, nf, frames, ts))
+    _load(ctx, db, norms_default())
+    ctx.corr_set_target(synth_target(ts, L)[ts:ts + L], 0.5, 8.0)
+    before = len(ctx.kernel_ms_history(256))
+    for _ in range(6):
+        ctx.corr_run_screen_f16(0, nf)
+    ctx.synchronize()
+    h = ctx.kernel_ms_history(256)
+    assert len(h) == min(before + 6, 256) and np.all(h[-6:] > 0) and np.all(h[-6:] < 50)
+    assert abs(ctx.corr_last_kernel_ms() - h[-1]) < 1e-6
+    ctx.set_kernel_timing(3)
+    for _ in range(6):
+        ctx.corr_run(0, nf)
+    ctx.synchronize()
+    assert len(ctx.kernel_ms_history(256)) == min(before + 8, 256)  # runs 0 and 3 of the six
+    ctx.set_kernel_timing(0)
+    ctx.corr_run(0, nf)
+    ctx.synchronize()
+    assert len(ctx.kernel_ms_history(256)) == min(before + 8, 256)
+    ctx.set_kernel_timing(1)
