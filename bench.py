@@ -124,7 +124,8 @@ def main() -> int:
     ap.add_argument("--target-seconds", type=float, default=30.0)
     ap.add_argument("--num-matches", type=int, default=10)
     ap.add_argument("--settle-ms", type=float, default=100.0,
-                    help="untimed steps for this long before the warm-up steps, so that the clocks have settled")
+                    help="untimed steps for about this long (counted as 0.3 ms each) before the warm-up steps, so that the "
+                         "clocks have settled")
     ap.add_argument("--timing-every", type=int, default=1,
                     help="HIP events with one launch in n of the dominant kernel (matrix-core path)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget; 0 disables")
@@ -228,12 +229,11 @@ def main() -> int:
     ctx.set_kernel_timing(timing_every)
     # Clock settling, untimed and reported as such: after an idle period the chip needs some tens of
     # milliseconds of load before it holds its clocks; the first steps then run 5-10 % slower than the rest.
+    # (a fixed count, the same on every rank: the sharded step holds a collective)
     matches = []
-    settle_steps = 0
-    t_settle = time.perf_counter()
-    while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
+    settle_steps = int(args.settle_ms / 0.3)
+    for _ in range(settle_steps):
         matches = step()
-        settle_steps += 1
     for _ in range(args.warmup):
         matches = step()
     kernel_ms = []
