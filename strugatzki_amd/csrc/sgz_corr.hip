@@ -579,6 +579,15 @@ __device__ __forceinline__ void reduce_waves(double *red, const double (&acc)[kR
     }
 }
 
+// Windows whose prefix-sum statistics cannot be trusted (window_result): listed by the exact kernel for a
+// two-pass evaluation, or just given `fill` (+inf in a screening run: a certain candidate, re-scored anyway).
+struct SuspectList {
+    sgz_candidate *list;        // null: no list
+    unsigned long long *count;  // zero when the kernel starts
+    long long capacity;
+    float fill;                 // the similarity written for such a window (exact run: NaN until re-evaluated)
+};
+
 // T = double: the exact path.  T = float: the screening path -- fp32 products and
 // fp32 sums over one phase (<= 176 * 16 lags of one channel per wave), folded into
 // fp64 sums after every phase.
@@ -590,7 +599,7 @@ __global__ __launch_bounds__(kThreads, 4) void corr_kernel(const FileDesc *__res
                                                            const double *__restrict__ tbase,
                                                            const T *__restrict__ aprime, CorrParams cp,
                                                            float *__restrict__ simOut,
-                                                           float *__restrict__ boostOut)
+                                                           float *__restrict__ boostOut, SuspectList sus)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
     T *lds = reinterpret_cast<T *>(ldsRaw);  // 2 x [kR][kMT] of T, then 2 x [kR][64] doubles
@@ -735,10 +744,43 @@ __global__ __launch_bounds__(kThreads, 4) void corr_kernel(const FileDesc *__res
         const long long o = oBase + k;
         if (o < fd.num_windows) {
             float sim, boost;
-            window_result(cp, ep, o, redT[r * 64 + lane], redS[r * 64 + lane], sim, boost);
+            bool suspect;
+            window_result(cp, ep, o, redT[r * 64 + lane], redS[r * 64 + lane], sim, boost, suspect);
+            if (suspect) {
+                // statistics too close to the rounding of the prefix sums: the window is listed for a two-pass
+                // evaluation from its frames (exact run) or made a certain candidate (screening run)
+                sim = sus.fill;
+                if (sus.list) {
+                    const unsigned long long slot = atomicAdd(sus.count, 1ull);
+                    if ((long long)slot < sus.capacity) {
+                        sgz_candidate c;
+                        c.file = td.file;
+                        c.offset = (int)o;
+                        c.sim = sim;
+                        c.boost = boost;
+                        sus.list[slot] = c;
+                    }
+                }
+            }
             simOut[fd.win_off + o] = sim;
             boostOut[fd.win_off + o] = boost;
         }
+    }
+}
+
+// Writes re-evaluated windows back into the dense arrays.
+__global__ __launch_bounds__(256) void scatter_kernel(const FileDesc *__restrict__ files,
+                                                      const sgz_candidate *__restrict__ list,
+                                                      const unsigned long long *__restrict__ count,
+                                                      long long capacity, float *__restrict__ simOut,
+                                                      float *__restrict__ boostOut)
+{
+    const long long n = min((long long)*count, capacity);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const sgz_candidate c = list[i];
+        const long long at = files[c.file].win_off + c.offset;
+        simOut[at] = c.sim;
+        boostOut[at] = c.boost;
     }
 }
 
@@ -1439,6 +1481,9 @@ int64_t sgz_corr_num_windows(const sgz_context *ctx, int file)
 enum RunMode { kRunExact = 0, kRunScreenF32 = 1, kRunScreenF16 = 2 };
 
 static int corr_run_impl(sgz_context *ctx, int file_begin, int file_end, int mode);
+static int rescore_device_impl(sgz_context *ctx, sgz_candidate *device_cands, int64_t capacity,
+                               const unsigned long long *device_count, const HostReport &hr);
+constexpr int64_t kSuspectCap = 1 << 16;  // windows an exact run can re-evaluate from their frames
 
 int sgz_corr_run(sgz_context *ctx, int file_begin, int file_end)
 {
@@ -1522,6 +1567,16 @@ static int corr_run_impl(sgz_context *ctx, int file_begin, int file_end, int mod
                        file_begin, ctx->d_tbase);
     SGZ_HIP(ctx, hipGetLastError());
     const size_t corrLds = exact ? corr_lds_bytes<double>() : corr_lds_bytes<float>();
+    // windows whose prefix-sum statistics cannot be trusted (constant stretches): see SuspectList
+    SuspectList suspects{nullptr, nullptr, 0, INFINITY};
+    if (exact) {
+        if ((rc = ensure(ctx, ctx->d_suspect, ctx->suspect_cap, (size_t)kSuspectCap + 1))) return rc;
+        suspects.list = ctx->d_suspect + 1;
+        suspects.count = reinterpret_cast<unsigned long long *>(ctx->d_suspect);
+        suspects.capacity = kSuspectCap;
+        suspects.fill = NAN;
+        SGZ_HIP(ctx, hipMemsetAsync(ctx->d_suspect, 0, sizeof(sgz_candidate), stream));
+    }
     // kernel time for sgz_corr_last_kernel_ms: the matrix-core kernel carries the two events in its own
     // dispatch (no separate marker packets, which would each cost a few idle microseconds on the stream)
     if (!half && timed) SGZ_HIP(ctx, hipEventRecord(ctx->ev0, stream));
@@ -1531,13 +1586,21 @@ static int corr_run_impl(sgz_context *ctx, int file_begin, int file_end, int mod
     } else if (exact)
         hipLaunchKernelGGL(corr_kernel<double>, dim3(t1 - t0), dim3(kThreads), corrLds, stream, ctx->d_files,
                            ctx->d_tiles + t0, ctx->d_planar, ctx->d_prefix, ctx->d_tbase, ctx->d_aprime, ctx->cp,
-                           ctx->d_sim, ctx->d_boost);
+                           ctx->d_sim, ctx->d_boost, suspects);
     else
         hipLaunchKernelGGL(corr_kernel<float>, dim3(t1 - t0), dim3(kThreads), corrLds, stream, ctx->d_files,
                            ctx->d_tiles + t0, planarF, ctx->d_prefix, ctx->d_tbase, ctx->d_aprime_f, ctx->cp,
-                           ctx->d_sim, ctx->d_boost);
+                           ctx->d_sim, ctx->d_boost, suspects);
     SGZ_HIP(ctx, hipGetLastError());
     if (!half && timed) SGZ_HIP(ctx, hipEventRecord(ctx->ev1, stream));
+    if (exact) {
+        // two-pass evaluation of the listed windows, written back into the dense arrays (three small kernels
+        // that return at once when the list is empty); windows beyond the list's capacity stay NaN
+        if ((rc = rescore_device_impl(ctx, suspects.list, kSuspectCap, suspects.count, HostReport{}))) return rc;
+        hipLaunchKernelGGL(scatter_kernel, dim3(64), dim3(256), 0, stream, ctx->d_files, suspects.list, suspects.count,
+                           (long long)kSuspectCap, ctx->d_sim, ctx->d_boost);
+        SGZ_HIP(ctx, hipGetLastError());
+    }
     if (timed) {
         ctx->ev_valid = true;
         ctx->ev_runs++;

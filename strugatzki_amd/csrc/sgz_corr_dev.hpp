@@ -29,29 +29,44 @@ struct Epilogue {
 
 // The similarity and boost of window o as the reference computes them from the cross terms
 // (impl/FeatureCorrelationImpl.scala:193-232): fp64 statistics, fp32 mix.
+// The variance comes from differences of prefix sums; where it is so small that the rounding of those sums
+// (a few 2^-52 of their magnitude) could move it by more than one part in 10^6 -- stretches of constant
+// features, digital silence -- `suspect` is set: the reference's two-pass statistics give exactly 0 there
+// (and a NaN similarity), and only a two-pass evaluation from the frames reproduces that.
 __device__ __forceinline__ void window_result(const CorrParams &cp, const Epilogue &ep, long long o,
-                                              double crossT, double crossS, float &simOut, float &boostOut)
+                                              double crossT, double crossS, float &simOut, float &boostOut,
+                                              bool &suspect)
 {
+    constexpr double kRound = 8.0 * 2.220446049250313e-16, kTrust = 1.0e6;
     const double nT = (double)cp.L;
     const double nS = (double)cp.L * (double)(cp.numCh - 1);
-    const double dmT = (ep.P(0, o + cp.L) - ep.P(0, o)) / nT;  // window mean - kT
+    const double p0h = ep.P(0, o + cp.L), p0l = ep.P(0, o);
+    const double dmT = (p0h - p0l) / nT;  // window mean - kT
     const double avgD = cp.kT + dmT;
     const float avgF = (float)avgD;  // MathUtil.avg returns Float
     const double lnAvgB = log((double)avgF);
     const float boost = (float)exp((cp.lnAvgIn - lnAvgB) / 0.6);
     float sim = 0.0f;
+    suspect = false;
     if (boost <= cp.maxBoost) {
         float temporal = 0.0f, spectral = 0.0f;
         if (cp.w > 0.0f) {
-            double var = (ep.P(1, o + cp.L) - ep.P(1, o)) / nT - dmT * dmT;
+            const double p1h = ep.P(1, o + cp.L), p1l = ep.P(1, o);
+            double var = (p1h - p1l) / nT - dmT * dmT;
+            const double err = kRound * ((fabs(p1h) + fabs(p1l)) + 2.0 * fabs(dmT) * (fabs(p0h) + fabs(p0l))) / nT;
+            suspect |= !(var >= kTrust * err);
             if (var < 0.0) var = 0.0;
             const double bStd = sqrt(var);
             const double cross = crossT - dmT * cp.sumAT;
             temporal = (float)(cross / (cp.aStdT * bStd * nT));
         }
         if (cp.w < 1.0f) {
-            const double dmS = (ep.P(2, o + cp.L) - ep.P(2, o)) / nS;
-            double var = (ep.P(3, o + cp.L) - ep.P(3, o)) / nS - dmS * dmS;
+            const double p2h = ep.P(2, o + cp.L), p2l = ep.P(2, o);
+            const double p3h = ep.P(3, o + cp.L), p3l = ep.P(3, o);
+            const double dmS = (p2h - p2l) / nS;
+            double var = (p3h - p3l) / nS - dmS * dmS;
+            const double err = kRound * ((fabs(p3h) + fabs(p3l)) + 2.0 * fabs(dmS) * (fabs(p2h) + fabs(p2l))) / nS;
+            suspect |= !(var >= kTrust * err);
             if (var < 0.0) var = 0.0;
             const double bStd = sqrt(var);
             const double cross = crossS - dmS * cp.sumAS;

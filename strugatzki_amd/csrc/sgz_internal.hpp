@@ -155,6 +155,8 @@ struct sgz_context {
     size_t rs_part_cap = 0;
 
     sgz_candidate *d_cand = nullptr;         // [two count headers][records]
+    sgz_candidate *d_suspect = nullptr;      // [count header][windows an exact run hands to the two-pass kernels]
+    size_t suspect_cap = 0;
     unsigned int *d_done = nullptr;          // workgroup counter of the host report (rescore_final_kernel)
     size_t done_cap = 0;
     bool done_init = false;

@@ -450,3 +450,34 @@ def test_kernel_time_history_and_sampling(ctx):
     ctx.synchronize()
     assert len(ctx.kernel_ms_history(256)) == min(before + 8, 256)
     ctx.set_kernel_timing(1)
+
+
+@pytest.mark.parametrize("weight", [0.0, 0.5, 1.0])
+def test_constant_stretches_in_the_exact_kernel(ctx, weight):
+    """Windows over constant features (digital silence): the reference's two-pass statistics give a variance of
+    exactly 0 and a NaN similarity, which is never offered.  The exact kernel's prefix-sum statistics cannot
+    tell such a window from one with a tiny variance; it hands those windows to the two-pass kernels."""
+    import strugatzki_amd as S
+    L, ts, nf, frames = 64, 7, 3, 1200
+    db = synth_db(nf, frames, make_plants(2, L, nf, frames, ts))
+    db[0][200:500] = db[0][200]             # everything constant
+    db[1][100:400, 0] = np.float32(0.75)     # constant loudness only
+    db[2][300:600, 1:] = np.float32(0.25)    # all MFCC channels at one value
+    tgt = synth_target(ts, L)
+    norms = norms_default()
+    cfg = corr_config(ts, L, weight=weight, num_matches=5, num_per_file=2)
+    want, sims, boosts = O.correlation_run(cfg, tgt, norms, db)
+    _load(ctx, db, norms)
+    ctx.corr_set_target(tgt[ts:ts + L], weight, 8.0)
+    nan_seen = 0
+    for f, (gs, gb) in enumerate(_gpu_dense(ctx, nf)):
+        assert np.array_equal(np.isnan(gs), np.isnan(sims[f]))
+        assert np.array_equal(np.isinf(gs), np.isinf(sims[f]))
+        ok = np.isfinite(sims[f])
+        assert float(np.max(np.abs(gs[ok] - sims[f][ok]))) < 1e-5
+        nan_seen += int(np.isnan(gs).sum())
+    if weight > 0.0:
+        assert nan_seen > 0
+    for screen in (False, "f32", "auto"):
+        got = S.search(ctx, S.SearchParams(5, 2, 0, STEP, screen=bool(screen), screen_mode=screen or "auto"))
+        assert [(g.file, g.start, g.stop) for g in got] == [(w.file, w.start, w.stop) for w in want]

@@ -1,0 +1,17 @@
+"""Random search configurations (channel counts, target lengths, ragged and short files, weights, boost gates,
+numPerFile / minSpacing, screening modes, awkward data) on the GPU against the oracle."""
+import os
+import sys
+
+import pytest
+
+from common import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_random_configurations_match_the_oracle(ctx, seed):
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_parity
+    assert fuzz_parity.run(120, seed, ctx=ctx) == 0
