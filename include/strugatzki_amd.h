@@ -140,6 +140,14 @@ SGZ_API int sgz_corr_set_target(sgz_context *ctx, const float *frames, int num_f
  * this context left in the L-frame ring (:154, :190-195); an empty file has 0. */
 SGZ_API int64_t sgz_corr_num_windows(const sgz_context *ctx, int file);
 
+/* The sliding passes that follow stop `frames` frames before the end of every
+ * database file: what the punch-in pass of a search with punch-out does with
+ * frames = minPunch (impl/FeatureCorrelationImpl.scala:182-185: it runs over
+ * numFrames - minPunch frames).  Window counts, the one window of a file that
+ * becomes shorter than the target and the ring contents later files see follow
+ * the shortened files.  0 (the state after sgz_db_reset) = whole files. */
+SGZ_API int sgz_corr_set_tail_trim(sgz_context *ctx, int64_t frames);
+
 /* Computes boost and similarity of every window of files [file_begin, file_end)
  * on the GPU and keeps them in device memory.  Asynchronous on the context's
  * stream.  Replaces the sliding loop of impl/FeatureCorrelationImpl.scala:190-210

@@ -78,6 +78,7 @@ SIGNATURES = {
     "sgz_set_norms": (C.c_int, [_vp, _vp]),
     "sgz_corr_set_target": (C.c_int, [_vp, _vp, C.c_int, C.c_float, C.c_float]),
     "sgz_corr_num_windows": (C.c_int64, [_vp, C.c_int]),
+    "sgz_corr_set_tail_trim": (C.c_int, [_vp, C.c_int64]),
     "sgz_corr_run": (C.c_int, [_vp, C.c_int, C.c_int]),
     "sgz_corr_run_screen": (C.c_int, [_vp, C.c_int, C.c_int]),
     "sgz_get_stream": (C.c_void_p, [_vp]),

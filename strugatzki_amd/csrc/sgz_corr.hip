@@ -1117,7 +1117,9 @@ int build_layout(sgz_context *ctx)
     for (int f = 0; f < nf; f++) {
         FileDesc &fd = ctx->h_files[f];
         fd.raw = ctx->files[f].d_raw;
-        fd.frames = ctx->files[f].frames;
+        // a pass that stops tail_trim frames before the end of every file (the punch-in pass of a search with
+        // punch-out, :182-185) neither scores nor leaves in the ring what lies behind that point
+        fd.frames = std::max<long long>(ctx->files[f].frames - ctx->tail_trim, 0);
         const long long own = fd.frames;
         if (own > 0 && own < L) {
             const size_t rowBytes = sizeof(float) * (size_t)ctx->numCh;
@@ -1248,6 +1250,18 @@ int sgz_db_reset(sgz_context *ctx, int num_channels)
     ctx->numCh = num_channels;
     ctx->layout_dirty = true;
     ctx->have_target = false;
+    ctx->tail_trim = 0;
+    return SGZ_OK;
+}
+
+int sgz_corr_set_tail_trim(sgz_context *ctx, int64_t frames)
+{
+    if (!ctx) return SGZ_E_ARG;
+    if (frames < 0) return ctx->fail(SGZ_E_ARG, "tail trim must be >= 0");
+    if (frames != ctx->tail_trim) {
+        ctx->tail_trim = frames;
+        ctx->layout_dirty = true;
+    }
     return SGZ_OK;
 }
 
@@ -1473,7 +1487,7 @@ int sgz_corr_set_target(sgz_context *ctx, const float *frames, int num_frames, f
 int64_t sgz_corr_num_windows(const sgz_context *ctx, int file)
 {
     if (!ctx || !ctx->have_target || file < 0 || file >= (int)ctx->files.size()) return -1;
-    const long long n = ctx->files[file].frames;
+    const long long n = std::max<long long>(ctx->files[file].frames - ctx->tail_trim, 0);
     if (n >= ctx->cp.L) return n - ctx->cp.L + 1;
     return n > 0 ? 1 : 0;  // the single window over the ring's stale contents
 }

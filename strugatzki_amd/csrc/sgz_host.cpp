@@ -213,7 +213,9 @@ std::vector<Match> runFeatureCorrelation(sgz_context *ctx, const FeatureCorrelat
         };
         std::vector<float> inSim, inBoost, outSim, outBoost;
         std::vector<size_t> inPos, outPos;
+        check(ctx, sgz_corr_set_tail_trim(ctx, minPunch));  // the punch-in pass stops minPunch frames early, :182-185
         denseAll(inSim, inBoost, inPos);
+        check(ctx, sgz_corr_set_tail_trim(ctx, 0));
         checkAborted(obs, 0.7);
         check(ctx, sgz_corr_set_target(ctx, afIn.frames.data() + (size_t)oStart * numCh, Lout,
                                        cfg.punchOut->temporalWeight, cfg.maxBoost));

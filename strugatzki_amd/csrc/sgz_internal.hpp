@@ -109,6 +109,7 @@ struct sgz_context {
 
     // layout (depends on db + target length)
     bool layout_dirty = true;
+    long long tail_trim = 0;                 // frames at the end of every file that the passes leave out
     std::vector<sgz::FileDesc> h_files;
     std::vector<sgz::TileDesc> h_tiles;      // correlation tiles, grouped by file
     std::vector<int> tile_begin;             // first tile of each file (+ sentinel)

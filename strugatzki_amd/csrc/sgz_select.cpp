@@ -189,8 +189,10 @@ int sgz_sel_feed_file_punch(sgz_selector *sel, int file, int64_t num_frames, int
     if (!sel || num_frames < 0 || in_frames < 1 || out_frames < 1 || min_punch < 0) return SGZ_E_ARG;
     sel->entry.clear();
     sel->has_last = false;
-    // windows of the punch-in pass: it runs over num_frames - minPunch frames (:182-185)
-    const int64_t n_in = num_frames - min_punch >= in_frames ? num_frames - min_punch - in_frames + 1 : 0;
+    // windows of the punch-in pass: it runs over num_frames - minPunch frames (:182-185); fewer than a target's
+    // length still give one iteration (:190-195)
+    const int64_t rem = num_frames - min_punch;
+    const int64_t n_in = rem >= in_frames ? rem - in_frames + 1 : (rem > 0 ? 1 : 0);
     if (n_in > 0 && (!in_sim || !in_boost || !out_sim || !out_boost)) return SGZ_E_ARG;
     // no match is added during that pass: its gate (:212) is the same for every window
     const bool hs0 = sel->entry_has_space();

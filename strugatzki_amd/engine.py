@@ -121,6 +121,11 @@ class Context:
     def corr_num_windows(self, file: int) -> int:
         return lib.sgz_corr_num_windows(self._h, file)
 
+    def corr_set_tail_trim(self, frames: int) -> None:
+        """The passes that follow stop `frames` frames before the end of every file (the punch-in pass of a
+        search with punch-out, impl/FeatureCorrelationImpl.scala:182-185); 0 = whole files."""
+        self._check(lib.sgz_corr_set_tail_trim(self._h, int(frames)))
+
     def corr_run(self, file_begin: int = 0, file_end: int | None = None) -> None:
         if file_end is None:
             file_end = self.num_files
@@ -328,7 +333,10 @@ class Selector:
                         out_boost: np.ndarray) -> None:
         """One file of a punch-in / punch-out search from the dense results of both targets."""
         a = [np.ascontiguousarray(x, dtype=np.float32) for x in (in_sim, in_boost, out_sim, out_boost)]
-        if len(a[0]) < max(0, num_frames - in_frames + 1) or len(a[2]) < max(0, num_frames - out_frames + 1):
+        rem = num_frames - min_punch  # frames the punch-in pass runs over
+        n_in = rem - in_frames + 1 if rem >= in_frames else (1 if rem > 0 else 0)
+        if len(a[0]) < n_in or len(a[1]) < n_in or len(a[2]) < max(0, num_frames - out_frames + 1) or \
+                len(a[3]) < len(a[2]):
             raise ValueError("dense arrays are shorter than the file's windows")
         rc = lib.sgz_sel_feed_file_punch(self._h, file, num_frames, in_frames, out_frames, min_punch, max_punch,
                                          N.ptr(a[0]), N.ptr(a[1]), N.ptr(a[2]), N.ptr(a[3]))

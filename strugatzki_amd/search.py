@@ -100,7 +100,9 @@ def search_punch(ctx: Context, p: SearchParams, target_in: np.ndarray, weight_in
     sel = Selector(p.num_matches, p.num_per_file, p.min_spacing, p.step_size, len(target_in))
     try:
         dense = []
-        for tgt, w in ((target_in, weight_in), (target_out, weight_out)):
+        # the punch-in pass stops min_punch frames before the end of a file (:182-185)
+        for tgt, w, trim in ((target_in, weight_in, min_punch), (target_out, weight_out, 0)):
+            ctx.corr_set_tail_trim(trim)
             ctx.corr_set_target(tgt, w, max_boost)
             ctx.corr_run(0, nf)
             dense.append(ctx.corr_read_dense_range(0, nf) if nf else [])
@@ -110,6 +112,7 @@ def search_punch(ctx: Context, p: SearchParams, target_in: np.ndarray, weight_in
                                 isim, iboost, osim, oboost)
         return sel.result()
     finally:
+        ctx.corr_set_tail_trim(0)
         sel.close()
 
 

@@ -15,3 +15,12 @@ def test_random_configurations_match_the_oracle(ctx, seed):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import fuzz_parity
     assert fuzz_parity.run(120, seed, ctx=ctx) == 0
+
+
+@pytest.mark.parametrize("seed", [21])
+def test_random_punch_out_searches_match_the_oracle(ctx, seed):
+    """Punch-in / punch-out: random spans, gaps, punch ranges, files that the punch-in pass sees shorter than its
+    span (one window over the ring's stale contents), constant stretches."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_punch
+    assert fuzz_punch.run(150, seed, ctx=ctx) == 0
