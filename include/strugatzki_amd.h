@@ -333,8 +333,10 @@ SGZ_API int sgz_sel_result(const sgz_selector *sel, sgz_match *out, int capacity
  * impl/FeatureSegmentationImpl.scala:107-120 (MathUtil.correlateHalf,
  * impl/MathUtil.scala:80-99).  `frames` is host memory (raw interleaved,
  * num_frames x num_channels); `norms` is [num_channels][2] (min, max) or NULL
- * for no normalisation; sim_out receives
- * max(0, af_stop - af_start - 2*half_win + 1) values. */
+ * for no normalisation; sim_out receives af_stop - af_start - 2*half_win + 1
+ * values; a non-empty span shorter than the window gives 1 value, the span's
+ * frames followed by the zeros of the reference's fresh buffer (:86, :107-113);
+ * an empty span gives none. */
 SGZ_API int sgz_segm_curve(sgz_context *ctx, const float *frames, int64_t num_frames, int num_channels,
                            const float *norms, int af_start, int af_stop, int half_win,
                            float temporal_weight, float *sim_out, int64_t *num_out);

@@ -176,6 +176,17 @@ int sgz_segm_curve(sgz_context *ctx, const float *frames, int64_t num_frames, in
     const long long afLen = (long long)af_stop - af_start;
     // the reference loop runs once per frame after the first 2H have been read
     // (impl/FeatureSegmentationImpl.scala:101-129)
+    if (afLen > 0 && afLen < 2ll * half_win) {
+        // a span shorter than the window still gives one iteration: its frames followed by the zeros of the
+        // fresh buffer, which normalisation never touches (:86, :107-113) -- here raw values that normalise to 0
+        const size_t win = 2 * (size_t)half_win;
+        std::vector<float> padded(win * num_channels);
+        std::memcpy(padded.data(), frames + (size_t)af_start * num_channels, sizeof(float) * (size_t)afLen * num_channels);
+        for (size_t i = (size_t)afLen; i < win; i++)
+            for (int c = 0; c < num_channels; c++) padded[i * num_channels + c] = norms ? norms[2 * c] : 0.0f;
+        return sgz_segm_curve(ctx, padded.data(), (int64_t)win, num_channels, norms, 0, (int)win, half_win,
+                              temporal_weight, sim_out, num_out);
+    }
     const long long numWin = afLen >= 2ll * half_win ? afLen - 2ll * half_win + 1 : 0;
     *num_out = numWin;
     if (numWin == 0) return SGZ_OK;

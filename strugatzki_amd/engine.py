@@ -255,7 +255,7 @@ class Context:
                    temporal_weight: float) -> np.ndarray:
         a = _as_frames(frames)
         nrm = None if norms is None else np.ascontiguousarray(norms, dtype=np.float32)
-        n = max(0, (af_stop - af_start) - 2 * half_win + 1)
+        n = max(0, (af_stop - af_start) - 2 * half_win + 1)  # (a short non-empty span: 1 value)
         out = np.empty(max(n, 1), dtype=np.float32)
         cnt = C.c_int64(0)
         self._check(lib.sgz_segm_curve(self._h, N.ptr(a), a.shape[0], a.shape[1], N.ptr(nrm), af_start, af_stop, half_win,

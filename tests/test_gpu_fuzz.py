@@ -24,3 +24,10 @@ def test_random_punch_out_searches_match_the_oracle(ctx, seed):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import fuzz_punch
     assert fuzz_punch.run(150, seed, ctx=ctx) == 0
+
+
+@pytest.mark.parametrize("seed", [31])
+def test_random_segmentation_selfsimilarity_stats_crosssimilarity_inputs_match_the_oracle(ctx, seed):
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_halfcorr
+    assert fuzz_halfcorr.run(240, seed, ctx=ctx) == 0

@@ -39,9 +39,17 @@ def test_segmentation_curve_and_breaks(ctx, span, corr_len, weight, normalize):
     assert [(b.sim, b.pos) for b in br] == [(w.sim, w.pos) for w in want]
 
 
-def test_segmentation_window_longer_than_span_gives_nothing(ctx):
+@pytest.mark.parametrize("normalize", [True, False])
+def test_segmentation_window_longer_than_span_gives_one_value(ctx, normalize):
+    """The reference's loop still runs once: the span's frames followed by the zeros of its fresh buffer
+    (impl/FeatureSegmentationImpl.scala:86, 107-113)."""
     frames = _frames(60)
-    assert ctx.segm_curve(frames, norms_default(), 0, 60, 43, 0.5).shape == (0,)
+    norms = norms_default() if normalize else None
+    cfg = O.SegmConfig(1, 0, 4 * STEP, 0, 43 * STEP, 0.5, int(normalize), 3, 0, STEP, NUM_CH - 1)
+    want, dense = O.segmentation_run(cfg, frames, norms)
+    got = ctx.segm_curve(frames, norms, 4, 60, 43, 0.5)
+    assert dense.shape == (1,) and np.array_equal(got, dense)
+    assert ctx.segm_curve(frames, norms, 20, 20, 43, 0.5).shape == (0,)
 
 
 @pytest.mark.parametrize("decim,corr_len,warp,ceil,inv", [(1, 4 * STEP, 1.0, 1.0, False), (3, 8 * STEP, 0.5, 0.8, True),
