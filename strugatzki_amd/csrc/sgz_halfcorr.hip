@@ -8,8 +8,11 @@
 // evaluation to the last bit.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "sgz_internal.hpp"
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(256) void segm_kernel(const float *__restrict__ x, 
 __device__ int gray_color(float sim, double warp, float scale, int inv)
 {
     const float m0 = (sim != sim) ? sim : (sim > 0.0f ? sim : 0.0f);
-    const float v = (float)pow((double)m0, warp) * scale;
+    const float v = (warp == 1.0 ? m0 : (float)pow((double)m0, warp)) * scale;  // pow(x, 1) == x
     const float s = inv ? (1.0f - v) : v;
     const double d = (double)(s * 255) + 0.5;
     int i;
@@ -109,32 +112,292 @@ __device__ int gray_color(float sim, double warp, float scale, int inv)
     return (i << 16) | (i << 8) | i;
 }
 
-// impl/SelfSimilarityImpl.scala:127-163: pixel (x, y), y >= x, compares the half
-// window of file 1 at afStart + x*decim with that of file 2 at afStart + y*decim.
-__global__ __launch_bounds__(256) void selfsim_kernel(const float *__restrict__ x1, long long frames1,
-                                                      const float *__restrict__ x2, long long frames2, int numCh,
-                                                      int afStart, int H, int decim, int imgExt, float w,
-                                                      double warp, float scale, int inv,
-                                                      float *__restrict__ simOut, int *__restrict__ imgOut)
+// ---------------------------------------------------------------------------
+// Tiled self-similarity.  correlateHalf over a window made of the half windows a (file 1 at x) and b (file 2 at
+// y), n values each, is a function of five sums over values shifted by any common constant:
+//     S = sum(a) + sum(b),  Q = sum(a^2) + sum(b^2),  P = sum(a * b)
+//     joint mean m = S / 2n,  sum (v - m)^2 = Q - S^2 / 2n,  sum (a - m)(b - m) = P - S^2 / 4n
+//     sim = 2 (P - S^2 / 4n) / (Q - S^2 / 2n)
+// selfsim_gather_kernel stores every window as a column of n values minus the window's own mean level mu (so the
+// stored values are small and mostly exact differences) together with their fp64 sums.  With d = mu_a - mu_b
+// the sums in the frame of b are  S = Sa + n d + Sb,  Q = Qa + 2 d Sa + n d^2 + Qb,  P = P'' + d Sb,  where only
+// P'' = sum(a'' b'') couples x and y: the matrix product of the two column sets.  A workgroup of
+// selfsim_tile_kernel evaluates it for 128 x 128 pixels on the matrix cores in fp32 (v_mfma_f32_32x32x2_f32) over
+// runs of 32 products that are folded into fp64; everything else is fp64.
+// The error of P'' is at most 35 * 2^-24 * sqrt(Qa Qb); a pixel for which that could move the similarity by more
+// than 8e-6 is evaluated by correlate_half_dev instead.
+// ---------------------------------------------------------------------------
+constexpr int kSsTile = 128;   // pixels per workgroup tile edge
+constexpr int kSsRun = 32;     // products per fp32 run
+
+struct SelfSimStat {
+    double S, Q;   // sum and sum of squares of the stored (shifted) values
+    double mu;     // the shift
+    double pad;
+};
+
+// Window w (frame afStart + w*decim, H frames) of planar matrix x -> column w of cols[numCh * H][stride]: rows
+// [0, H) = channel 0 (temporal group), rows [H, numCh * H) = channels 1.. (spectral group), each minus the mean
+// level of its group in this window; stats[2 w + group].  Columns in [imgExt, stride) are zero.
+__global__ __launch_bounds__(256) void selfsim_gather_kernel(const float *__restrict__ x, long long frames, int numCh,
+                                                             int afStart, int H, int decim, int imgExt,
+                                                             long long stride, float *__restrict__ cols,
+                                                             SelfSimStat *__restrict__ stats)
 {
-    const int px = blockIdx.x * 16 + (threadIdx.x & 15);
-    const int py = blockIdx.y * 16 + (threadIdx.x >> 4);
-    if (px >= imgExt || py >= imgExt || py < px) return;
-    const long long left = (long long)afStart + (long long)px * decim;
-    const long long right = (long long)afStart + (long long)py * decim;
-    float temporal = 0.0f, spectral = 0.0f;
-    if (w > 0.0f) temporal = correlate_half_dev(x1, frames1, left, x2, frames2, right, H, 0, 0, 1);
-    if (w < 1.0f) spectral = correlate_half_dev(x1, frames1, left, x2, frames2, right, H, 0, 1, numCh);
-    const float sim = temporal * w + spectral * (1.0f - w);
-    if (simOut) {
-        simOut[(long long)px * imgExt + py] = sim;
-        simOut[(long long)py * imgExt + px] = sim;
+    const long long w = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (w >= stride) return;
+    if (w >= imgExt) {
+        for (long long e = 0; e < (long long)numCh * H; e++) cols[e * stride + w] = 0.0f;
+        return;
     }
-    if (imgOut) {
-        const int colr = gray_color(sim, warp, scale, inv);
-        imgOut[(long long)(imgExt - 1 - py) * imgExt + px] = colr;
-        imgOut[(long long)(imgExt - 1 - px) * imgExt + py] = colr;
+    const long long f0 = (long long)afStart + w * decim;
+    for (int group = 0; group < 2; group++) {
+        const int c0 = group == 0 ? 0 : 1, c1 = group == 0 ? 1 : numCh;
+        double sum = 0.0;
+        for (int c = c0; c < c1; c++)
+            for (int k = 0; k < H; k++) sum += (double)x[(long long)c * frames + f0 + k];
+        float mu = (float)(sum / ((double)(c1 - c0) * H));
+        if (!(fabsf(mu) < 3.0e38f)) mu = 0.0f;
+        double S = 0.0, Q = 0.0;
+        for (int c = c0; c < c1; c++)
+            for (int k = 0; k < H; k++) {
+                const float v = x[(long long)c * frames + f0 + k] - mu;
+                cols[((long long)c * H + k) * stride + w] = v;
+                S += (double)v;
+                Q = fma((double)v, (double)v, Q);
+            }
+        SelfSimStat st;
+        st.S = S;
+        st.Q = Q;
+        st.mu = (double)mu;
+        st.pad = 0.0;
+        stats[2 * w + group] = st;
     }
+}
+
+struct SelfSimArgs {
+    const float *x1, *x2;            // planar normalised [numCh][frames]
+    long long frames1, frames2;
+    const float *cols1, *cols2;      // gathered windows [numCh * H][stride]
+    const SelfSimStat *st1, *st2;
+    long long stride;
+    int numCh, afStart, H, decim, imgExt;
+    int c0, c1;                      // channel group of this pass
+    int first, last;                 // first pass: no earlier part to read; last pass: writes the final values
+    float wThis;                     // weight of this group's similarity
+    double warp;
+    float scale;
+    int inv;
+    float *simOut;                   // [imgExt][imgExt]; between two passes: the weighted first part, upper triangle
+    int *imgOut;
+};
+
+__device__ __noinline__ float correlate_half_exact(const float *xl, long long strideL, long long left, const float *xr,
+                                                   long long strideR, long long right, int H, int c0, int c1)
+{
+    return correlate_half_dev(xl, strideL, left, xr, strideR, right, H, 0, c0, c1);
+}
+
+// Similarity of one pixel's channel group from the product sum of its shifted columns and the statistics of its
+// two windows, or the mark for the exact evaluation.
+__device__ __forceinline__ float selfsim_pixel(const SelfSimStat &sA, const SelfSimStat &sB, double pSum, double dn,
+                                               float unsure)
+{
+    const double d = sA.mu - sB.mu;
+    const double S = sA.S + dn * d + sB.S;
+    const double Q = sA.Q + 2.0 * d * sA.S + dn * d * d + sB.Q;
+    const double varsum = Q - S * S / (2.0 * dn);
+    const double cross = pSum + d * sB.S - S * S / (4.0 * dn);
+    // 2 * 35 * 2^-24 * sqrt(Qa Qb) <= 8e-6 * varsum, squared (fails for NaN as well)
+    const bool sure = varsum >= 0.0 && 1.764e-11 * (sA.Q * sB.Q) <= 6.4e-11 * (varsum * varsum);
+    return sure ? (float)(2.0 * cross / varsum) : unsure;
+}
+
+typedef __attribute__((address_space(3))) void ss_lds_void;
+
+__global__ __launch_bounds__(256, 2) void selfsim_tile_kernel(SelfSimArgs g)
+{
+    const int tileX = blockIdx.x, tileY = blockIdx.y;
+    if (tileY < tileX) return;  // pixels with y >= x only (:127-163); the rest is mirrored
+    // two stages of one run for both sides (rows of 128 columns: side 1, then side 2); afterwards the
+    // similarities of half a tile (64 x 128, rows padded)
+    constexpr int kStage = 2 * kSsRun * kSsTile;  // floats
+    __shared__ __align__(16) float lds[2 * kStage];
+    static_assert(2 * kStage >= 64 * (kSsTile + 1), "the similarities of half a tile must fit");
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, q = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int X0 = tileX * kSsTile, Y0 = tileY * kSsTile;
+    const int H = g.H, nCh = g.c1 - g.c0;
+    const int n = H * nCh;
+    const int group = g.c0 == 0 ? 0 : 1;
+    const long long eBeg = (long long)g.c0 * H;
+
+    // Staging with buffer loads whose destination is the LDS: a wave instruction moves two rows (2 x 512 bytes);
+    // the descriptor starts at the run's first row and ends with its last, so the rows of a short last run that
+    // do not exist read as zeros.
+    auto stage = [&](int e0, int buf) {
+        const int len = min(kSsRun, n - e0);
+        const unsigned bytes = (unsigned)(((long long)(len - 1) * g.stride + kSsTile) * 4);
+        const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(g.cols1 + (eBeg + e0) * g.stride + X0), 0, bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(g.cols2 + (eBeg + e0) * g.stride + Y0), 0, bytes, 0x00020000);
+        float *dst = lds + buf * kStage;
+        for (int piece = q; piece < kSsRun; piece += 4) {  // pieces 0..15: side 1, 16..31: side 2
+            const int row = 2 * (piece & 15) + (lane >> 5);
+            const unsigned off = (unsigned)(((long long)row * g.stride + (lane & 31) * 4) * 4);
+            ss_lds_void *to = (ss_lds_void *)(dst + piece * 256);
+            if (piece < 16)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, to, 16, off, 0, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r2, to, 16, off, 0, 0, 0);
+        }
+    };
+
+    // Wave q owns the 64 x 64 pixels at (64 wx, 64 wy) of the tile as 2 x 2 matrix-core tiles of 32 x 32
+    // (v_mfma_f32_32x32x2_f32: lane l supplies row l % 32 of each operand for run element l / 32 and receives,
+    // in register v, the product at row 8 (v / 4) + 4 (l / 32) + v % 4, column l % 32).
+    typedef float v16f __attribute__((ext_vector_type(16)));
+    const int wx = q & 1, wy = q >> 1, l32 = lane & 31, lhi = lane >> 5;
+    v16f acc[2][2];
+    double sum[2][2][16];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int v = 0; v < 16; v++) {
+                acc[i][j][v] = 0.0f;
+                sum[i][j][v] = 0.0;
+            }
+
+    stage(0, 0);
+    int buf = 0;
+    for (int e0 = 0; e0 < n; e0 += kSsRun, buf ^= 1) {
+        const int len = min(kSsRun, n - e0);
+        __syncthreads();  // retires the loads of this run; everyone is done with the other stage
+        if (e0 + kSsRun < n) stage(e0 + kSsRun, buf ^ 1);
+        const float *Aw = lds + buf * kStage + lhi * kSsTile + 64 * wx + l32;
+        const float *Bw = lds + buf * kStage + kSsRun * kSsTile + lhi * kSsTile + 64 * wy + l32;
+        for (int r = 0; r < len; r += 2) {  // (a row past an odd length holds zeros)
+            const float a0 = Aw[r * kSsTile], a1 = Aw[r * kSsTile + 32];
+            const float b0 = Bw[r * kSsTile], b1 = Bw[r * kSsTile + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int v = 0; v < 16; v++) {
+                    sum[i][j][v] += (double)acc[i][j][v];
+                    acc[i][j][v] = 0.0f;
+                }
+    }
+
+    // Similarities, half a tile at a time through LDS (row rho of the staging area = pixel row
+    // 64 (rho / 32) + 32 half + rho % 32 of the tile) so that the rows of the matrix and of its mirror image are
+    // written by neighbouring lanes.
+    const double dn = (double)n;
+    constexpr int kRow = kSsTile + 1;
+    const float kUnsure = __int_as_float(0x7fc0beef);  // marks a pixel for the exact evaluation
+    for (int half = 0; half < 2; half++) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int pyl = 64 * wy + 32 * j + l32, py = Y0 + pyl;
+            if (py >= g.imgExt) continue;
+            const SelfSimStat sB = g.st2[2 * (long long)py + group];
+#pragma unroll
+            for (int v = 0; v < 16; v++) {
+                const int rowInTile = 8 * (v >> 2) + 4 * lhi + (v & 3);
+                const int px = X0 + 64 * wx + 32 * half + rowInTile;
+                if (px >= g.imgExt || py < px) continue;
+                const SelfSimStat sA = g.st1[2 * (long long)px + group];
+                const double pSum = half == 0 ? sum[0][j][v] : sum[1][j][v];
+                lds[(32 * wx + rowInTile) * kRow + pyl] = selfsim_pixel(sA, sB, pSum, dn, kUnsure);
+            }
+        }
+        __syncthreads();
+        const int XH = X0 + 32 * half;
+        // rows of the matrix: neighbouring lanes = neighbouring y
+        for (int idx = tid; idx < 64 * kSsTile; idx += 256) {
+            const int pxl = idx >> 7, pyl = idx & (kSsTile - 1);
+            const int px = XH + 64 * (pxl >> 5) + (pxl & 31), py = Y0 + pyl;
+            if (px >= g.imgExt || py >= g.imgExt || py < px) continue;
+            float part = lds[pxl * kRow + pyl];
+            if (__float_as_int(part) == __float_as_int(kUnsure))
+                part = correlate_half_exact(g.x1, g.frames1, (long long)g.afStart + (long long)px * g.decim, g.x2,
+                                            g.frames2, (long long)g.afStart + (long long)py * g.decim, H, g.c0, g.c1);
+            // sim = temporal * w + spectral * (1 - w), impl/SelfSimilarityImpl.scala:146
+            float sim = part * g.wThis;
+            const long long up = (long long)px * g.imgExt + py;
+            if (!g.first) sim = g.simOut[up] + sim;
+            if (g.simOut) g.simOut[up] = sim;
+            if (g.last) {
+                lds[pxl * kRow + pyl] = sim;
+                if (g.imgOut)
+                    g.imgOut[(long long)(g.imgExt - 1 - py) * g.imgExt + px] = gray_color(sim, g.warp, g.scale, g.inv);
+            }
+        }
+        if (!g.last) continue;
+        __syncthreads();
+        // rows of the mirror image: neighbouring lanes = neighbouring x
+        for (int idx = tid; idx < 64 * kSsTile; idx += 256) {
+            const int pxl = idx & 63, pyl = idx >> 6;
+            const int px = XH + 64 * (pxl >> 5) + (pxl & 31), py = Y0 + pyl;
+            if (px >= g.imgExt || py >= g.imgExt || py <= px) continue;
+            const float sim = lds[pxl * kRow + pyl];
+            if (g.simOut) g.simOut[(long long)py * g.imgExt + px] = sim;
+            if (g.imgOut)
+                g.imgOut[(long long)(g.imgExt - 1 - px) * g.imgExt + py] = gray_color(sim, g.warp, g.scale, g.inv);
+        }
+    }
+}
+
+// Large results go to pageable host memory through several pinned staging buffers, one thread and stream each:
+// a single pageable copy is bound by one core's page faults and memcpy (about 9 GB/s), far below the link.
+int copy_to_host(sgz_context *ctx, void *dst, const void *src, size_t bytes)
+{
+    constexpr size_t kChunk = (size_t)32 << 20;
+    constexpr int kThreads = 8;
+    if (bytes < 8 * kChunk) {
+        SGZ_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        SGZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return SGZ_OK;
+    }
+    SGZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t chunks = (bytes + kChunk - 1) / kChunk;
+    std::atomic<size_t> next{0};
+    std::atomic<int> failed{0};
+    auto worker = [&]() {
+        void *pin = nullptr;
+        hipStream_t st = nullptr;
+        if (hipSetDevice(ctx->device) != hipSuccess || hipHostMalloc(&pin, kChunk, hipHostMallocDefault) != hipSuccess ||
+            hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
+            failed = 1;
+        } else {
+            for (size_t c = next++; c < chunks && !failed; c = next++) {
+                const size_t off = c * kChunk, len = std::min(kChunk, bytes - off);
+                if (hipMemcpyAsync(pin, (const char *)src + off, len, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                    hipStreamSynchronize(st) != hipSuccess) {
+                    failed = 1;
+                    break;
+                }
+                std::memcpy((char *)dst + off, pin, len);
+            }
+        }
+        if (st) (void)hipStreamDestroy(st);
+        if (pin) (void)hipHostFree(pin);
+    };
+    std::vector<std::thread> pool;
+    for (int t = 0; t < kThreads; t++) pool.emplace_back(worker);
+    for (auto &t : pool) t.join();
+    if (failed) return ctx->fail(SGZ_E_HIP, "copy of a result to host memory failed");
+    return SGZ_OK;
 }
 
 struct DevBuf {
@@ -251,18 +514,70 @@ int sgz_selfsim_run(sgz_context *ctx, const float *frames1, int64_t num_frames1,
         SGZ_HIP(ctx, hipGetLastError());
     }
     const size_t pix = (size_t)img_ext * img_ext;
-    if (sim_out) SGZ_HIP(ctx, hipMalloc(&simd.p, pix * sizeof(float)));
+    // the reference skips a group whose weight is 0 (:143-145)
+    const bool doT = temporal_weight > 0.0f, doS = temporal_weight < 1.0f || !doT;
+    if (sim_out || (doT && doS)) SGZ_HIP(ctx, hipMalloc(&simd.p, pix * sizeof(float)));
     if (img_out) SGZ_HIP(ctx, hipMalloc(&imgd.p, pix * sizeof(int32_t)));
-    const unsigned gb = (unsigned)((img_ext + 15) / 16);
-    hipLaunchKernelGGL(selfsim_kernel, dim3(gb, gb), dim3(256), 0, ctx->stream, (const float *)p1.p,
-                       (long long)num_frames1, (const float *)(same ? p1.p : p2.p), (long long)num_frames2,
-                       num_channels, af_start, half_win, decim, img_ext, temporal_weight, (double)color_warp,
-                       1.0f / color_ceil, color_inv, (float *)simd.p, (int *)imgd.p);
+    DevBuf st1, st2, cols1, cols2;
+    const unsigned gt = (unsigned)((img_ext + kSsTile - 1) / kSsTile);
+    const long long stride = (long long)gt * kSsTile;
+    const size_t colFloats = (size_t)num_channels * half_win * (size_t)stride;
+    SGZ_HIP(ctx, hipMalloc(&st1.p, 2 * (size_t)stride * sizeof(SelfSimStat)));
+    SGZ_HIP(ctx, hipMalloc(&cols1.p, colFloats * sizeof(float)));
+    const unsigned gs = (unsigned)((stride + 255) / 256);
+    hipLaunchKernelGGL(selfsim_gather_kernel, dim3(gs), dim3(256), 0, ctx->stream, (const float *)p1.p,
+                       (long long)num_frames1, num_channels, af_start, half_win, decim, img_ext, stride,
+                       (float *)cols1.p, (SelfSimStat *)st1.p);
     SGZ_HIP(ctx, hipGetLastError());
-    if (sim_out)
-        SGZ_HIP(ctx, hipMemcpyAsync(sim_out, simd.p, pix * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-    if (img_out)
-        SGZ_HIP(ctx, hipMemcpyAsync(img_out, imgd.p, pix * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (!same) {
+        SGZ_HIP(ctx, hipMalloc(&st2.p, 2 * (size_t)stride * sizeof(SelfSimStat)));
+        SGZ_HIP(ctx, hipMalloc(&cols2.p, colFloats * sizeof(float)));
+        hipLaunchKernelGGL(selfsim_gather_kernel, dim3(gs), dim3(256), 0, ctx->stream, (const float *)p2.p,
+                           (long long)num_frames2, num_channels, af_start, half_win, decim, img_ext, stride,
+                           (float *)cols2.p, (SelfSimStat *)st2.p);
+        SGZ_HIP(ctx, hipGetLastError());
+    }
+    SelfSimArgs a;
+    a.x1 = (const float *)p1.p;
+    a.x2 = (const float *)(same ? p1.p : p2.p);
+    a.frames1 = num_frames1;
+    a.frames2 = num_frames2;
+    a.cols1 = (const float *)cols1.p;
+    a.cols2 = (const float *)(same ? cols1.p : cols2.p);
+    a.st1 = (const SelfSimStat *)st1.p;
+    a.st2 = (const SelfSimStat *)(same ? st1.p : st2.p);
+    a.stride = stride;
+    a.numCh = num_channels;
+    a.afStart = af_start;
+    a.H = half_win;
+    a.decim = decim;
+    a.imgExt = img_ext;
+    a.warp = (double)color_warp;
+    a.scale = 1.0f / color_ceil;
+    a.inv = color_inv;
+    a.simOut = (float *)simd.p;
+    a.imgOut = (int *)imgd.p;
+    if (doT) {
+        a.c0 = 0;
+        a.c1 = 1;
+        a.first = 1;
+        a.last = doS ? 0 : 1;
+        a.wThis = temporal_weight;
+        hipLaunchKernelGGL(selfsim_tile_kernel, dim3(gt, gt), dim3(256), 0, ctx->stream, a);
+        SGZ_HIP(ctx, hipGetLastError());
+    }
+    if (doS) {
+        a.c0 = 1;
+        a.c1 = num_channels;
+        a.first = doT ? 0 : 1;
+        a.last = 1;
+        a.wThis = 1.0f - temporal_weight;
+        hipLaunchKernelGGL(selfsim_tile_kernel, dim3(gt, gt), dim3(256), 0, ctx->stream, a);
+        SGZ_HIP(ctx, hipGetLastError());
+    }
+    int rc;
+    if (sim_out && (rc = copy_to_host(ctx, sim_out, simd.p, pix * sizeof(float)))) return rc;
+    if (img_out && (rc = copy_to_host(ctx, img_out, imgd.p, pix * sizeof(int32_t)))) return rc;
     SGZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return SGZ_OK;
 }
