@@ -123,12 +123,12 @@ __device__ int gray_color(float sim, double warp, float scale, int inv)
 // the sums in the frame of b are  S = Sa + n d + Sb,  Q = Qa + 2 d Sa + n d^2 + Qb,  P = P'' + d Sb,  where only
 // P'' = sum(a'' b'') couples x and y: the matrix product of the two column sets.  A workgroup of
 // selfsim_tile_kernel evaluates it for 128 x 128 pixels on the matrix cores in fp32 (v_mfma_f32_32x32x2_f32) over
-// runs of 32 products that are folded into fp64; everything else is fp64.
-// The error of P'' is at most 35 * 2^-24 * sqrt(Qa Qb); a pixel for which that could move the similarity by more
+// runs of 64 products that are folded into fp64; everything else is fp64.
+// The error of P'' is at most 67 * 2^-24 * sqrt(Qa Qb); a pixel for which that could move the similarity by more
 // than 8e-6 is evaluated by correlate_half_dev instead.
 // ---------------------------------------------------------------------------
 constexpr int kSsTile = 128;   // pixels per workgroup tile edge
-constexpr int kSsRun = 32;     // products per fp32 run
+constexpr int kSsRun = 32;     // products staged at a time (two of these per fp32 run)
 
 struct SelfSimStat {
     double S, Q;   // sum and sum of squares of the stored (shifted) values
@@ -182,6 +182,7 @@ struct SelfSimArgs {
     const SelfSimStat *st1, *st2;
     long long stride;
     int numCh, afStart, H, decim, imgExt;
+    int tilesEdge, superEdge;        // tiles and blocks of 8 x 8 tiles per edge of the matrix
     int c0, c1;                      // channel group of this pass
     int first, last;                 // first pass: no earlier part to read; last pass: writes the final values
     float wThis;                     // weight of this group's similarity
@@ -189,6 +190,7 @@ struct SelfSimArgs {
     float scale;
     int inv;
     float *simOut;                   // [imgExt][imgExt]; between two passes: the weighted first part, upper triangle
+    int wantSim;                     // the last pass writes the matrix
     int *imgOut;
 };
 
@@ -200,25 +202,30 @@ __device__ __noinline__ float correlate_half_exact(const float *xl, long long st
 
 // Similarity of one pixel's channel group from the product sum of its shifted columns and the statistics of its
 // two windows, or the mark for the exact evaluation.
-__device__ __forceinline__ float selfsim_pixel(const SelfSimStat &sA, const SelfSimStat &sB, double pSum, double dn,
-                                               float unsure)
+__device__ __forceinline__ float selfsim_pixel(double Sa, double Qa, double mua, double Sb, double Qb, double mub,
+                                               double pSum, double dn, double inv2n, float unsure)
 {
-    const double d = sA.mu - sB.mu;
-    const double S = sA.S + dn * d + sB.S;
-    const double Q = sA.Q + 2.0 * d * sA.S + dn * d * d + sB.Q;
-    const double varsum = Q - S * S / (2.0 * dn);
-    const double cross = pSum + d * sB.S - S * S / (4.0 * dn);
-    // 2 * 35 * 2^-24 * sqrt(Qa Qb) <= 8e-6 * varsum, squared (fails for NaN as well)
-    const bool sure = varsum >= 0.0 && 1.764e-11 * (sA.Q * sB.Q) <= 6.4e-11 * (varsum * varsum);
-    return sure ? (float)(2.0 * cross / varsum) : unsure;
+    const double d = mua - mub;
+    const double S = Sa + dn * d + Sb;
+    const double Q = Qa + 2.0 * d * Sa + dn * d * d + Qb;
+    const double s2 = S * S * inv2n;
+    const double varsum = Q - s2;
+    const double cross2 = 2.0 * (pSum + d * Sb) - s2;  // twice the centred product sum
+    // 2 * 67 * 2^-24 * sqrt(Qa Qb) <= 8e-6 * varsum, squared (fails for NaN as well)
+    const bool sure = varsum >= 0.0 && 6.38e-11 * (Qa * Qb) <= 6.4e-11 * (varsum * varsum);
+    return sure ? (float)cross2 / (float)varsum : unsure;
 }
 
 typedef __attribute__((address_space(3))) void ss_lds_void;
 
 __global__ __launch_bounds__(256, 2) void selfsim_tile_kernel(SelfSimArgs g)
 {
-    const int tileX = blockIdx.x, tileY = blockIdx.y;
-    if (tileY < tileX) return;  // pixels with y >= x only (:127-163); the rest is mirrored
+    // Workgroups go round robin over the 8 XCDs, each with its own L2: the 64 workgroups that follow each other
+    // on one XCD form a block of 8 x 8 tiles, which share 8 + 8 column sets.
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    const int super = (slot >> 6) * 8 + xcd, within = slot & 63;
+    const int tileX = (super % g.superEdge) * 8 + (within & 7), tileY = (super / g.superEdge) * 8 + (within >> 3);
+    if (tileY < tileX || tileY >= g.tilesEdge) return;  // pixels with y >= x only (:127-163); the rest is mirrored
     // two stages of one run for both sides (rows of 128 columns: side 1, then side 2); afterwards the
     // similarities of half a tile (64 x 128, rows padded)
     constexpr int kStage = 2 * kSsRun * kSsTile;  // floats
@@ -274,19 +281,32 @@ __global__ __launch_bounds__(256, 2) void selfsim_tile_kernel(SelfSimArgs g)
     stage(0, 0);
     int buf = 0;
     for (int e0 = 0; e0 < n; e0 += kSsRun, buf ^= 1) {
-        const int len = min(kSsRun, n - e0);
         __syncthreads();  // retires the loads of this run; everyone is done with the other stage
         if (e0 + kSsRun < n) stage(e0 + kSsRun, buf ^ 1);
         const float *Aw = lds + buf * kStage + lhi * kSsTile + 64 * wx + l32;
         const float *Bw = lds + buf * kStage + kSsRun * kSsTile + lhi * kSsTile + 64 * wy + l32;
-        for (int r = 0; r < len; r += 2) {  // (a row past an odd length holds zeros)
-            const float a0 = Aw[r * kSsTile], a1 = Aw[r * kSsTile + 32];
-            const float b0 = Bw[r * kSsTile], b1 = Bw[r * kSsTile + 32];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        {
+            // Always the whole stage: rows past the end of a short last run were staged as zeros.  Straight-line;
+            // the operands of the next step are fetched while the matrix cores work on this one (the scheduling
+            // barriers keep that order).
+            float a[2][2], b[2][2];
+            a[0][0] = Aw[0], a[0][1] = Aw[32], b[0][0] = Bw[0], b[0][1] = Bw[32];
+#pragma unroll
+            for (int r = 0; r < kSsRun; r += 2) {
+                const int cur = (r >> 1) & 1, nxt = cur ^ 1;
+                if (r + 2 < kSsRun) {
+                    a[nxt][0] = Aw[(r + 2) * kSsTile], a[nxt][1] = Aw[(r + 2) * kSsTile + 32];
+                    b[nxt][0] = Bw[(r + 2) * kSsTile], b[nxt][1] = Bw[(r + 2) * kSsTile + 32];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][0], b[cur][0], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][0], b[cur][1], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][1], b[cur][0], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][1], b[cur][1], acc[1][1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
+        if (buf == 0 && e0 + kSsRun < n) continue;  // fold after every second run and after the last
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -301,24 +321,33 @@ __global__ __launch_bounds__(256, 2) void selfsim_tile_kernel(SelfSimArgs g)
     // Similarities, half a tile at a time through LDS (row rho of the staging area = pixel row
     // 64 (rho / 32) + 32 half + rho % 32 of the tile) so that the rows of the matrix and of its mirror image are
     // written by neighbouring lanes.
-    const double dn = (double)n;
+    const double dn = (double)n, inv2n = 1.0 / (2.0 * dn);
     constexpr int kRow = kSsTile + 1;
     const float kUnsure = __int_as_float(0x7fc0beef);  // marks a pixel for the exact evaluation
+    // statistics of the tile's 128 + 128 windows (indices past the end clamped: those pixels are never written)
+    double *stS = reinterpret_cast<double *>(lds + 64 * kRow), *stQ = stS + 2 * kSsTile, *stMu = stQ + 2 * kSsTile;
+    static_assert((64 * kRow) % 2 == 0 && 64 * kRow + 12 * kSsTile <= 2 * kStage, "statistics must fit behind the rows");
+    __syncthreads();
+    {
+        const int wdw = min((tid < kSsTile ? X0 + tid : Y0 + tid - kSsTile), g.imgExt - 1);
+        const SelfSimStat st = (tid < kSsTile ? g.st1 : g.st2)[2 * (long long)wdw + group];
+        stS[tid] = st.S;
+        stQ[tid] = st.Q;
+        stMu[tid] = st.mu;
+    }
     for (int half = 0; half < 2; half++) {
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < 2; j++) {
-            const int pyl = 64 * wy + 32 * j + l32, py = Y0 + pyl;
-            if (py >= g.imgExt) continue;
-            const SelfSimStat sB = g.st2[2 * (long long)py + group];
+            const int pyl = 64 * wy + 32 * j + l32;
+            const double Sb = stS[kSsTile + pyl], Qb = stQ[kSsTile + pyl], mub = stMu[kSsTile + pyl];
 #pragma unroll
             for (int v = 0; v < 16; v++) {
                 const int rowInTile = 8 * (v >> 2) + 4 * lhi + (v & 3);
-                const int px = X0 + 64 * wx + 32 * half + rowInTile;
-                if (px >= g.imgExt || py < px) continue;
-                const SelfSimStat sA = g.st1[2 * (long long)px + group];
+                const int pxl = 64 * wx + 32 * half + rowInTile;
                 const double pSum = half == 0 ? sum[0][j][v] : sum[1][j][v];
-                lds[(32 * wx + rowInTile) * kRow + pyl] = selfsim_pixel(sA, sB, pSum, dn, kUnsure);
+                lds[(32 * wx + rowInTile) * kRow + pyl] =
+                    selfsim_pixel(stS[pxl], stQ[pxl], stMu[pxl], Sb, Qb, mub, pSum, dn, inv2n, kUnsure);
             }
         }
         __syncthreads();
@@ -336,7 +365,7 @@ __global__ __launch_bounds__(256, 2) void selfsim_tile_kernel(SelfSimArgs g)
             float sim = part * g.wThis;
             const long long up = (long long)px * g.imgExt + py;
             if (!g.first) sim = g.simOut[up] + sim;
-            if (g.simOut) g.simOut[up] = sim;
+            if (!g.last || g.wantSim) g.simOut[up] = sim;
             if (g.last) {
                 lds[pxl * kRow + pyl] = sim;
                 if (g.imgOut)
@@ -351,7 +380,7 @@ __global__ __launch_bounds__(256, 2) void selfsim_tile_kernel(SelfSimArgs g)
             const int px = XH + 64 * (pxl >> 5) + (pxl & 31), py = Y0 + pyl;
             if (px >= g.imgExt || py >= g.imgExt || py <= px) continue;
             const float sim = lds[pxl * kRow + pyl];
-            if (g.simOut) g.simOut[(long long)py * g.imgExt + px] = sim;
+            if (g.wantSim) g.simOut[(long long)py * g.imgExt + px] = sim;
             if (g.imgOut)
                 g.imgOut[(long long)(g.imgExt - 1 - px) * g.imgExt + py] = gray_color(sim, g.warp, g.scale, g.inv);
         }
@@ -552,10 +581,15 @@ int sgz_selfsim_run(sgz_context *ctx, const float *frames1, int64_t num_frames1,
     a.H = half_win;
     a.decim = decim;
     a.imgExt = img_ext;
+    a.tilesEdge = (int)gt;
+    a.superEdge = (int)((gt + 7) / 8);
+    const unsigned supers = (unsigned)a.superEdge * a.superEdge;
+    const unsigned gridWGs = ((supers + 7) / 8) * 8 * 64;
     a.warp = (double)color_warp;
     a.scale = 1.0f / color_ceil;
     a.inv = color_inv;
     a.simOut = (float *)simd.p;
+    a.wantSim = sim_out ? 1 : 0;
     a.imgOut = (int *)imgd.p;
     if (doT) {
         a.c0 = 0;
@@ -563,7 +597,7 @@ int sgz_selfsim_run(sgz_context *ctx, const float *frames1, int64_t num_frames1,
         a.first = 1;
         a.last = doS ? 0 : 1;
         a.wThis = temporal_weight;
-        hipLaunchKernelGGL(selfsim_tile_kernel, dim3(gt, gt), dim3(256), 0, ctx->stream, a);
+        hipLaunchKernelGGL(selfsim_tile_kernel, dim3(gridWGs), dim3(256), 0, ctx->stream, a);
         SGZ_HIP(ctx, hipGetLastError());
     }
     if (doS) {
@@ -572,7 +606,7 @@ int sgz_selfsim_run(sgz_context *ctx, const float *frames1, int64_t num_frames1,
         a.first = doT ? 0 : 1;
         a.last = 1;
         a.wThis = 1.0f - temporal_weight;
-        hipLaunchKernelGGL(selfsim_tile_kernel, dim3(gt, gt), dim3(256), 0, ctx->stream, a);
+        hipLaunchKernelGGL(selfsim_tile_kernel, dim3(gridWGs), dim3(256), 0, ctx->stream, a);
         SGZ_HIP(ctx, hipGetLastError());
     }
     int rc;
