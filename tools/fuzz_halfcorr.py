@@ -1,4 +1,4 @@
-"""Random FeatureSegmentation, SelfSimilarity, FeatureStats and CrossSimilarity inputs on the GPU against the
+"""Random FeatureSegmentation, SelfSimilarity, FeatureStats, CrossSimilarity and FeatureExtraction inputs on the GPU against the
 oracle (ragged sizes, channel counts, awkward data).  usage: fuzz_halfcorr.py [cases] [seed]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -128,6 +128,33 @@ def _cross(ctx, rng):
     return None
 
 
+def _extract(ctx, rng):
+    """FeatureExtraction on random PCM: lengths around the framing's edges, channel behaviours, fft sizes."""
+    fft = int(rng.choice([256, 512, 1024, 2048]))
+    ov = int(rng.choice([1, 2, 4]))
+    nco = int(rng.choice([5, 13, 20]))
+    chans = int(rng.choice([1, 1, 2, 3]))
+    n = int(rng.choice([1, fft // ov - 1, fft // ov, fft, fft + 1, int(rng.integers(2, 60000))]))
+    sr = float(rng.choice([22050.0, 44100.0, 48000.0]))
+    t = np.arange(n, dtype=np.float32)[:, None]
+    f0 = rng.uniform(50.0, 4000.0, size=(1, chans)).astype(np.float32)
+    pcm = (0.3 * np.sin(t * (2 * np.pi * f0 / sr)) + 0.05 * rng.standard_normal((n, chans))).astype(np.float32)
+    kind = int(rng.integers(0, 6))
+    if kind == 0:
+        pcm[:] = 0.0
+    elif kind == 1:
+        pcm *= np.float32(1e-4)
+    elif kind == 2 and n > 10:
+        pcm[n // 3: n // 2] = 0.0
+    behav = int(rng.integers(0, 3))
+    want = O.extract(pcm, sr, fft, ov, nco, behav)
+    got = ctx.extract(pcm, sr, fft, ov, nco, behav)
+    if got.shape != want.shape or not _same(got, want, 2e-5):
+        worst = float(np.nanmax(np.abs(got - want))) if got.shape == want.shape and got.size else -1.0
+        return f"extract n={n} ch={chans} fft={fft} ov={ov} coeffs={nco} behav={behav} sr={sr} kind={kind} worst={worst}"
+    return None
+
+
 def run(cases: int, seed: int, ctx=None, verbose=True) -> int:
     rng = np.random.default_rng(seed)
     own = ctx is None
@@ -135,7 +162,7 @@ def run(cases: int, seed: int, ctx=None, verbose=True) -> int:
         ctx = S.Context(0)
     bad = 0
     for case in range(cases):
-        fn = (_segm, _selfsim, _stats, _cross)[case % 4]
+        fn = (_segm, _selfsim, _stats, _cross, _extract)[case % 5]
         msg = fn(ctx, rng)
         if msg:
             bad += 1
