@@ -131,8 +131,9 @@ constexpr int kSsTile = 128;   // pixels per workgroup tile edge
 constexpr int kSsRun = 32;     // products staged at a time (two of these per fp32 run)
 
 struct SelfSimStat {
-    double S, Q;   // sum and sum of squares of the stored (shifted) values
-    double mu;     // the shift
+    double S, Q;    // sum and sum of squares of the stored (shifted) values
+    double mu;      // the shift
+    double SR, QR;  // sum and sum of squares of the values themselves
     double pad;
 };
 
@@ -170,6 +171,9 @@ __global__ __launch_bounds__(256) void selfsim_gather_kernel(const float *__rest
         st.S = S;
         st.Q = Q;
         st.mu = (double)mu;
+        const double cnt = (double)(c1 - c0) * H;
+        st.SR = S + cnt * (double)mu;
+        st.QR = Q + 2.0 * (double)mu * S + cnt * (double)mu * (double)mu;
         st.pad = 0.0;
         stats[2 * w + group] = st;
     }
@@ -202,18 +206,22 @@ __device__ __noinline__ float correlate_half_exact(const float *xl, long long st
 
 // Similarity of one pixel's channel group from the product sum of its shifted columns and the statistics of its
 // two windows, or the mark for the exact evaluation.
-__device__ __forceinline__ float selfsim_pixel(double Sa, double Qa, double mua, double Sb, double Qb, double mub,
-                                               double pSum, double dn, double inv2n, float unsure)
+// Window a: shifted sum Sa, shift mua, raw sums SaR / QaR, and in fp32 its shifted sum of squares qa and
+// 1e-7 * QaR (ra); likewise b.  In fp64 the raw sums can be combined directly (their cancellation costs a relative
+// 1e-16 * QR / varsum, kept below 1e-8 by the second test); only the product sum needs the shifted columns:
+// sum(a b) = P'' + mua SbR + mub Sa.
+__device__ __forceinline__ float selfsim_pixel(double Sa, double mua, double SaR, double QaR, float qa, float ra,
+                                               double mub, double SbR, double QbR, float qb, float rb, double pSum,
+                                               double inv2n, float unsure)
 {
-    const double d = mua - mub;
-    const double S = Sa + dn * d + Sb;
-    const double Q = Qa + 2.0 * d * Sa + dn * d * d + Qb;
+    const double S = SaR + SbR;
     const double s2 = S * S * inv2n;
-    const double varsum = Q - s2;
-    const double cross2 = 2.0 * (pSum + d * Sb) - s2;  // twice the centred product sum
-    // 2 * 67 * 2^-24 * sqrt(Qa Qb) <= 8e-6 * varsum, squared (fails for NaN as well)
-    const bool sure = varsum >= 0.0 && 6.38e-11 * (Qa * Qb) <= 6.4e-11 * (varsum * varsum);
-    return sure ? (float)cross2 / (float)varsum : unsure;
+    const double varsum = (QaR + QbR) - s2;
+    const double cross2 = 2.0 * (fma(mua, SbR, fma(mub, Sa, pSum))) - s2;  // twice the centred product sum
+    const float v = (float)varsum;
+    // 2 * 67 * 2^-24 * sqrt(Qa Qb) <= 8e-6 * varsum, squared; both tests fail for NaN as well
+    const bool sure = 0.997f * qa * qb <= v * v && ra + rb <= v;
+    return sure ? (float)cross2 / v : unsure;
 }
 
 typedef __attribute__((address_space(3))) void ss_lds_void;
@@ -321,33 +329,40 @@ __global__ __launch_bounds__(256, 2) void selfsim_tile_kernel(SelfSimArgs g)
     // Similarities, half a tile at a time through LDS (row rho of the staging area = pixel row
     // 64 (rho / 32) + 32 half + rho % 32 of the tile) so that the rows of the matrix and of its mirror image are
     // written by neighbouring lanes.
-    const double dn = (double)n, inv2n = 1.0 / (2.0 * dn);
+    const double inv2n = 1.0 / (2.0 * (double)n);
     constexpr int kRow = kSsTile + 1;
     const float kUnsure = __int_as_float(0x7fc0beef);  // marks a pixel for the exact evaluation
     // statistics of the tile's 128 + 128 windows (indices past the end clamped: those pixels are never written)
-    double *stS = reinterpret_cast<double *>(lds + 64 * kRow), *stQ = stS + 2 * kSsTile, *stMu = stQ + 2 * kSsTile;
-    static_assert((64 * kRow) % 2 == 0 && 64 * kRow + 12 * kSsTile <= 2 * kStage, "statistics must fit behind the rows");
+    double *stS = reinterpret_cast<double *>(lds + 64 * kRow), *stMu = stS + 2 * kSsTile, *stSR = stMu + 2 * kSsTile,
+           *stQR = stSR + 2 * kSsTile;
+    float *stQ32 = reinterpret_cast<float *>(stQR + 2 * kSsTile), *stR32 = stQ32 + 2 * kSsTile;
+    static_assert((64 * kRow) % 2 == 0 && 64 * kRow + 20 * kSsTile <= 2 * kStage, "statistics must fit behind the rows");
     __syncthreads();
     {
         const int wdw = min((tid < kSsTile ? X0 + tid : Y0 + tid - kSsTile), g.imgExt - 1);
         const SelfSimStat st = (tid < kSsTile ? g.st1 : g.st2)[2 * (long long)wdw + group];
         stS[tid] = st.S;
-        stQ[tid] = st.Q;
         stMu[tid] = st.mu;
+        stSR[tid] = st.SR;
+        stQR[tid] = st.QR;
+        stQ32[tid] = (float)st.Q;
+        stR32[tid] = (float)(1.0e-7 * st.QR);
     }
     for (int half = 0; half < 2; half++) {
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < 2; j++) {
-            const int pyl = 64 * wy + 32 * j + l32;
-            const double Sb = stS[kSsTile + pyl], Qb = stQ[kSsTile + pyl], mub = stMu[kSsTile + pyl];
+            const int pyl = 64 * wy + 32 * j + l32, yb = kSsTile + pyl;
+            const double mub = stMu[yb], SbR = stSR[yb], QbR = stQR[yb];
+            const float qb = stQ32[yb], rb = stR32[yb];
 #pragma unroll
             for (int v = 0; v < 16; v++) {
                 const int rowInTile = 8 * (v >> 2) + 4 * lhi + (v & 3);
                 const int pxl = 64 * wx + 32 * half + rowInTile;
                 const double pSum = half == 0 ? sum[0][j][v] : sum[1][j][v];
                 lds[(32 * wx + rowInTile) * kRow + pyl] =
-                    selfsim_pixel(stS[pxl], stQ[pxl], stMu[pxl], Sb, Qb, mub, pSum, dn, inv2n, kUnsure);
+                    selfsim_pixel(stS[pxl], stMu[pxl], stSR[pxl], stQR[pxl], stQ32[pxl], stR32[pxl], mub, SbR, QbR, qb,
+                                  rb, pSum, inv2n, kUnsure);
             }
         }
         __syncthreads();
