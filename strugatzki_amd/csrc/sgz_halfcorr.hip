@@ -289,7 +289,10 @@ __global__ __launch_bounds__(256, 2) void selfsim_tile_kernel(SelfSimArgs g)
     stage(0, 0);
     int buf = 0;
     for (int e0 = 0; e0 < n; e0 += kSsRun, buf ^= 1) {
-        __syncthreads();  // retires the loads of this run; everyone is done with the other stage
+        // every direct-to-LDS load of this wave has to have landed before the barrier lets other waves read the
+        // stage (the compiler only waits for what this wave's own reads may touch): vmcnt(0)
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();  // everyone is done with the other stage
         if (e0 + kSsRun < n) stage(e0 + kSsRun, buf ^ 1);
         const float *Aw = lds + buf * kStage + lhi * kSsTile + 64 * wx + l32;
         const float *Bw = lds + buf * kStage + kSsRun * kSsTile + lhi * kSsTile + 64 * wy + l32;
@@ -383,8 +386,10 @@ __global__ __launch_bounds__(256, 2) void selfsim_tile_kernel(SelfSimArgs g)
             if (!g.last || g.wantSim) g.simOut[up] = sim;
             if (g.last) {
                 lds[pxl * kRow + pyl] = sim;
+                // (the raster's row is imgExt - 1 - y: of the two pixels that show this value, the one whose
+                // neighbours along y lie in the same row)
                 if (g.imgOut)
-                    g.imgOut[(long long)(g.imgExt - 1 - py) * g.imgExt + px] = gray_color(sim, g.warp, g.scale, g.inv);
+                    g.imgOut[(long long)(g.imgExt - 1 - px) * g.imgExt + py] = gray_color(sim, g.warp, g.scale, g.inv);
             }
         }
         if (!g.last) continue;
@@ -397,7 +402,7 @@ __global__ __launch_bounds__(256, 2) void selfsim_tile_kernel(SelfSimArgs g)
             const float sim = lds[pxl * kRow + pyl];
             if (g.wantSim) g.simOut[(long long)py * g.imgExt + px] = sim;
             if (g.imgOut)
-                g.imgOut[(long long)(g.imgExt - 1 - px) * g.imgExt + py] = gray_color(sim, g.warp, g.scale, g.inv);
+                g.imgOut[(long long)(g.imgExt - 1 - py) * g.imgExt + px] = gray_color(sim, g.warp, g.scale, g.inv);
         }
     }
 }
