@@ -53,11 +53,21 @@ __global__ __launch_bounds__(64 * kFramesPerBlock) void extract_kernel(const flo
                                                                        BandTable bt, ExtractParams p,
                                                                        float *__restrict__ out)
 {
-    extern __shared__ __attribute__((aligned(16))) float2 lds[];  // kFramesPerBlock x (M + 1)
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];  // kFramesPerBlock x (M + 8), then M twiddles
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     const int M = p.fftSize >> 1;
     float2 *z = lds + wv * (M + 8);
+    float2 *tw = lds + kFramesPerBlock * (M + 8);  // the twiddle table, shared by the workgroup's waves
+    for (int n = threadIdx.x; n < M; n += 64 * kFramesPerBlock) tw[n] = twiddle[n];
+    float *dctL = reinterpret_cast<float *>(tw + M);  // the DCT table [numCoeffs][kBands]
+    for (int n = threadIdx.x; n < p.numCoeffs * kBands; n += 64 * kFramesPerBlock) dctL[n] = dct[n];
+    // a wave works on its own frame: between the steps below only its own lanes exchange data through LDS
+    auto waveSync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
     const long long i = (long long)blockIdx.x * kFramesPerBlock + wv;  // output frame
     const bool live = i < p.numOut;
     const long long k = i + 1;
@@ -67,6 +77,7 @@ __global__ __launch_bounds__(64 * kFramesPerBlock) void extract_kernel(const flo
 
     // 1. load + mix down + window, bit-reversed complex packing z[rev(n)] = x[2n] + i x[2n+1]
     if (analysed) {
+#pragma unroll 8
         for (int n = lane; n < M; n += 64) {
             float xv[2];
 #pragma unroll
@@ -85,23 +96,24 @@ __global__ __launch_bounds__(64 * kFramesPerBlock) void extract_kernel(const flo
             z[r] = make_float2(xv[0], xv[1]);
         }
     }
-    __syncthreads();
+    __syncthreads();  // (the twiddle table is complete)
     // 2. radix-2 decimation-in-time stages over M complex points
     for (int s = 1; s <= p.logM; s++) {
         const int half = 1 << (s - 1);
         const int tstride = p.fftSize >> s;  // twiddle index stride: w_len^j = w_fftSize^(j * fftSize / len)
         if (analysed) {
+#pragma unroll 4
             for (int b = lane; b < (M >> 1); b += 64) {
                 const int j = b & (half - 1);
                 const int a = ((b >> (s - 1)) << s) + j;
-                const float2 w = twiddle[j * tstride];
+                const float2 w = tw[j * tstride];
                 const float2 u = z[a];
                 const float2 t = cmul(z[a + half], w);
                 z[a] = make_float2(u.x + t.x, u.y + t.y);
                 z[a + half] = make_float2(u.x - t.x, u.y - t.y);
             }
         }
-        __syncthreads();
+        waveSync();
     }
     // 3. unpack to the spectrum of the real signal, keep |X[k]|^2 * norm in place (as .x), k = 0..M
     //    X[k] = (Z[k] + conj Z[M-k]) / 2 - i w^k (Z[k] - conj Z[M-k]) / 2
@@ -113,14 +125,14 @@ __global__ __launch_bounds__(64 * kFramesPerBlock) void extract_kernel(const flo
             {
                 const float2 e = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
                 const float2 o = make_float2(0.5f * (zk.x - zm.x), 0.5f * (zk.y + zm.y));
-                const float2 w = kk < M ? twiddle[kk] : make_float2(-1.0f, 0.0f);
+                const float2 w = kk < M ? tw[kk] : make_float2(-1.0f, 0.0f);
                 const float2 t = cmul(o, w);  // w^k * o ; X = e - i t
                 const float xr = e.x + t.y, xi = e.y - t.x;
                 const float pk = (xr * xr + xi * xi) * p.norm;
                 // bin M - kk from the same pair
                 const float2 e2 = make_float2(e.x, -e.y);
                 const float2 o2 = make_float2(-o.x, o.y);
-                const float2 w2 = mk < M ? twiddle[mk] : make_float2(-1.0f, 0.0f);
+                const float2 w2 = mk < M ? tw[mk] : make_float2(-1.0f, 0.0f);
                 const float2 t2 = cmul(o2, w2);
                 const float yr = e2.x + t2.y, yi = e2.y - t2.x;
                 const float pm = (yr * yr + yi * yi) * p.norm;
@@ -136,7 +148,7 @@ __global__ __launch_bounds__(64 * kFramesPerBlock) void extract_kernel(const flo
             }
         }
     }
-    __syncthreads();
+    waveSync();
     // 4. band energies -> dB, loudness
     float db = 0.0f, sone = 0.0f;
     if (analysed && lane < kBands) {
@@ -145,10 +157,12 @@ __global__ __launch_bounds__(64 * kFramesPerBlock) void extract_kernel(const flo
         int b1 = (int)floorf(e2);
         if (b1 > M) b1 = M;
         float e = 0.0f;
+#pragma unroll 4
         for (int b = b0; b <= b1; b++) {
             const float fb = (float)b;
             const float w = fb <= e1 ? (e1 > e0 ? (fb - e0) / (e1 - e0) : 1.0f) : (e2 > e1 ? (e2 - fb) / (e2 - e1) : 0.0f);
-            if (w > 0.0f) e += w * z[b].x;
+            const float x = z[b].x;
+            e += w > 0.0f ? w * x : 0.0f;  // (adding 0.0f leaves e >= 0 as it is)
         }
         db = 100.0f + 10.0f * log10f(e + 1e-10f);
         if (db < 0.0f) db = 0.0f;
@@ -164,7 +178,7 @@ __global__ __launch_bounds__(64 * kFramesPerBlock) void extract_kernel(const flo
     float coef = 0.0f;
     for (int j = 0; j < kBands; j++) {
         const float dj = __shfl(db, j, 64);
-        if (lane < p.numCoeffs) coef += dct[lane * kBands + j] * dj;
+        if (lane < p.numCoeffs) coef += dctL[lane * kBands + j] * dj;
     }
     if (live) {
         float *o = out + i * numCh;
@@ -279,7 +293,7 @@ int sgz_extract(sgz_context *ctx, const float *pcm, int64_t num_frames, int num_
         const int erc = ctx->next_event_pair();
         if (erc) return erc;
     }
-    const size_t lds = sizeof(float2) * (size_t)kFramesPerBlock * (M + 8);
+    const size_t lds = sizeof(float2) * ((size_t)kFramesPerBlock * (M + 8) + (size_t)M) + sizeof(float) * (size_t)num_coeffs * kBands;
     const unsigned grid = (unsigned)((nOut + kFramesPerBlock - 1) / kFramesPerBlock);
     SGZ_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     hipLaunchKernelGGL(extract_kernel, dim3(grid), dim3(64 * kFramesPerBlock), lds, ctx->stream,
