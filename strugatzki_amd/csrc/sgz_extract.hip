@@ -17,6 +17,7 @@
 // fixed summation order), then DCT / loudness with wave shuffles.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <vector>
 
@@ -40,8 +41,9 @@ struct ExtractParams {
 };
 
 struct BandTable {
-    float e0[kBands], e1[kBands], e2[kBands];  // band edges in fractional bins
-    float aw[kBands];                          // A-weighting at the band centre, dB
+    int b0[kBands], cnt[kBands];  // first bin and number of bins of the band's triangle
+    float aw[kBands];             // A-weighting at the band centre, dB
+    int maxCnt;                   // row length of the weight table
 };
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
@@ -50,6 +52,7 @@ __global__ __launch_bounds__(64 * kFramesPerBlock) void extract_kernel(const flo
                                                                        const float2 *__restrict__ twiddle,  // e^{-2 pi i k / fftSize}, k < fftSize/2
                                                                        const float *__restrict__ hann,
                                                                        const float *__restrict__ dct,       // [numCoeffs][kBands]
+                                                                       const float *__restrict__ bandW,     // [maxCnt][kBands] triangle weights
                                                                        BandTable bt, ExtractParams p,
                                                                        float *__restrict__ out)
 {
@@ -152,16 +155,11 @@ __global__ __launch_bounds__(64 * kFramesPerBlock) void extract_kernel(const flo
     // 4. band energies -> dB, loudness
     float db = 0.0f, sone = 0.0f;
     if (analysed && lane < kBands) {
-        const float e0 = bt.e0[lane], e1 = bt.e1[lane], e2 = bt.e2[lane];
-        const int b0 = (int)ceilf(e0);
-        int b1 = (int)floorf(e2);
-        if (b1 > M) b1 = M;
+        const int b0 = bt.b0[lane], cnt = bt.cnt[lane];
         float e = 0.0f;
 #pragma unroll 4
-        for (int b = b0; b <= b1; b++) {
-            const float fb = (float)b;
-            const float w = fb <= e1 ? (e1 > e0 ? (fb - e0) / (e1 - e0) : 1.0f) : (e2 > e1 ? (e2 - fb) / (e2 - e1) : 0.0f);
-            const float x = z[b].x;
+        for (int t = 0; t < cnt; t++) {
+            const float w = bandW[t * kBands + lane], x = z[b0 + t].x;
             e += w > 0.0f ? w * x : 0.0f;  // (adding 0.0f leaves e >= 0 as it is)
         }
         db = 100.0f + 10.0f * log10f(e + 1e-10f);
@@ -265,19 +263,33 @@ int sgz_extract(sgz_context *ctx, const float *pcm, int64_t num_frames, int num_
     for (int c = 0; c < num_coeffs; c++)
         for (int j = 0; j < kBands; j++) dct[(size_t)c * kBands + j] = (float)std::cos(M_PI / kBands * (j + 0.5) * c);
     BandTable bt;
+    std::vector<float> bandW;
     {
         const double mHi = melOfHz(sample_rate * 0.5);
         double e[kBands + 2];
         for (int j = 0; j < kBands + 2; j++) e[j] = hzOfMel(mHi * j / (kBands + 1)) * fft_size / sample_rate;
+        bt.maxCnt = 1;
         for (int j = 0; j < kBands; j++) {
-            bt.e0[j] = (float)e[j];
-            bt.e1[j] = (float)e[j + 1];
-            bt.e2[j] = (float)e[j + 2];
+            const float e0 = (float)e[j], e2 = (float)e[j + 2];
+            bt.b0[j] = (int)std::ceil(e0);
+            const int b1 = std::min((int)std::floor(e2), M);
+            bt.cnt[j] = std::max(b1 - bt.b0[j] + 1, 0);
+            bt.maxCnt = std::max(bt.maxCnt, bt.cnt[j]);
             bt.aw[j] = (float)aWeightDb(e[j + 1] * sample_rate / fft_size);
+        }
+        // triangle weights in fp32, bin by bin
+        bandW.assign((size_t)bt.maxCnt * kBands, 0.0f);
+        for (int j = 0; j < kBands; j++) {
+            const float e0 = (float)e[j], e1 = (float)e[j + 1], e2 = (float)e[j + 2];
+            for (int t = 0; t < bt.cnt[j]; t++) {
+                const float fb = (float)(bt.b0[j] + t);
+                bandW[(size_t)t * kBands + j] =
+                    fb <= e1 ? (e1 > e0 ? (fb - e0) / (e1 - e0) : 1.0f) : (e2 > e1 ? (e2 - fb) / (e2 - e1) : 0.0f);
+            }
         }
     }
 
-    DevBuf dPcm, dTw, dHann, dDct, dOut;
+    DevBuf dPcm, dTw, dHann, dDct, dOut, dBandW;
     const size_t pcmBytes = sizeof(float) * (size_t)num_frames * num_channels;
     const size_t outBytes = sizeof(float) * (size_t)nOut * (num_coeffs + 1);
     SGZ_HIP(ctx, hipMalloc(&dPcm.p, pcmBytes));
@@ -285,6 +297,8 @@ int sgz_extract(sgz_context *ctx, const float *pcm, int64_t num_frames, int num_
     SGZ_HIP(ctx, hipMalloc(&dHann.p, sizeof(float) * hann.size()));
     SGZ_HIP(ctx, hipMalloc(&dDct.p, sizeof(float) * dct.size()));
     SGZ_HIP(ctx, hipMalloc(&dOut.p, outBytes));
+    SGZ_HIP(ctx, hipMalloc(&dBandW.p, sizeof(float) * bandW.size()));
+    SGZ_HIP(ctx, hipMemcpyAsync(dBandW.p, bandW.data(), sizeof(float) * bandW.size(), hipMemcpyHostToDevice, ctx->stream));
     SGZ_HIP(ctx, hipMemcpyAsync(dPcm.p, pcm, pcmBytes, hipMemcpyHostToDevice, ctx->stream));
     SGZ_HIP(ctx, hipMemcpyAsync(dTw.p, tw.data(), sizeof(float2) * tw.size(), hipMemcpyHostToDevice, ctx->stream));
     SGZ_HIP(ctx, hipMemcpyAsync(dHann.p, hann.data(), sizeof(float) * hann.size(), hipMemcpyHostToDevice, ctx->stream));
@@ -297,7 +311,7 @@ int sgz_extract(sgz_context *ctx, const float *pcm, int64_t num_frames, int num_
     const unsigned grid = (unsigned)((nOut + kFramesPerBlock - 1) / kFramesPerBlock);
     SGZ_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     hipLaunchKernelGGL(extract_kernel, dim3(grid), dim3(64 * kFramesPerBlock), lds, ctx->stream,
-                       (const float *)dPcm.p, (const float2 *)dTw.p, (const float *)dHann.p, (const float *)dDct.p, bt,
+                       (const float *)dPcm.p, (const float2 *)dTw.p, (const float *)dHann.p, (const float *)dDct.p, (const float *)dBandW.p, bt,
                        p, (float *)dOut.p);
     SGZ_HIP(ctx, hipGetLastError());
     SGZ_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
