@@ -1,5 +1,5 @@
 """Random search configurations on the GPU against the oracle: match list (file, span) identical, similarities
-within one fp32 ulp.  usage: fuzz_parity.py [cases] [seed]"""
+within one fp32 ulp.  usage: fuzz_parity.py [--big] [cases] [seed]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -7,6 +7,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from common import STEP, O, corr_config, make_plants, norms_default, synth_db, synth_target
 import strugatzki_amd as S
+
+BIG = False  # long targets and files of several kernel tiles (slow on the oracle's side: few cases)
+
 
 def run(cases: int, seed: int, ctx=None, verbose=True) -> int:
     """Runs `cases` random configurations; returns the number of mismatches."""
@@ -17,6 +20,8 @@ def run(cases: int, seed: int, ctx=None, verbose=True) -> int:
     bad = 0
     for case in range(cases):
         bad += 0 if _one_case(ctx, rng, case, verbose) else 1
+        if verbose and case % 20 == 19:
+            print(f"{case + 1} cases, {bad} mismatches so far", flush=True)
     if own:
         ctx.close()
     return bad
@@ -24,9 +29,9 @@ def run(cases: int, seed: int, ctx=None, verbose=True) -> int:
 
 def _one_case(ctx, rng, case, verbose) -> bool:
     num_ch = int(rng.choice([2, 5, 14, 14, 14, 21]))
-    L = int(rng.choice([3, 16, 17, 40, 96, 150, 431, 700]))
+    L = int(rng.choice([431, 700, 1000, 2584] if BIG else [3, 16, 17, 40, 96, 150, 431, 700]))
     nf = int(rng.integers(1, 9))
-    frames = [int(rng.integers(max(1, L // 2), 4 * L + 900)) for _ in range(nf)]
+    frames = [int(rng.integers(max(1, L // 2), (12000 if BIG else 4 * L + 900))) for _ in range(nf)]
     ts = int(rng.integers(0, 30))
     num_matches = int(rng.integers(1, 8))
     num_per_file = int(rng.choice([1, 1, 1, 2, 3]))
@@ -78,6 +83,9 @@ def _one_case(ctx, rng, case, verbose) -> bool:
 
 
 if __name__ == "__main__":
+    if "--big" in sys.argv:
+        sys.argv.remove("--big")
+        BIG = True
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     bad = run(n, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     print(f"{n} cases, {bad} mismatches", flush=True)
