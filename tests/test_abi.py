@@ -57,5 +57,6 @@ def test_null_and_bad_arguments_are_refused_without_a_gpu():
     n = C.c_int(0)
     assert lib.sgz_corr_search(None, 10, 1, 1, 0, 512, N.SGZ_SCREEN_AUTO, 1, 1024, -1.0, None, 0, C.byref(n)) == N.SGZ_E_ARG
     assert lib.sgz_set_kernel_timing(None, 1) == N.SGZ_E_ARG
+    assert lib.sgz_corr_set_tail_trim(None, 0) == N.SGZ_E_ARG
     assert lib.sgz_kernel_ms_history(None, None, 0) == N.SGZ_E_ARG
     assert lib.sgz_sel_feed_gathered(None, None, 1, 1, None, None, 0, 0) == N.SGZ_E_ARG

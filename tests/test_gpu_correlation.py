@@ -481,3 +481,35 @@ def test_constant_stretches_in_the_exact_kernel(ctx, weight):
     for screen in (False, "f32", "auto"):
         got = S.search(ctx, S.SearchParams(5, 2, 0, STEP, screen=bool(screen), screen_mode=screen or "auto"))
         assert [(g.file, g.start, g.stop) for g in got] == [(w.file, w.start, w.stop) for w in want]
+
+
+def test_tail_trim_shortens_every_file(ctx):
+    """sgz_corr_set_tail_trim: window counts and values are those of the files without their last frames; a file
+    that becomes shorter than the target keeps one window, an emptied one none; 0 restores whole files."""
+    L, trim = 40, 25
+    db = synth_db(4, [300, 60, 20, 140], [])
+    tgt = synth_target(3, L)
+    norms = norms_default()
+
+    def dense(files, t):
+        ctx.db_reset(NUM_CH)
+        for f in files:
+            ctx.db_add_file(f)
+        ctx.set_norms(norms)
+        ctx.corr_set_tail_trim(t)
+        ctx.corr_set_target(tgt[3:3 + L], 0.5, 8.0)
+        ctx.corr_run(0, len(files))
+        counts = [ctx.corr_num_windows(f) for f in range(len(files))]
+        return counts, ctx.corr_read_dense_range(0, len(files))
+
+    counts, got = dense(db, trim)
+    assert counts == [300 - trim - L + 1, 1, 0, 140 - trim - L + 1]
+    cut_counts, want = dense([x[:max(x.shape[0] - trim, 0)] for x in db], 0)
+    assert cut_counts == counts
+    for (gs, gb), (ws, wb) in zip(got, want):
+        assert np.array_equal(gs, ws, equal_nan=True) and np.array_equal(gb, wb, equal_nan=True)
+    import strugatzki_amd as S
+    with pytest.raises(S.NativeError):
+        ctx.corr_set_tail_trim(-1)
+    full_counts, _ = dense(db, 0)
+    assert full_counts == [261, 21, 1, 101]
