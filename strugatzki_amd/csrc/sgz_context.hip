@@ -1,6 +1,12 @@
 // Context life cycle of libstrugatzki_amd.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <atomic>
+#include <cstring>
+#include <thread>
+#include <vector>
+
 #include "sgz_internal.hpp"
 
 extern "C" {
@@ -115,3 +121,48 @@ int sgz_synchronize(sgz_context *ctx)
 }
 
 }  // extern "C"
+
+// Large transfers between pageable host memory and the device go through several pinned staging buffers, one
+// thread and stream each: a single pageable copy is bound by one core's page faults and memcpy (about 9 GB/s to
+// the host, 27 GB/s from it), well below the link.  Synchronous; work queued on ctx->stream is waited for first.
+int sgz::copy_large(sgz_context *ctx, void *dst, const void *src, size_t bytes, bool to_host)
+{
+    constexpr size_t kChunk = (size_t)32 << 20;
+    constexpr int kThreads = 8;
+    if (bytes < 8 * kChunk) {
+        SGZ_HIP(ctx, hipMemcpyAsync(dst, src, bytes, to_host ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice, ctx->stream));
+        SGZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return SGZ_OK;
+    }
+    SGZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t chunks = (bytes + kChunk - 1) / kChunk;
+    std::atomic<size_t> next{0};
+    std::atomic<int> failed{0};
+    auto worker = [&]() {
+        void *pin = nullptr;
+        hipStream_t st = nullptr;
+        if (hipSetDevice(ctx->device) != hipSuccess || hipHostMalloc(&pin, kChunk, hipHostMallocDefault) != hipSuccess ||
+            hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
+            failed = 1;
+        } else {
+            for (size_t c = next++; c < chunks && !failed; c = next++) {
+                const size_t off = c * kChunk, len = std::min(kChunk, bytes - off);
+                if (!to_host) std::memcpy(pin, (const char *)src + off, len);
+                const hipError_t e = to_host ? hipMemcpyAsync(pin, (const char *)src + off, len, hipMemcpyDeviceToHost, st)
+                                             : hipMemcpyAsync((char *)dst + off, pin, len, hipMemcpyHostToDevice, st);
+                if (e != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+                    failed = 1;
+                    break;
+                }
+                if (to_host) std::memcpy((char *)dst + off, pin, len);
+            }
+        }
+        if (st) (void)hipStreamDestroy(st);
+        if (pin) (void)hipHostFree(pin);
+    };
+    std::vector<std::thread> pool;
+    for (int t = 0; t < kThreads; t++) pool.emplace_back(worker);
+    for (auto &t : pool) t.join();
+    if (failed) return ctx->fail(SGZ_E_HIP, "large copy between host and device failed");
+    return SGZ_OK;
+}

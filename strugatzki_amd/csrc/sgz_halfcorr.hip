@@ -9,10 +9,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
-#include <atomic>
 #include <cmath>
 #include <cstring>
-#include <thread>
 #include <vector>
 
 #include "sgz_internal.hpp"
@@ -407,48 +405,6 @@ __global__ __launch_bounds__(256, 2) void selfsim_tile_kernel(SelfSimArgs g)
     }
 }
 
-// Large results go to pageable host memory through several pinned staging buffers, one thread and stream each:
-// a single pageable copy is bound by one core's page faults and memcpy (about 9 GB/s), far below the link.
-int copy_to_host(sgz_context *ctx, void *dst, const void *src, size_t bytes)
-{
-    constexpr size_t kChunk = (size_t)32 << 20;
-    constexpr int kThreads = 8;
-    if (bytes < 8 * kChunk) {
-        SGZ_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
-        SGZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        return SGZ_OK;
-    }
-    SGZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const size_t chunks = (bytes + kChunk - 1) / kChunk;
-    std::atomic<size_t> next{0};
-    std::atomic<int> failed{0};
-    auto worker = [&]() {
-        void *pin = nullptr;
-        hipStream_t st = nullptr;
-        if (hipSetDevice(ctx->device) != hipSuccess || hipHostMalloc(&pin, kChunk, hipHostMallocDefault) != hipSuccess ||
-            hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
-            failed = 1;
-        } else {
-            for (size_t c = next++; c < chunks && !failed; c = next++) {
-                const size_t off = c * kChunk, len = std::min(kChunk, bytes - off);
-                if (hipMemcpyAsync(pin, (const char *)src + off, len, hipMemcpyDeviceToHost, st) != hipSuccess ||
-                    hipStreamSynchronize(st) != hipSuccess) {
-                    failed = 1;
-                    break;
-                }
-                std::memcpy((char *)dst + off, pin, len);
-            }
-        }
-        if (st) (void)hipStreamDestroy(st);
-        if (pin) (void)hipHostFree(pin);
-    };
-    std::vector<std::thread> pool;
-    for (int t = 0; t < kThreads; t++) pool.emplace_back(worker);
-    for (auto &t : pool) t.join();
-    if (failed) return ctx->fail(SGZ_E_HIP, "copy of a result to host memory failed");
-    return SGZ_OK;
-}
-
 struct DevBuf {
     void *p = nullptr;
     ~DevBuf()
@@ -630,8 +586,8 @@ int sgz_selfsim_run(sgz_context *ctx, const float *frames1, int64_t num_frames1,
         SGZ_HIP(ctx, hipGetLastError());
     }
     int rc;
-    if (sim_out && (rc = copy_to_host(ctx, sim_out, simd.p, pix * sizeof(float)))) return rc;
-    if (img_out && (rc = copy_to_host(ctx, img_out, imgd.p, pix * sizeof(int32_t)))) return rc;
+    if (sim_out && (rc = copy_large(ctx, sim_out, simd.p, pix * sizeof(float), true))) return rc;
+    if (img_out && (rc = copy_large(ctx, img_out, imgd.p, pix * sizeof(int32_t), true))) return rc;
     SGZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return SGZ_OK;
 }

@@ -214,6 +214,9 @@ int half_screen_set_target(sgz_context *ctx, const std::vector<double> &aprime, 
 int half_screen_launch(sgz_context *ctx, int tile_begin, int tile_end, hipStream_t stream, hipEvent_t start,
                        hipEvent_t stop);
 
+// sgz_context.hip: synchronous copy between pageable host memory and the device, staged in parallel when large
+int copy_large(sgz_context *ctx, void *dst, const void *src, size_t bytes, bool to_host);
+
 // Grows a device buffer to at least `count` elements (contents are not kept).
 template <typename T>
 int ensure(const sgz_context *ctx, T *&ptr, size_t &cap, size_t count)
