@@ -355,7 +355,10 @@ SGZ_API int sgz_segm_select(const float *sims, int64_t n, int af_start, int half
  * (:81-91).  frames2 may equal frames1; norms as for sgz_segm_curve.  sim_out (nullable) receives
  * img_ext*img_ext floats, [x][y] with x = left; img_out (nullable) receives
  * the TYPE_INT_RGB raster of :150-155 (gray colour scheme only: colors must be
- * 0).  Both triangles are filled from the upper one, as the reference does. */
+ * 0).  Both triangles are filled from the upper one, as the reference does.
+ * Similarities are within 1e-5 of the reference's fp64 evaluation (product
+ * sums on the fp32 matrix cores, statistics in fp64; pixels for which that
+ * bound cannot be certified are evaluated in the reference's own order). */
 SGZ_API int sgz_selfsim_run(sgz_context *ctx, const float *frames1, int64_t num_frames1,
                     const float *frames2, int64_t num_frames2, int num_channels,
                     const float *norms, int af_start, int half_win, int decim, int img_ext,
