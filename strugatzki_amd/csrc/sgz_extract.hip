@@ -27,7 +27,7 @@ namespace {
 
 constexpr int kBands = 42;
 constexpr int kMaxFft = 8192;
-constexpr int kFramesPerBlock = 4;  // waves per workgroup
+constexpr int kMaxFramesPerBlock = 8;  // waves (= frames) per workgroup; fewer for large FFT sizes
 
 struct ExtractParams {
     long long numFrames;   // input sample frames
@@ -48,7 +48,7 @@ struct BandTable {
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 
-__global__ __launch_bounds__(64 * kFramesPerBlock) void extract_kernel(const float *__restrict__ pcm,
+__global__ __launch_bounds__(64 * kMaxFramesPerBlock) void extract_kernel(const float *__restrict__ pcm,
                                                                        const float2 *__restrict__ twiddle,  // e^{-2 pi i k / fftSize}, k < fftSize/2
                                                                        const float *__restrict__ hann,
                                                                        const float *__restrict__ dct,       // [numCoeffs][kBands]
@@ -56,7 +56,8 @@ __global__ __launch_bounds__(64 * kFramesPerBlock) void extract_kernel(const flo
                                                                        BandTable bt, ExtractParams p,
                                                                        float *__restrict__ out)
 {
-    extern __shared__ __attribute__((aligned(16))) float2 lds[];  // kFramesPerBlock x (M + 8), then M twiddles
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];  // frames per block x (M + 8), then M twiddles
+    const int kFramesPerBlock = blockDim.x >> 6;
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     const int M = p.fftSize >> 1;
@@ -308,7 +309,15 @@ int sgz_extract(sgz_context *ctx, const float *pcm, int64_t num_frames, int num_
         const int erc = ctx->next_event_pair();
         if (erc) return erc;
     }
-    const size_t lds = sizeof(float2) * ((size_t)kFramesPerBlock * (M + 8) + (size_t)M) + sizeof(float) * (size_t)num_coeffs * kBands;
+    // frames per workgroup: as many as leave room for two workgroups per CU (160 KB of LDS)
+    auto ldsBytes = [&](int nw) {
+        return sizeof(float2) * ((size_t)nw * (M + 8) + (size_t)M) + sizeof(float) * (size_t)num_coeffs * kBands;
+    };
+    int kFramesPerBlock = kMaxFramesPerBlock;
+    while (kFramesPerBlock > 1 && ldsBytes(kFramesPerBlock) > 80 * 1024) kFramesPerBlock >>= 1;
+    const size_t lds = ldsBytes(kFramesPerBlock);
+    SGZ_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(extract_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const unsigned grid = (unsigned)((nOut + kFramesPerBlock - 1) / kFramesPerBlock);
     SGZ_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     hipLaunchKernelGGL(extract_kernel, dim3(grid), dim3(64 * kFramesPerBlock), lds, ctx->stream,

@@ -90,3 +90,17 @@ def test_selfsim_rejects_bad_arguments(ctx):
         ctx.selfsim(frames, None, None, 0, 4, 1, 200, 0.5)  # windows past the end
     with pytest.raises(S.NativeError):
         ctx.selfsim(frames, None, None, 0, 4, 1, 10, 0.5, colors=1)  # psycho-optical palette not implemented
+
+
+@pytest.mark.parametrize("fft,overlap", [(4096, 2), (8192, 4), (16, 1)])
+def test_extraction_with_small_and_large_fft_sizes(ctx, fft, overlap):
+    """The number of frames a workgroup takes follows the FFT size (its LDS share): the largest and the smallest
+    size against the CPU statement."""
+    rng = np.random.default_rng(fft)
+    n = 6 * fft + 37
+    t = np.arange(n, dtype=np.float32)
+    pcm = (0.3 * np.sin(t * np.float32(2 * np.pi * 440.0 / 44100.0)) + 0.02 * rng.standard_normal(n)).astype(np.float32)
+    want = O.extract(pcm, 44100.0, fft, overlap, 13, 0)
+    got = ctx.extract(pcm, 44100.0, fft, overlap, 13, 0)
+    assert got.shape == want.shape and got.shape[0] > 0
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-5)

@@ -130,11 +130,11 @@ def _cross(ctx, rng):
 
 def _extract(ctx, rng):
     """FeatureExtraction on random PCM: lengths around the framing's edges, channel behaviours, fft sizes."""
-    fft = int(rng.choice([256, 512, 1024, 2048]))
+    fft = int(rng.choice([256, 512, 1024, 2048, 4096, 8192]))
     ov = int(rng.choice([1, 2, 4]))
     nco = int(rng.choice([5, 13, 20]))
     chans = int(rng.choice([1, 1, 2, 3]))
-    n = int(rng.choice([1, fft // ov - 1, fft // ov, fft, fft + 1, int(rng.integers(2, 60000))]))
+    n = int(rng.choice([1, fft // ov - 1, fft // ov, fft, fft + 1, int(rng.integers(2, 60000 + 8 * fft))]))
     sr = float(rng.choice([22050.0, 44100.0, 48000.0]))
     t = np.arange(n, dtype=np.float32)[:, None]
     f0 = rng.uniform(50.0, 4000.0, size=(1, chans)).astype(np.float32)
