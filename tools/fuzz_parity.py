@@ -28,8 +28,8 @@ def run(cases: int, seed: int, ctx=None, verbose=True) -> int:
 
 
 def _one_case(ctx, rng, case, verbose) -> bool:
-    num_ch = int(rng.choice([2, 5, 14, 14, 14, 21]))
-    L = int(rng.choice([431, 700, 1000, 2584] if BIG else [3, 16, 17, 40, 96, 150, 431, 700]))
+    num_ch = int(rng.choice([2, 5, 14, 14, 14, 21, 64]))
+    L = int(rng.choice([431, 700, 1000, 2584] if BIG else [1, 2, 3, 16, 17, 40, 96, 150, 431, 700]))
     nf = int(rng.integers(1, 9))
     frames = [int(rng.integers(max(1, L // 2), (12000 if BIG else 4 * L + 900))) for _ in range(nf)]
     ts = int(rng.integers(0, 30))
