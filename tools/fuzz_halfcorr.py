@@ -36,7 +36,7 @@ def _same(a, b, atol):
 
 
 def _segm(ctx, rng):
-    num_ch = int(rng.choice([2, 5, 14, 14, 21]))
+    num_ch = int(rng.choice([2, 5, 14, 14, 21, 64]))
     n = int(rng.integers(4, 1600))
     frames = _data(rng, n, num_ch)
     normalize = bool(rng.random() < 0.8)
@@ -64,7 +64,7 @@ def _segm(ctx, rng):
 
 
 def _selfsim(ctx, rng):
-    num_ch = int(rng.choice([2, 5, 14, 14, 21]))
+    num_ch = int(rng.choice([2, 5, 14, 14, 21, 64]))
     n1 = int(rng.integers(12, 420))
     two = rng.random() < 0.3
     n2 = int(rng.integers(12, 420)) if two else n1
@@ -106,7 +106,7 @@ def _stats(ctx, rng):
 
 def _cross(ctx, rng):
     """CrossSimilarity through the calls its processor makes (shorter span = target, longer = the one file)."""
-    num_ch = int(rng.choice([2, 5, 14, 14, 21]))
+    num_ch = int(rng.choice([2, 5, 14, 14, 21, 64]))
     na, nb = int(rng.integers(1, 500)), int(rng.integers(1, 2500))
     fa, fb = _data(rng, na, num_ch), _data(rng, nb, num_ch)
     fa[:, 0], fb[:, 0] = np.abs(fa[:, 0]) + np.float32(0.01), np.abs(fb[:, 0]) + np.float32(0.01)
