@@ -77,6 +77,9 @@ class Context:
     def db_reset(self, num_channels: int) -> None:
         self._check(lib.sgz_db_reset(self._h, num_channels))
         self.num_channels = num_channels
+        # the sharded search keeps every rank's file placement between searches: a new database starts afresh
+        # (when the files of one rank change, every rank of the group has to go through db_reset)
+        self.__dict__.pop("_rank_maps", None)
 
     def db_add_file(self, frames: np.ndarray) -> None:
         a = _as_frames(frames, self.num_channels)

@@ -192,7 +192,9 @@ def _sort_candidates(cands: np.ndarray) -> np.ndarray:
 
 
 def _rank_maps(ctx: Context, local_to_global: Sequence[int], group) -> dict:
-    """local index -> global file id of every rank (gathered once per placement, kept on the context)."""
+    """local index -> global file id of every rank (gathered once per placement, kept on the context until its
+    db_reset: the gathering is a collective, so when one rank's files change every rank has to start a new
+    database, or some ranks would enter it and others not)."""
     import torch
     import torch.distributed as dist
 
@@ -254,10 +256,15 @@ def _sharded_over_bounds(ctx: Context, p: SearchParams, local_to_global: Sequenc
     maps = _rank_maps(ctx, local_to_global, group)
     b = _exchange_buffers(ctx, cap, world, on_gpu)
     rec, rows = b["rec"], b["rows"]
-    ctx.corr_run_screen_f16(0, nloc)
-    # row 0 = header (the count, written by the library), rows 1.. = records
-    ctx.corr_compact_bounded_device(0, nloc, nloc, b["rec_ptr"], cap, b["count_ptr"])
-    ctx.corr_rescore_device(b["rec_ptr"], cap, b["count_ptr"])
+    if nloc:
+        ctx.corr_run_screen_f16(0, nloc)
+        # row 0 = header (the count, written by the library), rows 1.. = records
+        ctx.corr_compact_bounded_device(0, nloc, nloc, b["rec_ptr"], cap, b["count_ptr"])
+        ctx.corr_rescore_device(b["rec_ptr"], cap, b["count_ptr"])
+    else:
+        # fewer files than ranks: this rank has none, but takes part in the exchange with a count of zero
+        rec[0].zero_()
+        torch.cuda.current_stream().synchronize()
     ts = ctx.torch_stream
     if on_gpu and ts is not None:
         # the context runs on a stream torch owns (Context.on_torch_stream): collective and copy are queued
@@ -352,7 +359,7 @@ def search_sharded(ctx: Context, p: SearchParams, head_global: Sequence[int], ta
     assert ctx.num_files == nh + nt
     mode = _screen_mode(ctx, p) if p.screen else None
     if (p.screen and p.screen_head and p.num_per_file == 1 and p.num_matches >= 1 and mode == "f16"
-            and num_files_total is not None and ctx.num_files > 0):
+            and num_files_total is not None and num_files_total > 0):  # (nothing rank-dependent: a collective follows)
         out = _sharded_over_bounds(ctx, p, list(head_global) + list(tail_global), num_files_total, group)
         if out is not None:  # every rank holds the same candidates, so all ranks agree on this
             return out

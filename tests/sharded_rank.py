@@ -1,8 +1,9 @@
 """One rank of the sharded search on a real GPU (started by test_gpu_correlation.py as a child process:
 torch has to initialise the GPU before the library does, which a shared pytest process cannot guarantee).
-usage: sharded_rank.py PORT MODE RANK WORLD BACKEND
+usage: sharded_rank.py PORT MODE RANK WORLD BACKEND [CASES SEED]
 MODE: "bounds" (search over bounds), "general" (replicated head files, screen_head off), "exact" (no
-replicated files, no screening).  Every rank prints the matches as one JSON line."""
+replicated files, no screening), "fuzz" (CASES random cases from SEED, compared with the oracle on every rank).
+Every rank prints the matches (or the fuzz counts) as one JSON line."""
 import json
 import os
 import sys
@@ -22,8 +23,67 @@ import strugatzki_amd as S  # noqa: E402
 CASE = dict(L=96, ts=17, nf=14, frames=900, num_matches=4, nplants=5)
 
 
+def fuzz(port: int, rank: int, world: int, backend: str, cases: int, seed: int) -> int:
+    """Random databases and parameters (every rank draws the same ones), all three ways of sharding; every rank
+    compares its result with the oracle's.  Prints {"cases", "bad", "skipped"}."""
+    import numpy as np
+    from common import O, corr_config
+    kw = dict(device_id=torch.device("cuda", 0)) if backend == "nccl" else {}
+    dist.init_process_group(backend, init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, **kw)
+    ctx = S.Context.on_torch_stream(0) if backend == "nccl" else S.Context(0)
+    rng = np.random.default_rng(seed)
+    bad = skipped = 0
+    try:
+        for case in range(cases):
+            L = int(rng.choice([16, 40, 96, 150]))
+            nf = int(rng.integers(1, 11))
+            frames = [int(rng.integers(L, 4 * L + 600)) for _ in range(nf)]
+            ts = int(rng.integers(0, 20))
+            nm, npf = int(rng.integers(1, 6)), int(rng.choice([1, 1, 2, 3]))
+            sp = int(rng.choice([0, 0, 10 * STEP]))
+            weight = float(rng.choice([0.0, 0.5, 1.0]))
+            mode = str(rng.choice(["bounds", "general", "exact"]))
+            if npf > 1 or nf < nm:
+                mode = "general"
+            plants = [q for q in make_plants(int(rng.integers(0, 4)), L, nf, max(frames), ts)
+                      if q["file"] < nf and q["offset"] + L <= frames[q["file"]]]
+            db = synth_db(nf, frames, plants, seed=int(rng.integers(1, 1 << 30)))
+            tgt = synth_target(ts, L)
+            want, _, _ = O.correlation_run(corr_config(ts, L, weight=weight, num_matches=nm, num_per_file=npf,
+                                                       min_spacing=sp), tgt, norms_default(), db, dense=False)
+            nh = min(nm, nf) if mode == "general" else 0
+            head = list(range(nh))
+            tail = [g for g in range(nh, nf) if (g - nh) % world == rank]
+            ctx.db_reset(db[0].shape[1])
+            for g in head + tail:
+                ctx.db_add_file(db[g])
+            ctx.set_norms(norms_default())
+            ctx.corr_set_target(tgt[ts:ts + L], weight, 8.0)
+            p = S.SearchParams(nm, npf, sp, STEP, screen=mode != "exact", screen_head=mode == "bounds")
+            try:
+                got = S.search_sharded(ctx, p, head, tail, num_files_total=nf)
+            except RuntimeError as e:  # (head files that do not fill the match set: refused on every rank alike)
+                if "head files" not in str(e):
+                    raise
+                skipped += 1
+                continue
+            ok = [(g.file, g.start, g.stop) for g in got] == [(w.file, w.start, w.stop) for w in want] and all(
+                abs(g.sim - w.sim) <= 1e-5 for g, w in zip(got, want))
+            if not ok:
+                bad += 1
+                print(f"rank {rank} case {case} mode {mode} L={L} frames={frames} nm={nm} npf={npf} sp={sp}: "
+                      f"{[(g.file, g.start) for g in got]} != {[(w.file, w.start) for w in want]}", file=sys.stderr)
+    finally:
+        dist.destroy_process_group()
+    print(json.dumps({"cases": cases, "bad": bad, "skipped": skipped}))
+    ctx.close()
+    return 0
+
+
 def main() -> int:
     port, mode, rank, world, backend = int(sys.argv[1]), sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+    if mode == "fuzz":
+        return fuzz(port, rank, world, backend, int(sys.argv[6]), int(sys.argv[7]))
     q = CASE
     db = synth_db(q["nf"], q["frames"], make_plants(q["nplants"], q["L"], q["nf"], q["frames"], q["ts"]))
     tgt = synth_target(q["ts"], q["L"])

@@ -306,7 +306,7 @@ def test_search_over_bounds_and_its_fallbacks(ctx, case):
         assert abs(g.sim - w.sim) <= 1.2e-7
 
 
-def _run_ranks(mode, world, backend):
+def _run_ranks(mode, world, backend, extra=()):
     import json
     import os
     import socket
@@ -317,7 +317,7 @@ def _run_ranks(mode, world, backend):
     port = sock.getsockname()[1]
     sock.close()
     script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "sharded_rank.py")
-    procs = [subprocess.Popen([sys.executable, script, str(port), mode, str(r), str(world), backend],
+    procs = [subprocess.Popen([sys.executable, script, str(port), mode, str(r), str(world), backend, *map(str, extra)],
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
     outs = []
     for pr in procs:
@@ -357,6 +357,14 @@ def test_search_sharded_two_ranks_on_one_gpu(mode):
     assert [(g[0], g[1], g[2]) for g in outs[0]] == [(w.file, w.start, w.stop) for w in want]
     for g, w in zip(outs[0], want):
         assert abs(g[3] - w.sim) <= (1e-5 if mode == "exact" else 1.2e-7)
+
+
+@pytest.mark.parametrize("world,seed", [(2, 5), (3, 6)])
+def test_search_sharded_random_cases(world, seed):
+    """Random databases, parameters and ways of sharding (search over bounds, replicated head files, exact),
+    ranks without any file among them: every rank's result equals the oracle's."""
+    outs = _run_ranks("fuzz", world, "gloo", extra=(40, seed))
+    assert all(o["bad"] == 0 and o["cases"] == 40 for o in outs), outs
 
 
 @pytest.mark.parametrize("num_matches,num_per_file,min_spacing,min_punch,max_punch",
