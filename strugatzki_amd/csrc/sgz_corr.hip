@@ -902,6 +902,18 @@ __global__ __launch_bounds__(256) void compact_bounded_kernel(const FileDesc *__
 constexpr int kRsThreads = 256;
 constexpr int kRsParts = 6;  // sumT, sumS, sqT, sqS, crossT, crossS
 
+// Records of a candidate list that may be read.  A count beyond the capacity comes from two sources: more
+// candidates than slots (then every slot is written), or a compaction kernel that reports a file it cannot
+// screen by adding capacity + 1 without writing anything (then slots may hold stale records of an earlier,
+// possibly larger database, whose file indices and frame pointers are no longer valid).  Only a caller that
+// knows its list is of the first kind (`truncatedOk`: the suspect list of an exact run) has the first
+// `capacity` records read; everybody else gets none -- such a list is reported as an overflow and discarded.
+__device__ __forceinline__ long long listed_records(unsigned long long count, long long capacity, int truncatedOk)
+{
+    if (count > (unsigned long long)capacity) return truncatedOk ? capacity : 0;
+    return (long long)count;
+}
+
 __device__ __forceinline__ double block_sum_256(double v, double *scratch /* 4 doubles */)
 {
 #pragma unroll
@@ -923,11 +935,11 @@ __global__ __launch_bounds__(kRsThreads) void rescore_pass_kernel(
     const float *__restrict__ normTab /* min[64], max - min[64] */, int normEnabled, CorrParams cp, RescoreGeom rg,
     double aMeanT, double aMeanS,
     const sgz_candidate *__restrict__ cands, const unsigned long long *__restrict__ count, long long capacity,
-    double *__restrict__ part /* [window][slice][kRsParts] */)
+    int truncatedOk, double *__restrict__ part /* [window][slice][kRsParts] */)
 {
     constexpr int U = 16;  // loads in flight per thread
     __shared__ double scratch[4];
-    const long long n = min((long long)*count, capacity);
+    const long long n = listed_records(*count, capacity, truncatedOk);
     const long long work = n * rg.slices;
     if ((long long)blockIdx.x >= work) return;
     const int numCh = cp.numCh, L = cp.L;
@@ -1020,10 +1032,10 @@ struct HostReport {
 __global__ __launch_bounds__(256) void rescore_final_kernel(CorrParams cp, RescoreGeom rg,
                                                             sgz_candidate *__restrict__ cands,
                                                             const unsigned long long *__restrict__ count,
-                                                            long long capacity, const double *__restrict__ part,
-                                                            HostReport hr)
+                                                            long long capacity, int truncatedOk,
+                                                            const double *__restrict__ part, HostReport hr)
 {
-    const long long n = min((long long)*count, capacity);
+    const long long n = listed_records(*count, capacity, truncatedOk);
     const double nT = (double)cp.L, nS = (double)cp.L * (double)(cp.numCh - 1);
     for (long long ci = (long long)blockIdx.x * blockDim.x + threadIdx.x; ci < n;
          ci += (long long)gridDim.x * blockDim.x) {
@@ -1496,7 +1508,7 @@ enum RunMode { kRunExact = 0, kRunScreenF32 = 1, kRunScreenF16 = 2 };
 
 static int corr_run_impl(sgz_context *ctx, int file_begin, int file_end, int mode);
 static int rescore_device_impl(sgz_context *ctx, sgz_candidate *device_cands, int64_t capacity,
-                               const unsigned long long *device_count, const HostReport &hr);
+                               const unsigned long long *device_count, const HostReport &hr, bool truncated_ok = false);
 constexpr int64_t kSuspectCap = 1 << 16;  // windows an exact run can re-evaluate from their frames
 
 int sgz_corr_run(sgz_context *ctx, int file_begin, int file_end)
@@ -1610,7 +1622,7 @@ static int corr_run_impl(sgz_context *ctx, int file_begin, int file_end, int mod
     if (exact) {
         // two-pass evaluation of the listed windows, written back into the dense arrays (three small kernels
         // that return at once when the list is empty); windows beyond the list's capacity stay NaN
-        if ((rc = rescore_device_impl(ctx, suspects.list, kSuspectCap, suspects.count, HostReport{}))) return rc;
+        if ((rc = rescore_device_impl(ctx, suspects.list, kSuspectCap, suspects.count, HostReport{}, true))) return rc;
         hipLaunchKernelGGL(scatter_kernel, dim3(64), dim3(256), 0, stream, ctx->d_files, suspects.list, suspects.count,
                            (long long)kSuspectCap, ctx->d_sim, ctx->d_boost);
         SGZ_HIP(ctx, hipGetLastError());
@@ -1770,7 +1782,7 @@ int sgz_corr_compact_bounded_device(sgz_context *ctx, int file_begin, int file_e
 }
 
 static int rescore_device_impl(sgz_context *ctx, sgz_candidate *device_cands, int64_t capacity,
-                               const unsigned long long *device_count, const HostReport &hr)
+                               const unsigned long long *device_count, const HostReport &hr, bool truncated_ok)
 {
     if (!ctx) return SGZ_E_ARG;
     if (ctx->layout_dirty || !ctx->have_target) return ctx->fail(SGZ_E_STATE, "no correlation results");
@@ -1791,20 +1803,23 @@ static int rescore_device_impl(sgz_context *ctx, sgz_candidate *device_cands, in
         if ((rc = ensure(ctx, ctx->d_normtab, ctx->normtab_cap, (size_t)2 * SGZ_MAX_CHANNELS))) return rc;
         SGZ_HIP(ctx, hipMemsetAsync(ctx->d_normtab, 0, sizeof(float) * 2 * SGZ_MAX_CHANNELS, ctx->stream));
     }
+    double *part = ctx->d_rs_part;
+    const float *normtab = ctx->d_normtab;
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
     const int grid = (int)std::min<long long>((long long)capacity * rg.slices, 8ll * cus);
     const float *tframes = ctx->d_tnorm + perWindow;
     hipLaunchKernelGGL(rescore_pass_kernel<false>, dim3(grid), dim3(kRsThreads), 0, ctx->stream, ctx->d_files, tframes,
-                       ctx->d_normtab, ctx->norm.enabled, ctx->cp, rg, ctx->aMeanT, ctx->aMeanS, device_cands, device_count,
-                       (long long)capacity, ctx->d_rs_part);
+                       normtab, ctx->norm.enabled, ctx->cp, rg, ctx->aMeanT, ctx->aMeanS, device_cands, device_count,
+                       (long long)capacity, (int)truncated_ok, part);
     SGZ_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(rescore_pass_kernel<true>, dim3(grid), dim3(kRsThreads), 0, ctx->stream, ctx->d_files, tframes,
-                       ctx->d_normtab, ctx->norm.enabled, ctx->cp, rg, ctx->aMeanT, ctx->aMeanS, device_cands, device_count,
-                       (long long)capacity, ctx->d_rs_part);
+                       normtab, ctx->norm.enabled, ctx->cp, rg, ctx->aMeanT, ctx->aMeanS, device_cands, device_count,
+                       (long long)capacity, (int)truncated_ok, part);
     SGZ_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(rescore_final_kernel, dim3((int)std::min<int64_t>((capacity + 255) / 256, 64)), dim3(256), 0,
-                       ctx->stream, ctx->cp, rg, device_cands, device_count, (long long)capacity, ctx->d_rs_part, hr);
+                       ctx->stream, ctx->cp, rg, device_cands, device_count, (long long)capacity, (int)truncated_ok,
+                       part, hr);
     SGZ_HIP(ctx, hipGetLastError());
     return SGZ_OK;
 }
@@ -1851,7 +1866,10 @@ static int compact_host(sgz_context *ctx, int file_begin, int file_end, float th
     // saves a clear (and its idle time on the stream) per call.
     const sgz_candidate *before = ctx->d_cand;
     if ((rc = ensure(ctx, ctx->d_cand, ctx->cand_cap, (size_t)capacity + 2))) return rc;
-    if (ctx->d_cand != before) ctx->cand_clean = false;
+    if (ctx->d_cand != before) {  // fresh memory: no stale record may ever be taken for a candidate
+        SGZ_HIP(ctx, hipMemsetAsync(ctx->d_cand, 0, sizeof(sgz_candidate) * ctx->cand_cap, ctx->stream));
+        ctx->cand_clean = true;
+    }
     unsigned long long *d_count = reinterpret_cast<unsigned long long *>(ctx->d_cand + ctx->cand_parity);
     unsigned long long *d_other = reinterpret_cast<unsigned long long *>(ctx->d_cand + (1 - ctx->cand_parity));
     sgz_candidate *d_rec = ctx->d_cand + 2;
@@ -1874,6 +1892,8 @@ static int compact_host(sgz_context *ctx, int file_begin, int file_end, float th
     if (!ctx->h_pinned) {  // + the sequence word of a host report
         SGZ_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_pinned), sizeof(sgz_candidate) * (kPinned + 1)));
         std::memset(ctx->h_pinned, 0, sizeof(sgz_candidate) * (kPinned + 1));
+        // every record slot starts as "not written" (file index -1), see the safety net below
+        std::memset(ctx->h_pinned + 2, 0xff, sizeof(sgz_candidate) * (kPinned - 2));
     }
     bool reported = false;
     if (rescore && capacity > 0) {
@@ -1921,6 +1941,7 @@ static int compact_host(sgz_context *ctx, int file_begin, int file_end, float th
         SGZ_HIP(ctx, hipMemcpyAsync(ctx->h_pinned, ctx->d_cand, sizeof(sgz_candidate) * (first + 2),
                                     hipMemcpyDeviceToHost, ctx->stream));
         SGZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->report_prev_n = first;  // these slots now hold valid-looking records: invalidated before the next report
     }
     unsigned long long n = 0;
     std::memcpy(&n, ctx->h_pinned + parity, sizeof n);

@@ -311,6 +311,12 @@ int sgz_sel_feed_gathered(sgz_selector *sel, const sgz_candidate *blocks, int wo
     std::sort(all.begin(), all.end(), [](const sgz_candidate &a, const sgz_candidate &b) {
         return a.file != b.file ? a.file < b.file : a.offset < b.offset;
     });
+    // files that several ranks hold (replicated head files) arrive once per holder: keep one record per window
+    all.erase(std::unique(all.begin(), all.end(),
+                          [](const sgz_candidate &a, const sgz_candidate &b) {
+                              return a.file == b.file && a.offset == b.offset;
+                          }),
+              all.end());
     return sgz_sel_feed_screened(sel, all.data(), (int64_t)all.size(), head_files, num_files);
 }
 

@@ -322,16 +322,30 @@ def _sharded_exact_maxima(ctx: Context, p: SearchParams, local_to_global: Sequen
     nloc = ctx.num_files
     ctx.corr_run(0, nloc)
     dense = ctx.corr_read_dense_range(0, nloc) if nloc else []
-    rows = []
+    parts = []
     for f, (sim, boost) in enumerate(dense):
         if len(sim) == 0:
             continue
-        if np.isnan(sim).any():
-            raise RuntimeError("NaN similarities: the sharded search needs replicated head files for this database")
-        o = int(np.argmax(sim))  # first occurrence
-        rows.append((local_to_global[f], o, sim[o], boost[o]))
+        nan = np.isnan(sim)
+        if nan[0]:
+            # A NaN similarity (a window without spread) can only ever be offered as the first window of its
+            # file, while the sets still have room (entryHasSpace, :124-128; `sim > lowestSim` is false for
+            # NaN, :234), and then blocks everything after it: such a file travels densely, whose replay is
+            # exact whatever the state of the sets.  Nothing here is decided per rank: a list that grows
+            # beyond the capacity is seen by every rank in the exchange.
+            part = np.zeros(len(sim), dtype=N.CANDIDATE_DTYPE)
+            part["offset"] = np.arange(len(sim), dtype=np.int32)
+            part["sim"], part["boost"] = sim, boost
+        else:
+            # later NaN windows are never offered: the file contributes its largest similarity, first occurrence
+            o = int(np.nanargmax(sim)) if nan.any() else int(np.argmax(sim))
+            part = np.zeros(1, dtype=N.CANDIDATE_DTYPE)
+            part["offset"], part["sim"], part["boost"] = o, sim[o], boost[o]
+        part["file"] = local_to_global[f]
+        parts.append(part)
+    rows = np.concatenate(parts) if parts else np.zeros(0, dtype=N.CANDIDATE_DTYPE)
     rec_h = np.zeros(max(p.capacity, 1), dtype=N.CANDIDATE_DTYPE)
-    rec_h[: len(rows)] = np.array(rows, dtype=N.CANDIDATE_DTYPE) if rows else rec_h[:0]
+    rec_h[: min(len(rows), len(rec_h))] = rows[: len(rec_h)]
     dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
     rec = torch.from_numpy(rec_h.view(np.int32).reshape(-1, 4).copy()).to(dev)
     cnt = torch.tensor([len(rows)], dtype=torch.int64, device=dev)

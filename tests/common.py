@@ -77,3 +77,18 @@ def corr_config(target_start: int, L: int, *, weight=0.5, normalize=True, max_bo
                 num_per_file=1, min_spacing=0, num_ch: int = NUM_CH) -> O.CorrConfig:
     return O.CorrConfig(target_start * STEP, (target_start + L) * STEP, weight, int(normalize), max_boost,
                         num_matches, num_per_file, min_spacing, STEP, num_ch - 1)
+
+
+SHARDED_CASE = dict(L=96, ts=17, nf=14, frames=900, num_matches=4, nplants=5)
+
+
+def sharded_case_db(mode: str):
+    """Database of the fixed sharded-search case (tests/sharded_rank.py and its callers).  Mode "nan": file 2
+    starts with a constant stretch (its first windows have no spread: NaN similarities, the first of which the
+    reference's loop keeps while the sets have room), file 5 holds one further inside."""
+    q = SHARDED_CASE
+    db = synth_db(q["nf"], q["frames"], make_plants(q["nplants"], q["L"], q["nf"], q["frames"], q["ts"]))
+    if mode == "nan":
+        db[2][0:300] = db[2][0]
+        db[5][400:700] = db[5][400]
+    return db

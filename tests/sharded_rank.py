@@ -1,8 +1,10 @@
 """One rank of the sharded search on a real GPU (started by test_gpu_correlation.py as a child process:
 torch has to initialise the GPU before the library does, which a shared pytest process cannot guarantee).
 usage: sharded_rank.py PORT MODE RANK WORLD BACKEND [CASES SEED]
-MODE: "bounds" (search over bounds), "general" (replicated head files, screen_head off), "exact" (no
-replicated files, no screening), "fuzz" (CASES random cases from SEED, compared with the oracle on every rank).
+MODE: "bounds" (search over bounds), "general" (replicated head files, screen_head off), "headbounds" (replicated
+head files and the search over bounds: every rank reports the head files' windows), "exact" (no replicated files,
+no screening), "nan" (as "bounds", over a database with constant stretches), "fuzz" (CASES random cases from SEED,
+compared with the oracle on every rank).
 Every rank prints the matches (or the fuzz counts) as one JSON line."""
 import json
 import os
@@ -16,11 +18,12 @@ import torch.distributed as dist  # noqa: E402
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from common import STEP, make_plants, norms_default, synth_db, synth_target  # noqa: E402
+from common import (SHARDED_CASE, STEP, make_plants, norms_default, sharded_case_db, synth_db,  # noqa: E402
+                    synth_target)
 
 import strugatzki_amd as S  # noqa: E402
 
-CASE = dict(L=96, ts=17, nf=14, frames=900, num_matches=4, nplants=5)
+CASE = SHARDED_CASE
 
 
 def fuzz(port: int, rank: int, world: int, backend: str, cases: int, seed: int) -> int:
@@ -42,7 +45,7 @@ def fuzz(port: int, rank: int, world: int, backend: str, cases: int, seed: int) 
             nm, npf = int(rng.integers(1, 6)), int(rng.choice([1, 1, 2, 3]))
             sp = int(rng.choice([0, 0, 10 * STEP]))
             weight = float(rng.choice([0.0, 0.5, 1.0]))
-            mode = str(rng.choice(["bounds", "general", "exact"]))
+            mode = str(rng.choice(["bounds", "general", "exact", "headbounds"]))
             if npf > 1 or nf < nm:
                 mode = "general"
             plants = [q for q in make_plants(int(rng.integers(0, 4)), L, nf, max(frames), ts)
@@ -51,7 +54,7 @@ def fuzz(port: int, rank: int, world: int, backend: str, cases: int, seed: int) 
             tgt = synth_target(ts, L)
             want, _, _ = O.correlation_run(corr_config(ts, L, weight=weight, num_matches=nm, num_per_file=npf,
                                                        min_spacing=sp), tgt, norms_default(), db, dense=False)
-            nh = min(nm, nf) if mode == "general" else 0
+            nh = min(nm, nf) if mode in ("general", "headbounds") else 0
             head = list(range(nh))
             tail = [g for g in range(nh, nf) if (g - nh) % world == rank]
             ctx.db_reset(db[0].shape[1])
@@ -59,7 +62,7 @@ def fuzz(port: int, rank: int, world: int, backend: str, cases: int, seed: int) 
                 ctx.db_add_file(db[g])
             ctx.set_norms(norms_default())
             ctx.corr_set_target(tgt[ts:ts + L], weight, 8.0)
-            p = S.SearchParams(nm, npf, sp, STEP, screen=mode != "exact", screen_head=mode == "bounds")
+            p = S.SearchParams(nm, npf, sp, STEP, screen=mode != "exact", screen_head=mode in ("bounds", "headbounds"))
             try:
                 got = S.search_sharded(ctx, p, head, tail, num_files_total=nf)
             except RuntimeError as e:  # (head files that do not fill the match set: refused on every rank alike)
@@ -85,9 +88,9 @@ def main() -> int:
     if mode == "fuzz":
         return fuzz(port, rank, world, backend, int(sys.argv[6]), int(sys.argv[7]))
     q = CASE
-    db = synth_db(q["nf"], q["frames"], make_plants(q["nplants"], q["L"], q["nf"], q["frames"], q["ts"]))
+    db = sharded_case_db(mode)
     tgt = synth_target(q["ts"], q["L"])
-    if mode == "general":  # head files on every rank, the rest dealt round robin
+    if mode in ("general", "headbounds"):  # head files on every rank, the rest dealt round robin
         head = list(range(q["num_matches"]))
         tail = [g for g in range(q["num_matches"], q["nf"]) if (g - q["num_matches"]) % world == rank]
     else:                  # nothing replicated
@@ -102,7 +105,8 @@ def main() -> int:
     kw = dict(device_id=torch.device("cuda", 0)) if backend == "nccl" else {}
     dist.init_process_group(backend, init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, **kw)
     try:
-        p = S.SearchParams(q["num_matches"], 1, 0, STEP, screen=mode != "exact", screen_head=mode == "bounds")
+        p = S.SearchParams(q["num_matches"], 1, 0, STEP, screen=mode != "exact",
+                           screen_head=mode in ("bounds", "headbounds", "nan"))
         got = S.search_sharded(ctx, p, head, tail, num_files_total=q["nf"])
     finally:
         dist.destroy_process_group()

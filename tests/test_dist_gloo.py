@@ -192,6 +192,25 @@ def test_feed_gathered_equals_feed_screened_on_the_merged_list():
     assert sel.feed_gathered(blocks, world, rows, flat, offsets, nf, nf) is True
     assert [match_tuple(m) for m in sel.result()] == [O.match_tuple(w) for w in want]
     sel.close()
+    # replicated head files: ranks 1 and 2 also hold (and report) rank 0's first file, as their last local file
+    dup = blocks.copy()
+    per_rank2 = [list(x) for x in per_rank]
+    g0 = per_rank[0][0]
+    rec0 = np.array([(0, o, sims[g0][o], boosts[g0][o]) for o in np.flatnonzero(sims[g0] >= sims[g0].max() - np.float32(1e-3))],
+                    dtype=N.CANDIDATE_DTYPE)
+    for r in (1, 2):
+        n_r = int(dup[r, 0, :2].copy().view(np.int64)[0])
+        extra = rec0.copy()
+        extra["file"] = len(per_rank2[r])
+        per_rank2[r].append(g0)
+        dup[r, 1 + n_r:1 + n_r + len(extra)] = extra.view(np.int32).reshape(-1, 4)
+        dup[r, 0, :2] = np.array([n_r + len(extra)], dtype=np.int64).view(np.int32)
+    flat2 = np.array(sum(per_rank2, []), dtype=np.int32)
+    offsets2 = np.concatenate([[0], np.cumsum([len(x) for x in per_rank2])]).astype(np.int64)
+    sel = Selector(4, 1, 0, STEP, L)
+    assert sel.feed_gathered(dup, world, rows, flat2, offsets2, nf, nf) is True
+    assert [match_tuple(m) for m in sel.result()] == [O.match_tuple(w) for w in want]
+    sel.close()
     blocks[1, 0, :2] = np.array([rows], dtype=np.int64).view(np.int32)  # more than rows - 1
     sel = Selector(4, 1, 0, STEP, L)
     assert sel.feed_gathered(blocks, world, rows, flat, offsets, nf, nf) is None

@@ -327,9 +327,10 @@ def _run_ranks(mode, world, backend, extra=()):
     return outs
 
 
-def _sharded_want():
-    q = dict(L=96, ts=17, nf=14, frames=900, num_matches=4, nplants=5)  # CASE of tests/sharded_rank.py
-    db = synth_db(q["nf"], q["frames"], make_plants(q["nplants"], q["L"], q["nf"], q["frames"], q["ts"]))
+def _sharded_want(mode=""):
+    from common import SHARDED_CASE, sharded_case_db
+    q = SHARDED_CASE
+    db = sharded_case_db(mode)
     tgt = synth_target(q["ts"], q["L"])
     want, _, _ = O.correlation_run(corr_config(q["ts"], q["L"], num_matches=q["num_matches"], num_per_file=1), tgt,
                                    norms_default(), db, dense=False)
@@ -347,16 +348,23 @@ def test_search_sharded_single_rank_rccl(mode):
         assert abs(g[3] - w.sim) <= 1.2e-7
 
 
-@pytest.mark.parametrize("mode", ["bounds", "general", "exact"])
+@pytest.mark.parametrize("mode", ["bounds", "general", "exact", "headbounds", "nan"])
 def test_search_sharded_two_ranks_on_one_gpu(mode):
     """Two ranks (two processes sharing the one GPU of the box, gloo for the exchange): both end with the
-    single-process result, with and without replicated head files."""
-    want = _sharded_want()
+    single-process result, with and without replicated head files ("headbounds": replicated head files in the
+    search over bounds, whose windows every rank reports), and over a database with constant stretches
+    ("nan": the bounds cannot decide, every rank switches to the exact maxima, the file that starts with a NaN
+    window travels densely)."""
+    want = _sharded_want(mode)
     outs = _run_ranks(mode, 2, "gloo")
-    assert outs[0] == outs[1]
-    assert [(g[0], g[1], g[2]) for g in outs[0]] == [(w.file, w.start, w.stop) for w in want]
-    for g, w in zip(outs[0], want):
-        assert abs(g[3] - w.sim) <= (1e-5 if mode == "exact" else 1.2e-7)
+    assert outs[0] == outs[1] or mode == "nan"  # (NaN != NaN in the printed lists)
+    for out in outs:
+        assert [(g[0], g[1], g[2]) for g in out] == [(w.file, w.start, w.stop) for w in want]
+        for g, w in zip(out, want):
+            assert abs(g[3] - w.sim) <= (1e-5 if mode in ("exact", "nan") else 1.2e-7) or (g[3] != g[3] and
+                                                                                           w.sim != w.sim)
+    if mode == "nan":
+        assert any(w.sim != w.sim for w in want)  # the case does exercise a kept NaN match
 
 
 @pytest.mark.parametrize("world,seed", [(2, 5), (3, 6)])
@@ -409,6 +417,35 @@ def test_search_falls_back_to_dense_on_candidate_overflow(ctx):
     ctx.corr_set_target(tgt[ts:ts + L], 0.5, 8.0)
     got = S.search(ctx, S.SearchParams(2, 2, 0, STEP, capacity=1))
     assert [(g.file, g.start, g.stop) for g in got] == [(w.file, w.start, w.stop) for w in want]
+
+
+def test_smaller_database_after_a_larger_one_with_unscreenable_file(ctx):
+    """A file the half-precision screening cannot handle (a constant stretch: NaN windows) is reported through the
+    candidate count, without candidate records.  The re-scoring that follows must not read the slots of the
+    candidate buffer, which still hold records of the earlier, larger database (file indices and frame pointers
+    that are gone)."""
+    import strugatzki_amd as S
+    L, ts = 64, 4
+    tgt = synth_target(ts, L)
+    norms = norms_default()
+    big = synth_db(40, 2500, make_plants(4, L, 40, 2500, ts))
+    _load(ctx, big, norms)
+    ctx.corr_set_target(tgt[ts:ts + L], 0.5, 8.0)
+    for npf in (1, 3):  # both candidate paths leave records behind
+        got = S.search(ctx, S.SearchParams(6, npf, 0, STEP, capacity=4096))
+        want, _, _ = O.correlation_run(corr_config(ts, L, num_matches=6, num_per_file=npf), tgt, norms, big, dense=False)
+        assert [(g.file, g.start, g.stop) for g in got] == [(w.file, w.start, w.stop) for w in want]
+    small = synth_db(3, 700, make_plants(2, L, 3, 700, ts))
+    small[1][100:400] = small[1][100]
+    _load(ctx, small, norms)
+    ctx.corr_set_target(tgt[ts:ts + L], 0.5, 8.0)
+    for npf in (1, 3):
+        want, _, _ = O.correlation_run(corr_config(ts, L, num_matches=2, num_per_file=npf), tgt, norms, small,
+                                       dense=False)
+        got = S.search(ctx, S.SearchParams(2, npf, 0, STEP, capacity=4096, screen_mode="auto"))
+        assert [(g.file, g.start, g.stop) for g in got] == [(w.file, w.start, w.stop) for w in want]
+        for g, w in zip(got, want):
+            assert abs(g.sim - w.sim) <= TOL
 
 
 def test_synthetic_generator_matches_oracle_bits(ctx):
