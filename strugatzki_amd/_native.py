@@ -95,6 +95,7 @@ SIGNATURES = {
     "sgz_corr_compact": (C.c_int, [_vp, C.c_int, C.c_int, C.c_float, _vp, C.c_int64, C.POINTER(C.c_int64)]),
     "sgz_corr_compact_device": (C.c_int, [_vp, C.c_int, C.c_int, C.c_float, _vp, C.c_int64, _vp]),
     "sgz_corr_rescore_device": (C.c_int, [_vp, _vp, C.c_int64, _vp]),
+    "sgz_corr_rescore_device_noalloc": (C.c_int, [_vp, _vp, C.c_int64, _vp]),
     "sgz_corr_compact_rescored": (C.c_int, [_vp, C.c_int, C.c_int, C.c_float, _vp, C.c_int64, C.POINTER(C.c_int64)]),
     "sgz_corr_compact_bounded": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int64, C.POINTER(C.c_int64)]),
     "sgz_corr_compact_bounded_device": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int64, _vp]),

@@ -40,6 +40,13 @@ int sgz_create(int device, void *hip_stream, sgz_context **out)
         delete ctx;
         return SGZ_E_HIP;
     }
+    if (sgz::noalloc_scratch_init(ctx) != SGZ_OK) {
+        (void)hipStreamDestroy(ctx->copy_stream);
+        (void)hipStreamDestroy(ctx->screen_stream);
+        if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return SGZ_E_HIP;
+    }
     *out = ctx;
     return SGZ_OK;
 }

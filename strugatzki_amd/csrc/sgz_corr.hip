@@ -24,6 +24,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <string>
 
 #include <type_traits>
 
@@ -1083,6 +1085,20 @@ __global__ __launch_bounds__(256) void rescore_final_kernel(CorrParams cp, Resco
     }
 }
 
+// ---------------------------------------------------------------------------
+// Scratch of sgz_corr_rescore_device_noalloc: the partial sums of the exact re-scoring
+// ([window][slice][kRsParts] doubles), which sgz_corr_rescore_device keeps in a buffer it allocates on
+// demand.  A file-scope device array: every GPU the library runs on holds its own copy, at its own address,
+// from the moment the code object is loaded there until the process ends.  Host code must never pass the
+// array's name to a kernel (on the host it is only a handle for hipGetSymbolAddress); the address is looked
+// up once per device and kept in g_scratch_ptr.
+// ---------------------------------------------------------------------------
+constexpr size_t kNoAllocScratchBytes = (size_t)4 << 20;
+static __device__ __align__(256) unsigned char scratch[kNoAllocScratchBytes];
+constexpr int kScratchMaxDevices = 64;
+static void *g_scratch_ptr[kScratchMaxDevices];  // per device; null until that device's first sgz_create
+static std::mutex g_scratch_mutex;
+
 // Picks the chunks-per-tile of prep_kernel so that its LDS image stays <= 32 KiB
 // (the kernel is bandwidth bound: several workgroups per CU matter more than tile size).
 int pick_prep_cb(int numCh)
@@ -1242,6 +1258,25 @@ int build_layout(sgz_context *ctx)
 }
 
 }  // namespace
+
+// Called by sgz_create with the context's device current: looks up, once per device, where that device keeps
+// its copy of `scratch`.
+int sgz::noalloc_scratch_init(sgz_context *ctx)
+{
+    if (ctx->device < 0 || ctx->device >= kScratchMaxDevices) {
+        ctx->noalloc_scratch = nullptr;  // the entry point then reports that it is not available there
+        return SGZ_OK;
+    }
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[ctx->device]) {
+        void *ptr = nullptr;
+        SGZ_HIP(ctx, hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+        if (!ptr) return ctx->fail(SGZ_E_HIP, "hipGetSymbolAddress(scratch) returned no address");
+        g_scratch_ptr[ctx->device] = ptr;
+    }
+    ctx->noalloc_scratch = g_scratch_ptr[ctx->device];
+    return SGZ_OK;
+}
 
 // ---------------------------------------------------------------------------
 // C ABI
@@ -1508,7 +1543,8 @@ enum RunMode { kRunExact = 0, kRunScreenF32 = 1, kRunScreenF16 = 2 };
 
 static int corr_run_impl(sgz_context *ctx, int file_begin, int file_end, int mode);
 static int rescore_device_impl(sgz_context *ctx, sgz_candidate *device_cands, int64_t capacity,
-                               const unsigned long long *device_count, const HostReport &hr, bool truncated_ok = false);
+                               const unsigned long long *device_count, const HostReport &hr, bool truncated_ok = false,
+                               double *part_noalloc = nullptr);
 constexpr int64_t kSuspectCap = 1 << 16;  // windows an exact run can re-evaluate from their frames
 
 int sgz_corr_run(sgz_context *ctx, int file_begin, int file_end)
@@ -1782,7 +1818,8 @@ int sgz_corr_compact_bounded_device(sgz_context *ctx, int file_begin, int file_e
 }
 
 static int rescore_device_impl(sgz_context *ctx, sgz_candidate *device_cands, int64_t capacity,
-                               const unsigned long long *device_count, const HostReport &hr, bool truncated_ok)
+                               const unsigned long long *device_count, const HostReport &hr, bool truncated_ok,
+                               double *part_noalloc)
 {
     if (!ctx) return SGZ_E_ARG;
     if (ctx->layout_dirty || !ctx->have_target) return ctx->fail(SGZ_E_STATE, "no correlation results");
@@ -1798,13 +1835,28 @@ static int rescore_device_impl(sgz_context *ctx, sgz_candidate *device_cands, in
     rg.sliceFrames = (ctx->cp.L + rg.slices - 1) / rg.slices;
     rg.slices = (ctx->cp.L + rg.sliceFrames - 1) / rg.sliceFrames;  // no empty slice
     int rc;
-    if ((rc = ensure(ctx, ctx->d_rs_part, ctx->rs_part_cap, (size_t)capacity * rg.slices * kRsParts))) return rc;
-    if (!ctx->d_normtab) {  // sgz_set_norms was never called: normalisation is off, the table is not read
-        if ((rc = ensure(ctx, ctx->d_normtab, ctx->normtab_cap, (size_t)2 * SGZ_MAX_CHANNELS))) return rc;
-        SGZ_HIP(ctx, hipMemsetAsync(ctx->d_normtab, 0, sizeof(float) * 2 * SGZ_MAX_CHANNELS, ctx->stream));
-    }
-    double *part = ctx->d_rs_part;
+    double *part = part_noalloc;
     const float *normtab = ctx->d_normtab;
+    if (part_noalloc) {
+        // the variant that allocates nothing: partial sums in the device's scratch array.  Every value read is
+        // written earlier in the same call, so nothing has to be cleared.
+        const size_t need = (size_t)capacity * rg.slices * kRsParts * sizeof(double);
+        if (need > kNoAllocScratchBytes)
+            return ctx->fail(SGZ_E_ARG, "sgz_corr_rescore_device_noalloc: capacity " + std::to_string(capacity) + " x " +
+                                            std::to_string(rg.slices) + " slices of this target needs " +
+                                            std::to_string(need) + " bytes of scratch, the limit is " +
+                                            std::to_string(kNoAllocScratchBytes));
+        // no norms were ever set: normalisation is off and the kernels read but do not use the table
+        if (!normtab) normtab = reinterpret_cast<const float *>(part_noalloc);
+    } else {
+        if ((rc = ensure(ctx, ctx->d_rs_part, ctx->rs_part_cap, (size_t)capacity * rg.slices * kRsParts))) return rc;
+        part = ctx->d_rs_part;
+        if (!ctx->d_normtab) {  // sgz_set_norms was never called: normalisation is off, the table is not read
+            if ((rc = ensure(ctx, ctx->d_normtab, ctx->normtab_cap, (size_t)2 * SGZ_MAX_CHANNELS))) return rc;
+            SGZ_HIP(ctx, hipMemsetAsync(ctx->d_normtab, 0, sizeof(float) * 2 * SGZ_MAX_CHANNELS, ctx->stream));
+        }
+        normtab = ctx->d_normtab;
+    }
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
     const int grid = (int)std::min<long long>((long long)capacity * rg.slices, 8ll * cus);
@@ -1829,6 +1881,16 @@ int sgz_corr_rescore_device(sgz_context *ctx, sgz_candidate *device_cands, int64
 {
     if (!ctx) return SGZ_E_ARG;
     return rescore_device_impl(ctx, device_cands, capacity, device_count, HostReport{});
+}
+
+int sgz_corr_rescore_device_noalloc(sgz_context *ctx, sgz_candidate *device_cands, int64_t capacity,
+                                    const unsigned long long *device_count)
+{
+    if (!ctx) return SGZ_E_ARG;
+    if (!ctx->noalloc_scratch)
+        return ctx->fail(SGZ_E_STATE, "sgz_corr_rescore_device_noalloc: no scratch array on this device");
+    return rescore_device_impl(ctx, device_cands, capacity, device_count, HostReport{}, false,
+                               reinterpret_cast<double *>(ctx->noalloc_scratch));
 }
 
 static int compact_host(sgz_context *ctx, int file_begin, int file_end, float threshold, bool rescore,

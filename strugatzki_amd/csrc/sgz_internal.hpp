@@ -154,6 +154,7 @@ struct sgz_context {
     size_t normtab_cap = 0;
     double *d_rs_part = nullptr;             // partial sums of the exact re-scoring [window][slice][6]
     size_t rs_part_cap = 0;
+    void *noalloc_scratch = nullptr;         // this device's copy of the file-scope scratch array (sgz_corr.hip)
 
     sgz_candidate *d_cand = nullptr;         // [two count headers][records]
     sgz_candidate *d_suspect = nullptr;      // [count header][windows an exact run hands to the two-pass kernels]
@@ -213,6 +214,9 @@ bool half_screen_fits(const sgz_context *ctx);
 int half_screen_set_target(sgz_context *ctx, const std::vector<double> &aprime, size_t Lpad);
 int half_screen_launch(sgz_context *ctx, int tile_begin, int tile_end, hipStream_t stream, hipEvent_t start,
                        hipEvent_t stop);
+
+// sgz_corr.hip: address of the device's scratch array of sgz_corr_rescore_device_noalloc (device must be current)
+int noalloc_scratch_init(sgz_context *ctx);
 
 // sgz_context.hip: synchronous copy between pageable host memory and the device, staged in parallel when large
 int copy_large(sgz_context *ctx, void *dst, const void *src, size_t bytes, bool to_host);

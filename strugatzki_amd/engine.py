@@ -213,6 +213,11 @@ class Context:
     def corr_rescore_device(self, cands_ptr: int, capacity: int, count_ptr: int) -> None:
         self._check(lib.sgz_corr_rescore_device(self._h, C.c_void_p(cands_ptr), capacity, C.c_void_p(count_ptr)))
 
+    def corr_rescore_device_noalloc(self, cands_ptr: int, capacity: int, count_ptr: int) -> None:
+        """corr_rescore_device without any device allocation (fixed scratch array inside the library)."""
+        self._check(lib.sgz_corr_rescore_device_noalloc(self._h, C.c_void_p(cands_ptr), capacity,
+                                                        C.c_void_p(count_ptr)))
+
     def corr_last_kernel_ms(self) -> float:
         return float(lib.sgz_corr_last_kernel_ms(self._h))
 
