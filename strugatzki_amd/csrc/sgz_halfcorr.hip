@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -197,7 +198,17 @@ struct SelfSimArgs {
     float *simOut;                   // [imgExt][imgExt]; between two passes: the weighted first part, upper triangle
     int wantSim;                     // the last pass writes the matrix
     int *imgOut;
+    float wT;                        // temporal weight of the whole similarity
+    // pixels whose gray level the certified error of the similarity could change: listed by the last pass,
+    // evaluated in the reference's own order by selfsim_fix_kernel
+    unsigned long long *fixCount;
+    int2 *fixList;
+    long long fixCap;
 };
+
+// Largest error of a similarity that left selfsim_pixel as "sure": 8e-6 from the fp32 product sums (both groups,
+// weights adding to 1) and about 1e-6 from the fp32 quotient and mix.
+constexpr float kSsSimErr = 1.0e-5f;
 
 __device__ __noinline__ float correlate_half_exact(const float *xl, long long strideL, long long left, const float *xr,
                                                    long long strideR, long long right, int H, int c0, int c1)
@@ -389,8 +400,16 @@ __global__ __launch_bounds__(256, 2) void selfsim_tile_kernel(SelfSimArgs g)
                 lds[pxl * kRow + pyl] = sim;
                 // (the raster's row is imgExt - 1 - y: of the two pixels that show this value, the one whose
                 // neighbours along y lie in the same row)
-                if (g.imgOut)
-                    g.imgOut[(long long)(g.imgExt - 1 - px) * g.imgExt + py] = gray_color(sim, g.warp, g.scale, g.inv);
+                if (g.imgOut) {
+                    const int colr = gray_color(sim, g.warp, g.scale, g.inv);
+                    g.imgOut[(long long)(g.imgExt - 1 - px) * g.imgExt + py] = colr;
+                    // the colour map is monotonic: the level is certain when both ends of the error interval agree
+                    if (gray_color(sim - kSsSimErr, g.warp, g.scale, g.inv) !=
+                        gray_color(sim + kSsSimErr, g.warp, g.scale, g.inv)) {
+                        const unsigned long long slot = atomicAdd(g.fixCount, 1ull);
+                        if ((long long)slot < g.fixCap) g.fixList[slot] = make_int2(px, py);
+                    }
+                }
             }
         }
         if (!g.last) continue;
@@ -404,6 +423,38 @@ __global__ __launch_bounds__(256, 2) void selfsim_tile_kernel(SelfSimArgs g)
             if (g.wantSim) g.simOut[(long long)py * g.imgExt + px] = sim;
             if (g.imgOut)
                 g.imgOut[(long long)(g.imgExt - 1 - py) * g.imgExt + px] = gray_color(sim, g.warp, g.scale, g.inv);
+        }
+    }
+}
+
+// The listed pixels (or, without a list, every pixel with y >= x) in the reference's own order of operations
+// (impl/SelfSimilarityImpl.scala:143-150, MathUtil.correlateHalf): similarity, gray level, both mirror positions.
+__global__ __launch_bounds__(256) void selfsim_fix_kernel(SelfSimArgs g, const int2 *__restrict__ list,
+                                                          const unsigned long long *__restrict__ count, long long total)
+{
+    const long long n = list ? min((long long)*count, g.fixCap) : total;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        int px, py;
+        if (list) {
+            px = list[i].x;
+            py = list[i].y;
+        } else {
+            px = (int)(i / g.imgExt);
+            py = (int)(i - (long long)px * g.imgExt);
+            if (py < px) continue;
+        }
+        const long long left = (long long)g.afStart + (long long)px * g.decim;
+        const long long right = (long long)g.afStart + (long long)py * g.decim;
+        float temporal = 0.0f, spectral = 0.0f;
+        if (g.wT > 0.0f) temporal = correlate_half_dev(g.x1, g.frames1, left, g.x2, g.frames2, right, g.H, 0, 0, 1);
+        if (g.wT < 1.0f) spectral = correlate_half_dev(g.x1, g.frames1, left, g.x2, g.frames2, right, g.H, 0, 1, g.numCh);
+        const float sim = temporal * g.wT + spectral * (1.0f - g.wT);
+        const int colr = gray_color(sim, g.warp, g.scale, g.inv);
+        g.imgOut[(long long)(g.imgExt - 1 - px) * g.imgExt + py] = colr;
+        g.imgOut[(long long)(g.imgExt - 1 - py) * g.imgExt + px] = colr;
+        if (g.wantSim) {
+            g.simOut[(long long)px * g.imgExt + py] = sim;
+            g.simOut[(long long)py * g.imgExt + px] = sim;
         }
     }
 }
@@ -570,6 +621,25 @@ int sgz_selfsim_run(sgz_context *ctx, const float *frames1, int64_t num_frames1,
     a.simOut = (float *)simd.p;
     a.wantSim = sim_out ? 1 : 0;
     a.imgOut = (int *)imgd.p;
+    a.wT = temporal_weight;
+    // Gray levels are integer work: a pixel whose level the similarity's error bound could change is listed and
+    // evaluated again in the reference's order.  The list holds 1/16 of the pixels (with 255 level boundaries and
+    // an error of 1e-5 about 1/200 of them are expected); data that overflows it gets every pixel evaluated that way.
+    DevBuf fixd;
+    long long fixCap = std::max<long long>(1 << 16, (long long)(pix / 16));
+    if (const char *e = std::getenv("SGZ_SELFSIM_FIX_CAP")) {  // tuning / test knob: entries of that list
+        const long long v = std::atoll(e);
+        if (v >= 0) fixCap = v;
+    }
+    a.fixCount = nullptr;
+    a.fixList = nullptr;
+    a.fixCap = fixCap;
+    if (img_out) {
+        SGZ_HIP(ctx, hipMalloc(&fixd.p, sizeof(int2) * (size_t)(fixCap + 1)));
+        SGZ_HIP(ctx, hipMemsetAsync(fixd.p, 0, sizeof(int2), ctx->stream));
+        a.fixCount = reinterpret_cast<unsigned long long *>(fixd.p);
+        a.fixList = reinterpret_cast<int2 *>(fixd.p) + 1;
+    }
     if (doT) {
         a.c0 = 0;
         a.c1 = 1;
@@ -587,6 +657,19 @@ int sgz_selfsim_run(sgz_context *ctx, const float *frames1, int64_t num_frames1,
         a.wThis = 1.0f - temporal_weight;
         hipLaunchKernelGGL(selfsim_tile_kernel, dim3(gridWGs), dim3(256), 0, ctx->stream, a);
         SGZ_HIP(ctx, hipGetLastError());
+    }
+    if (img_out) {
+        hipLaunchKernelGGL(selfsim_fix_kernel, dim3(2048), dim3(256), 0, ctx->stream, a, (const int2 *)a.fixList,
+                           (const unsigned long long *)a.fixCount, 0ll);
+        SGZ_HIP(ctx, hipGetLastError());
+        unsigned long long listed = 0;
+        SGZ_HIP(ctx, hipMemcpyAsync(&listed, a.fixCount, sizeof listed, hipMemcpyDeviceToHost, ctx->stream));
+        SGZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (listed > (unsigned long long)fixCap) {  // more than the list holds: every pixel in the reference's order
+            hipLaunchKernelGGL(selfsim_fix_kernel, dim3(8192), dim3(256), 0, ctx->stream, a, (const int2 *)nullptr,
+                               (const unsigned long long *)nullptr, (long long)pix);
+            SGZ_HIP(ctx, hipGetLastError());
+        }
     }
     int rc;
     if (sim_out && (rc = copy_large(ctx, sim_out, simd.p, pix * sizeof(float), true))) return rc;

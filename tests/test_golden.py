@@ -138,6 +138,6 @@ def test_gpu_reproduces_selfsim_golden(ctx):
     ext, decim, af_start, num_corrs, H = (int(v) for v in g["params"])
     sim, img = ctx.selfsim(g["frames"], None, g["norms"], af_start, H, decim, ext, 0.5, 0, 0.7, 0.9, False)
     np.testing.assert_allclose(sim, g["sim"], rtol=0, atol=1e-5)
-    # pixel values: allow one grey level where pow() rounds differently
-    d = np.abs((img & 0xFF).astype(np.int64) - (g["img"] & 0xFF).astype(np.int64))
-    assert d.max() <= 1 and (d > 0).mean() < 0.01
+    # gray levels are integer work: every pixel whose level the similarity's error could change is evaluated in
+    # the reference's own order, so the raster is the oracle's
+    assert np.array_equal(img, g["img"])

@@ -137,9 +137,22 @@ def test_config4_self_similarity_of_a_30_minute_file():
     sample = np.random.default_rng(3).integers(0, ext, size=(20000, 2))
     px, py = sample[:, 0], sample[:, 1]
     assert np.array_equal(img[ext - 1 - py, px], img[ext - 1 - px, py])
-    # a corner against the oracle: the same geometry cut to the first 24 columns
+    # a corner against the oracle: the same geometry cut to the first 24 columns (windows on the diagonal overlap)
     ncut = 24
-    cut = x[:af_start + (ncut - 1) * decim + 2 * half + 8]
-    with S.Context(0) as ctx:
-        _, small = ctx.selfsim(cut, None, norms, af_start, half, decim, ncut, 0.5, want_sim=False)
-    assert np.array_equal(img[ext - ncut:, :ncut], small)
+    cut = x[:af_start + ncut * decim + 2 * half - 1]
+    ccfg = O.SelfSimConfig(0, 0, 0, 0, 44100, decim, 0.5, 0, 1.0, 1.0, 0, 1, STEP, NUM_CH - 1)
+    assert O.selfsim_geometry(ccfg, cut.shape[0], cut.shape[0])[:3] == (ncut, decim, af_start)
+    _, want = O.selfsim_run(ccfg, cut, None, norms)
+    assert np.array_equal(img[ext - ncut:, :ncut], want)
+    # and a block far from the diagonal: the oracle's two-file form compares windows of its first file (x) with
+    # windows of its second (y) for x <= y
+    X0, Y0, nb = 5000, 31000, 40
+    f1 = x[af_start + X0 * decim: af_start + (X0 + nb) * decim + 2 * half - 1]
+    f2 = x[af_start + Y0 * decim: af_start + (Y0 + nb) * decim + 2 * half - 1]
+    bcfg = O.SelfSimConfig(0, 0, 0, 0, 44100, decim, 0.5, 0, 1.0, 1.0, 0, 1, STEP, NUM_CH - 1)
+    assert O.selfsim_geometry(bcfg, f1.shape[0], f2.shape[0])[:3] == (nb, decim, 0)
+    _, blk = O.selfsim_run(bcfg, f1, f2, norms)
+    for bx in range(nb):
+        for by in range(bx, nb):
+            assert img[ext - 1 - (Y0 + by), X0 + bx] == blk[nb - 1 - by, bx]
+            assert img[ext - 1 - (X0 + bx), Y0 + by] == blk[nb - 1 - by, bx]  # the mirrored pixel

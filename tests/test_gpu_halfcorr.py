@@ -53,7 +53,8 @@ def test_segmentation_window_longer_than_span_gives_one_value(ctx, normalize):
 
 
 @pytest.mark.parametrize("decim,corr_len,warp,ceil,inv", [(1, 4 * STEP, 1.0, 1.0, False), (3, 8 * STEP, 0.5, 0.8, True),
-                                                         (2, 44100, 2.0, 1.0, False)])
+                                                         (2, 44100, 2.0, 1.0, False), (1, 6 * STEP, 1.0, 0.004, False),
+                                                         (1, 2 * STEP, 0.05, 1.0, True)])
 def test_selfsim_matrix_and_image(ctx, decim, corr_len, warp, ceil, inv):
     frames = _frames(260)
     norms = norms_default()
@@ -64,9 +65,22 @@ def test_selfsim_matrix_and_image(ctx, decim, corr_len, warp, ceil, inv):
     sim, img = ctx.selfsim(frames, None, norms, af_start, H, d, ext, 0.5, 0, warp, ceil, inv)
     np.testing.assert_allclose(sim, want_sim, rtol=0, atol=1e-5)
     assert np.array_equal(sim, sim.T)
-    dpx = np.abs((img & 0xFF).astype(np.int64) - (want_img & 0xFF).astype(np.int64))
-    assert dpx.max() <= 1 and (dpx > 0).mean() < 0.01
+    assert np.array_equal(img, want_img)  # pixels are integer work: bit-exact
     assert np.array_equal(img & 0xFF, (img >> 8) & 0xFF) and np.array_equal(img & 0xFF, (img >> 16) & 0xFF)
+
+
+def test_selfsim_image_when_the_fix_list_overflows(ctx, monkeypatch):
+    """More uncertain pixels than their list holds (here: a list of 3 entries, SGZ_SELFSIM_FIX_CAP): the whole
+    raster is evaluated in the reference's order instead."""
+    frames = _frames(300)
+    norms = norms_default()
+    cfg = O.SelfSimConfig(0, 0, 0, 0, 2 * STEP, 1, 0.5, 0, 1.0, 1.0, 0, 1, STEP, NUM_CH - 1)
+    ext, d, af_start, _ = O.selfsim_geometry(cfg, frames.shape[0], frames.shape[0])
+    want_sim, want_img = O.selfsim_run(cfg, frames, None, norms)
+    monkeypatch.setenv("SGZ_SELFSIM_FIX_CAP", "3")
+    sim, img = ctx.selfsim(frames, None, norms, af_start, 2, d, ext, 0.5)
+    assert np.array_equal(img, want_img)
+    assert np.array_equal(sim, want_sim)  # (then the similarities are the reference-order ones as well)
 
 
 def test_cross_file_similarity(ctx):
