@@ -12,8 +12,11 @@ windows per second, whole job.
 
 Workload at N=1: BASELINE.json configs[2] -- 30 s target (2584 feature frames)
 against a 10 h database (120 files x 300 s), 13 MFCC + loudness,
-temporalWeight 0.5, top-10.  For N>1 the database grows with N (weak scaling,
-120 tail files per GPU, sharded by file).
+temporalWeight 0.5, top-10.  For N>1 the default is BASELINE.json configs[4]:
+60 s target (5168 frames) against 1500 files x 300 s per GPU (125 h per GPU,
+1000 h on 8 GPUs), sharded by file; --target-seconds / --files-per-gpu override
+either.  The same run also times the reference-precision dense path (fp64
+kernel over every window) and reports it as roofline.exact.
 """
 from __future__ import annotations
 
@@ -119,9 +122,14 @@ def main() -> int:
     # few dozen steps after an idle period run 5-10 % slower) and still finish in a fraction of a second
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--files-per-gpu", type=int, default=120)
+    ap.add_argument("--files-per-gpu", type=int, default=None,
+                    help="database files per GPU (default: 120 at N=1, 1500 at N>1)")
     ap.add_argument("--file-seconds", type=float, default=300.0)
-    ap.add_argument("--target-seconds", type=float, default=30.0)
+    ap.add_argument("--target-seconds", type=float, default=None,
+                    help="target length (default: 30 at N=1, 60 at N>1)")
+    ap.add_argument("--exact-steps", type=int, default=30,
+                    help="steps of the reference-precision search (fp64 kernel, every window) timed after the main "
+                         "loop at N=1 for roofline.exact; 0 disables")
     ap.add_argument("--num-matches", type=int, default=10)
     ap.add_argument("--settle-ms", type=float, default=100.0,
                     help="untimed steps for about this long (counted as 0.3 ms each) before the warm-up steps, so that the "
@@ -146,6 +154,10 @@ def main() -> int:
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if args.files_per_gpu is None:
+        args.files_per_gpu = 120 if world == 1 else 1500
+    if args.target_seconds is None:
+        args.target_seconds = 30.0 if world == 1 else 60.0
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
@@ -258,6 +270,44 @@ def main() -> int:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    screened_work = ctx.corr_last_work()
+
+    # The same search at reference arithmetic: the fp64 kernel evaluates every window (no screening), the
+    # selection replays over its values.  Timed here, after the main loop, so that the driver's own run carries
+    # the number next to the screened one.
+    exact = None
+    if world == 1 and not sharded and not args.exact_only and args.exact_steps > 0:
+        pe = S.SearchParams(args.num_matches, 1, 0, STEP, capacity=1 << 16, screen=False)
+        ctx.set_kernel_timing(1)
+        for _ in range(3):
+            em = S.search(ctx, pe)
+        ctx.synchronize()
+        e_ms = []
+        te = time.perf_counter()
+        for _ in range(args.exact_steps):
+            em = S.search(ctx, pe)
+            e_ms.append(ctx.corr_last_kernel_ms())  # the tail launch: all files but the first num_matches
+        ctx.synchronize()
+        e_elapsed = time.perf_counter() - te
+        e_windows, e_flops = ctx.corr_last_work()
+        ek = float(np.mean(e_ms))
+        exact = {
+            "kernel": "corr_kernel<double>",
+            "dtype": "f64",
+            "windows_per_s": unique_windows / (e_elapsed / args.exact_steps),
+            "ms_per_step": e_elapsed / args.exact_steps * 1e3,
+            "steps": args.exact_steps,
+            "kernel_ms": ek,
+            "windows_per_launch": e_windows,
+            "achieved": e_flops / (ek * 1e-3) / 1e12 if ek > 0 else 0.0,
+            "peak": PEAK_F64_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": (e_flops / (ek * 1e-3) / 1e12) / PEAK_F64_TFLOPS if ek > 0 else 0.0,
+            "verified": [(m.file, m.start // STEP) for m in em] == [(p["file"], p["offset"]) for p in plants],
+            "same_matches_as_screened": [(m.file, m.start, m.stop) for m in em] == [(m.file, m.start, m.stop) for m in matches],
+            "note": "every window evaluated by the fp64 kernel (v_fmac_f64, fp64 vector peak 78.6 TFLOP/s), selection "
+                    "replayed over its values: the search at the reference's arithmetic, no screening",
+        }
 
     # known answer: match j is plant j (noise grows with j), at its planted offset
     got = [(m.file, m.start // STEP) for m in matches]
@@ -267,7 +317,7 @@ def main() -> int:
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         # dominant kernel: corr_kernel of the tail launch (the last sgz_corr_run of a step)
-        tail_windows, tail_flops = ctx.corr_last_work()
+        tail_windows, tail_flops = screened_work
         k_ms = float(np.mean(kernel_ms))
         achieved = tail_flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         alg_bytes = tail_windows * 64.0
@@ -295,7 +345,8 @@ def main() -> int:
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": mode,
+            "dtype": {"f16": "f16 screening (matrix cores), f64 re-scoring of every returned similarity",
+                      "f32": "f32 screening, f64 re-scoring of every returned similarity", "f64": "f64"}[mode],
             "data": "synthetic",
             "config": {
                 "workload": f"FeatureCorrelation: {args.target_seconds:g} s target ({L} frames) vs "
@@ -306,7 +357,11 @@ def main() -> int:
                 "files": total_files,
                 "sharding": "by file, round robin, nothing replicated; one all-gather of per-file candidates"
                             if world > 1 else "none",
+                "baseline_config": "configs[2]" if (L, args.files_per_gpu) == (2584, 120) else (
+                    "configs[4] (per-GPU shard)" if (L, args.files_per_gpu) == (5168, 1500) else "custom"),
             },
+            # work per window grows with the target length: this figure compares runs of different configurations
+            "whole_job_tflops": unique_windows * 2.0 * NUM_CH * L / (elapsed / args.steps) / 1e12,
             "roofline": {
                 "bound": "mfma",
                 "kernel": kernel,
@@ -324,6 +379,8 @@ def main() -> int:
             },
             "verified": verified,
         }
+        if exact is not None:
+            out["roofline"]["exact"] = exact
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(L, frames_per_file, args.cpu_seconds)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]

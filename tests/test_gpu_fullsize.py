@@ -64,15 +64,18 @@ def test_config3_search_30s_target_vs_10h_database():
         assert abs(one[0].sim - m.sim) <= 1.2e-7 and abs(one[0].boost_in - m.boost_in) <= 2e-6 * m.boost_in
 
 
-def test_config5_shape_60s_target():
-    """The 60 s target of the 8-GPU configuration (5168 frames: the staged channel of the matrix-core kernel is
-    twice as large, one workgroup per CU) on a slice of one rank's shard: known answer, and the search over
-    bounds equals the general path."""
+def test_config5_one_rank_shard_60s_target_1500_files():
+    """One rank's shard of the 8-GPU configuration at its real size: 60 s target (5168 frames: the staged channel
+    of the matrix-core kernel is twice as large, one workgroup per CU) against 1500 files x 300 s (125 h, 2.17 GB
+    of frames, 31 008 000 windows).  Known answer (planted copies in noise order at their offsets); the search
+    over bounds, the general path and the exact fp64 path return the same list; the bounds bracket the exact
+    similarities on whole files; a returned window equals the CPU oracle's value for that window."""
     import bench as B
     import strugatzki_amd as S
     from strugatzki_amd import _native as N
-    L, frames, nf, nm = 5168, 25839, 16, 4
-    plants = B.plant_list(nm, L, [1, 6, 11, 15], frames)
+    L, frames, nf, nm = 5168, 25839, 1500, 10
+    plant_files = [int(round(j * (nf - 1) / (nm - 1))) for j in range(nm)]
+    plants = B.plant_list(nm, L, plant_files, frames)
     npl = [N.Plant(p["file"], p["offset"], p["src_file"], p["src_offset"], p["length"], p["amp"], p["gain"])
            for p in plants]
     with S.Context(0) as ctx:
@@ -83,17 +86,35 @@ def test_config5_shape_60s_target():
         with S.Context(0) as c2:
             c2.db_reset(NUM_CH)
             c2.db_add_synthetic(B.SEED, B.TARGET_FILE, B.TARGET_START + L + 16, [])
-            target = c2.db_read_file(0)[B.TARGET_START:B.TARGET_START + L].copy()
+            tfile = c2.db_read_file(0)
+        target = tfile[B.TARGET_START:B.TARGET_START + L].copy()
         ctx.corr_set_target(target, 0.5, 8.0)
         assert ctx.screen_f16_available
+        assert sum(ctx.corr_num_windows(f) for f in range(nf)) == nf * (frames - L + 1) == 31_008_000
         fast = S.search(ctx, S.SearchParams(nm, 1, 0, STEP))
         assert [(m.file, m.start // STEP) for m in fast] == [(p["file"], p["offset"]) for p in plants]
+        assert all(m.stop - m.start == L * STEP for m in fast)
         general = S.search(ctx, S.SearchParams(nm, 1, 0, STEP, screen_head=False))
         exact = S.search(ctx, S.SearchParams(nm, 1, 0, STEP, screen=False))
         key = lambda ms: [(m.file, m.start, m.stop) for m in ms]
         assert key(general) == key(fast) == key(exact)
         assert [m.sim for m in general] == [m.sim for m in fast]
         assert all(abs(a.sim - b.sim) <= 1e-5 for a, b in zip(exact, fast))
+        # bounds vs the exact kernel on whole files from both ends of the shard
+        for f0 in (0, nf - 2):
+            ctx.corr_run_screen_f16(f0, f0 + 2)
+            up = [ctx.corr_read_dense(f)[0] for f in (f0, f0 + 1)]
+            ctx.corr_run(f0, f0 + 2)
+            for k, f in enumerate((f0, f0 + 1)):
+                ex = ctx.corr_read_dense(f)[0]
+                d = up[k].astype(np.float64) - ex
+                assert ex.shape[0] == frames - L + 1 and d.min() >= 0.0 and d.max() < 5e-3
+        # one matched window against the oracle (a single window: file cut to L frames)
+        m = fast[6]
+        raw = ctx.db_read_file(m.file)[m.start // STEP:m.start // STEP + L]
+        one, _, _ = O.correlation_run(corr_config(B.TARGET_START, L, num_matches=1), tfile, B.norms_default(), [raw],
+                                      dense=False)
+        assert abs(one[0].sim - m.sim) <= 1.2e-7 and abs(one[0].boost_in - m.boost_in) <= 2e-6 * m.boost_in
 
 
 def test_config2_extraction_of_one_hour_mono():
