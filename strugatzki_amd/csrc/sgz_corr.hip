@@ -105,13 +105,16 @@ __global__ __launch_bounds__(256) void prep_kernel(const FileDesc *__restrict__ 
                                                    const PrepTile *__restrict__ ptiles,
                                                    T *__restrict__ planar, double *__restrict__ prefix,
                                                    double *__restrict__ tbase, NormParams nrm, int numCh, int cb,
-                                                   double kT, double kS, int *__restrict__ hflags,
-                                                   int *__restrict__ lokey)
+                                                   double kT, double kS, int *__restrict__ hflags)
 {
     extern __shared__ __attribute__((aligned(16))) float xs[];
     __shared__ double wtot[4][4];
     const PrepTile pt = ptiles[blockIdx.x];
     const FileDesc fd = files[pt.file];
+    if constexpr (std::is_same<T, _Float16>::value) {  // the half-precision image is centred per file
+        kT = (double)fd.cT;
+        kS = (double)fd.cS;
+    }
     const int jstride = cb + 1;
     const int cstride = kR * jstride + 1;
     const long long f0 = (long long)pt.chunk0 * kR;
@@ -199,11 +202,8 @@ __global__ __launch_bounds__(256) void prep_kernel(const FileDesc *__restrict__ 
                 *reinterpret_cast<half8 *>(dst + (long long)c * rowLen + fr0) = out;
             }
         }
-        if (outOfRange) hflags[pt.file] = 1;
-        // the matrix-core kernel that follows folds its lower bounds into this per-file maximum
-        if (pt.chunk0 == 0 && tid == 0) lokey[pt.file] = bound_key(-INFINITY);
+        if (outOfRange) atomicOr(&hflags[pt.file], 1);
     } else {
-        if (pt.chunk0 == 0 && tid == 0) hflags[pt.file] = 0;  // exact values follow: no range flag
         // idx = tid + 256*k over [rows][cb]; cb is a power of two
         const int cbShift = 31 - __clz(cb);
         for (int idx = tid; idx < rows * cb; idx += 256) {
@@ -298,8 +298,9 @@ __global__ __launch_bounds__(256) void prep_kernel(const FileDesc *__restrict__ 
 #pragma unroll
                 for (int q = 0; q < 4; q++) base[q] += m[k][q];
                 if constexpr (std::is_same<T, _Float16>::value) {
-                    // screening: one fp32 record per frame (its bounds account for that rounding)
-                    reinterpret_cast<float4 *>(pre)[gf] =
+                    // screening: one fp32 record per frame (its bounds account for that rounding); `prefix` is
+                    // the record buffer of the half-precision path here
+                    (reinterpret_cast<float4 *>(prefix) + fd.prefix_off / 4)[gf] =
                         make_float4((float)base[0], (float)base[1], (float)base[2], (float)base[3]);
                 } else {
 #pragma unroll
@@ -347,9 +348,9 @@ constexpr int kPrepHalfFrames = 512;  // frames per workgroup of prep_half_kerne
 template <int NCH>
 __global__ __launch_bounds__(256) void prep_half_kernel(const FileDesc *__restrict__ files,
                                                         const PrepTile *__restrict__ ptiles,
-                                                        _Float16 *__restrict__ planar, double *__restrict__ prefix,
-                                                        double *__restrict__ tbase, NormParams nrm, double kT,
-                                                        double kS, int *__restrict__ hflags, int *__restrict__ lokey)
+                                                        _Float16 *__restrict__ planar, float4 *__restrict__ prefix,
+                                                        double *__restrict__ tbase, NormParams nrm,
+                                                        int *__restrict__ hflags)
 {
     static_assert((2 * NCH) % 4 == 0, "two frames must be whole 16-byte vectors");
     constexpr int kVecPerThread = 2 * NCH / 4;
@@ -400,7 +401,7 @@ __global__ __launch_bounds__(256) void prep_half_kernel(const FileDesc *__restri
     }
     const long long gf0 = f0 + 2 * tid;
     const bool ok[2] = {gf0 < fd.frames, gf0 + 1 < fd.frames};
-    const float kTf = (float)kT, kSf = (float)kS;
+    const float kTf = fd.cT, kSf = fd.cS;  // the file's own mean levels (file_const_kernel)
     float peak = 0.0f;
     float mom[2][4];
     // the half-precision image and its bounds do not need the reference's exact fp32 quotient (re-scoring
@@ -441,9 +442,7 @@ __global__ __launch_bounds__(256) void prep_half_kernel(const FileDesc *__restri
             *reinterpret_cast<half2v *>(dst + (long long)c * rowLen) = h;
         }
     }
-    if (peak > 60000.0f) hflags[pt.file] = 1;
-    // the matrix-core kernel that follows folds its lower bounds into this per-file maximum
-    if (pt.chunk0 == 0 && tid == 0) lokey[pt.file] = bound_key(-INFINITY);
+    if (peak > 60000.0f) atomicOr(&hflags[pt.file], 1);
 
     // phase 3: frame moments (loudness: x, x^2; MFCC rows: sum x, sum x^2, all centred; the 13-term sums of
     // one frame in fp32, the running sums in fp64), inclusive prefix sums inside this tile; the tile totals go
@@ -469,7 +468,7 @@ __global__ __launch_bounds__(256) void prep_half_kernel(const FileDesc *__restri
         }
         __syncthreads();
         // one fp32 record of the four running sums per frame (the screening bounds account for that rounding)
-        float4 *pre = reinterpret_cast<float4 *>(prefix + fd.prefix_off);
+        float4 *pre = prefix + fd.prefix_off / 4;  // (prefix_off counts four values per frame)
         double base[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -490,6 +489,52 @@ __global__ __launch_bounds__(256) void prep_half_kernel(const FileDesc *__restri
                 tbase[fd.tbase_off + (long long)q * fd.nptiles + tileIdx] = wtot[0][q] + wtot[1][q] + wtot[2][q] + inc[q];
         }
     }
+}
+
+// ---------------------------------------------------------------------------
+// file_const_kernel: the centring constants of a file's half-precision image -- the mean of the normalised
+// loudness channel and the mean of all other normalised channels over the whole file -- written into the file
+// table on the device.  Any constant gives correct bounds (the target image is centred on its own mean, so the
+// constant drops out of the cross term); the file's own mean keeps the half-precision values, and with them
+// the error bound, small.  One workgroup per file; thread t owns channel t % numCh (fixed order of summation).
+// A file whose mean is not finite gets 0: its bounds are NaN then and the exact path takes over.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void file_const_kernel(FileDesc *__restrict__ files, int fileBegin, NormParams nrm,
+                                                          int numCh)
+{
+    __shared__ double part[1024];
+    FileDesc &fd = files[fileBegin + blockIdx.x];
+    const int tid = threadIdx.x;
+    const int rows = 1024 / numCh, stride = rows * numCh;
+    const long long total = fd.frames * numCh;
+    double s = 0.0;
+    if (tid < stride) {
+        const int c = tid % numCh;
+        const float mn = nrm.enabled ? nrm.mn[c] : 0.0f, d = nrm.enabled ? nrm.d[c] : 1.0f;
+        for (long long e = tid; e < total; e += stride) s += (double)((fd.raw[e] - mn) / d);
+    }
+    part[tid] = s;
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0, sp = 0.0;
+        for (int k = 0; k < stride; k++) {
+            if (k % numCh == 0) t += part[k]; else sp += part[k];
+        }
+        const double n = (double)fd.frames;
+        float cT = n > 0 ? (float)(t / n) : 0.0f, cS = n > 0 ? (float)(sp / (n * (numCh - 1))) : 0.0f;
+        if (!(fabsf(cT) < 3.0e38f)) cT = 0.0f;
+        if (!(fabsf(cS) < 3.0e38f)) cS = 0.0f;
+        fd.cT = cT;
+        fd.cS = cS;
+    }
+}
+
+// New target, same layout: the NaN marks the matrix-core kernel left (bit 2) belong to the previous target; the
+// range marks of the image (bit 1) stay.
+__global__ void clear_nan_flags_kernel(int *__restrict__ hflags, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) hflags[i] &= 1;
 }
 
 // ---------------------------------------------------------------------------
@@ -796,7 +841,7 @@ __global__ __launch_bounds__(256) void compact_kernel(const FileDesc *__restrict
                                                       const float *__restrict__ boost, float threshold,
                                                       sgz_candidate *__restrict__ out, long long capacity,
                                                       unsigned long long *__restrict__ count,
-                                                      const int *__restrict__ hflags,
+                                                      const int *__restrict__ hflags, int flagBegin, int flagEnd,
                                                       unsigned long long *__restrict__ zeroOther)
 {
     const TileDesc td = tiles[blockIdx.x];
@@ -804,8 +849,11 @@ __global__ __launch_bounds__(256) void compact_kernel(const FileDesc *__restrict
     // the counter of the next call (callers that alternate between two counters need no separate clear)
     if (zeroOther && blockIdx.x == 0 && threadIdx.x == 0) *zeroOther = 0ull;
     // A file whose half-precision image overflowed has no usable screening values: report it as a
-    // candidate overflow, which sends the caller to the exact dense path.
-    if (hflags[td.file] && td.o0 == 0 && threadIdx.x == 0) atomicAdd(count, (unsigned long long)capacity + 1ull);
+    // candidate overflow, which sends the caller to the exact dense path.  (The marks belong to the image: they
+    // count for the files [flagBegin, flagEnd) that have one, whose stored values may be bounds of a half-precision
+    // run; a marked file that has been through an exact run since is reported all the same, which is safe.)
+    if (td.file >= flagBegin && td.file < flagEnd && hflags[td.file] && td.o0 == 0 && threadIdx.x == 0)
+        atomicAdd(count, (unsigned long long)capacity + 1ull);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const long long o = (long long)td.o0 + k * 256 + threadIdx.x;
@@ -862,6 +910,7 @@ __global__ __launch_bounds__(256) void compact_bounded_kernel(const FileDesc *__
     const TileDesc td = tiles[blockIdx.x];
     const FileDesc fd = files[td.file];
     if (zeroOther && blockIdx.x == 0 && threadIdx.x == 0) *zeroOther = 0ull;
+    // (every file this kernel sees holds bounds of a half-precision run: the host checks)
     if (hflags[td.file] && td.o0 == 0 && threadIdx.x == 0) atomicAdd(count, (unsigned long long)capacity + 1ull);
     const bool headFile = td.file < headEnd;
     const float t = headFile ? bound_from_key(lokey[td.file]) : tailThr[0];
@@ -1228,15 +1277,23 @@ int build_layout(sgz_context *ctx)
     }
     if ((rc = ensure(ctx, ctx->d_hflags, ctx->hflags_cap, (size_t)nf))) return rc;
     if (nf) SGZ_HIP(ctx, hipMemsetAsync(ctx->d_hflags, 0, sizeof(int) * nf, ctx->stream));
+    ctx->hc_begin = ctx->hc_end = 0;  // no half-precision preparation of this layout yet
+    if (halfOk) {
+        if ((rc = ensure(ctx, ctx->d_prefix_h, ctx->prefix_h_cap, (size_t)prefix))) return rc;
+        if ((rc = ensure(ctx, ctx->d_tbase_h, ctx->tbase_h_cap, (size_t)tb))) return rc;
+    }
     if ((rc = ensure(ctx, ctx->d_prefix, ctx->prefix_cap, (size_t)prefix))) return rc;
     if ((rc = ensure(ctx, ctx->d_tbase, ctx->tbase_cap, (size_t)tb))) return rc;
     if ((rc = ensure(ctx, ctx->d_sim, ctx->dense_cap, (size_t)wins))) return rc;
     if ((rc = ensure(ctx, ctx->d_boost, ctx->boost_cap, (size_t)wins))) return rc;
     if (halfOk && (rc = ensure(ctx, ctx->d_lo, ctx->lo_cap, (size_t)wins))) return rc;
-    if (halfOk && (rc = ensure(ctx, ctx->d_lokey, ctx->lokey_cap, (size_t)nf))) return rc;
-    if (halfOk && nf)  // key of -inf; files without windows keep it (no prep tile resets them)
-        SGZ_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ctx->d_lokey), (int)0x807fffff, (size_t)nf,
+    if (halfOk && (rc = ensure(ctx, ctx->d_lokey, ctx->lokey_cap, (size_t)2 * nf))) return rc;
+    if (halfOk && nf)  // key of -inf in both arrays; files without windows keep it (no tile ever writes them)
+        SGZ_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ctx->d_lokey), (int)0x807fffff, (size_t)2 * nf,
                                        ctx->stream));
+    ctx->lokey_clean[0] = ctx->lokey_clean[1] = true;
+    ctx->lokey_parity = 0;
+    ctx->lokey_cur = ctx->d_lokey;
     ctx->lo_begin = ctx->lo_end = 0;
     // the three tables are consumed by kernels queued later on ctx->stream
     if (nf) SGZ_HIP(ctx, hipMemcpyAsync(ctx->d_files, ctx->h_files.data(), sizeof(FileDesc) * nf,
@@ -1524,10 +1581,13 @@ int sgz_corr_set_target(sgz_context *ctx, const float *frames, int num_frames, f
     const bool hadHalf = ctx->hg.S2 > 0;
     if ((rc = half_screen_set_target(ctx, ap, Lpad))) return rc;
     if (oldL != L || hadHalf != (ctx->hg.S2 > 0)) ctx->layout_dirty = true;
-    // the range flags of half-precision runs belong to the previous target
-    // (a pending layout rebuild clears them itself, for the files of the new layout)
-    if (ctx->d_hflags && !ctx->layout_dirty && !ctx->files.empty())
-        SGZ_HIP(ctx, hipMemsetAsync(ctx->d_hflags, 0, sizeof(int) * ctx->files.size(), ctx->stream));
+    // the NaN marks of half-precision runs belong to the previous target
+    // (a pending layout rebuild clears all marks itself, for the files of the new layout)
+    if (ctx->d_hflags && !ctx->layout_dirty && !ctx->files.empty()) {
+        const int n = (int)ctx->files.size();
+        hipLaunchKernelGGL(clear_nan_flags_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_hflags, n);
+        SGZ_HIP(ctx, hipGetLastError());
+    }
     return SGZ_OK;
 }
 
@@ -1606,28 +1666,45 @@ static int corr_run_impl(sgz_context *ctx, int file_begin, int file_end, int mod
     // an earlier run over some of these files (possibly on the other stream) writes the same outputs
     for (auto &run : ctx->runs)
         if (run.fb < file_end && run.fe > file_begin && (rc = ctx->wait_for_run(run, stream))) return rc;
-    // Range flags of these files: a half-precision run sets them and never clears them (they depend on the
-    // frames, the norms and the target only: cleared when one of those changes), any other run clears them.
+    // Half precision: image, prefix records, tile bases, range marks and centring constants depend on database,
+    // norms and target length only; they are built when a run first covers these files and kept until the layout
+    // is rebuilt.  A search with a new target of the same length then starts with the matrix-core kernel.
+    const bool halfCached = half && ctx->hc_begin <= file_begin && file_end <= ctx->hc_end;
+    if (half && !halfCached) {
+        SGZ_HIP(ctx, hipMemsetAsync(ctx->d_hflags + file_begin, 0, sizeof(int) * (size_t)(file_end - file_begin), stream));
+        hipLaunchKernelGGL(file_const_kernel, dim3(file_end - file_begin), dim3(1024), 0, stream, ctx->d_files, file_begin,
+                           ctx->norm, ctx->numCh);
+        SGZ_HIP(ctx, hipGetLastError());
+    }
     if (exact)
         hipLaunchKernelGGL(prep_kernel<double>, dim3(pt1 - pt0), dim3(256), prepLds, stream, ctx->d_files,
                            ctx->d_ptiles + pt0, ctx->d_planar, ctx->d_prefix, ctx->d_tbase, ctx->norm, ctx->numCh, cb,
-                           ctx->cp.kT, ctx->cp.kS, ctx->d_hflags, ctx->d_lokey);
+                           ctx->cp.kT, ctx->cp.kS, ctx->d_hflags);
+    else if (halfCached)
+        ;
     else if (half && ctx->numCh == 14 && cb * kR == kPrepHalfFrames)  // the reference's default: 13 MFCC + loudness
         hipLaunchKernelGGL(prep_half_kernel<14>, dim3(pt1 - pt0), dim3(256), 0, stream, ctx->d_files,
-                           ctx->d_ptiles + pt0, reinterpret_cast<_Float16 *>(ctx->d_planar_h), ctx->d_prefix,
-                           ctx->d_tbase, ctx->norm, ctx->cp.kT, ctx->cp.kS, ctx->d_hflags, ctx->d_lokey);
+                           ctx->d_ptiles + pt0, reinterpret_cast<_Float16 *>(ctx->d_planar_h),
+                           reinterpret_cast<float4 *>(ctx->d_prefix_h), ctx->d_tbase_h, ctx->norm, ctx->d_hflags);
     else if (half)
         hipLaunchKernelGGL(prep_kernel<_Float16>, dim3(pt1 - pt0), dim3(256), prepLds, stream, ctx->d_files,
-                           ctx->d_ptiles + pt0, reinterpret_cast<_Float16 *>(ctx->d_planar_h), ctx->d_prefix,
-                           ctx->d_tbase, ctx->norm, ctx->numCh, cb, ctx->cp.kT, ctx->cp.kS, ctx->d_hflags, ctx->d_lokey);
+                           ctx->d_ptiles + pt0, reinterpret_cast<_Float16 *>(ctx->d_planar_h),
+                           reinterpret_cast<double *>(ctx->d_prefix_h), ctx->d_tbase_h, ctx->norm, ctx->numCh, cb, 0.0, 0.0,
+                           ctx->d_hflags);
     else
         hipLaunchKernelGGL(prep_kernel<float>, dim3(pt1 - pt0), dim3(256), prepLds, stream, ctx->d_files,
                            ctx->d_ptiles + pt0, planarF, ctx->d_prefix, ctx->d_tbase, ctx->norm, ctx->numCh, cb,
-                           ctx->cp.kT, ctx->cp.kS, ctx->d_hflags, ctx->d_lokey);
+                           ctx->cp.kT, ctx->cp.kS, ctx->d_hflags);
     SGZ_HIP(ctx, hipGetLastError());
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(file_end - file_begin), dim3(256), 0, stream, ctx->d_files,
-                       file_begin, ctx->d_tbase);
-    SGZ_HIP(ctx, hipGetLastError());
+    if (!halfCached) {
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(file_end - file_begin), dim3(256), 0, stream, ctx->d_files,
+                           file_begin, half ? ctx->d_tbase_h : ctx->d_tbase);
+        SGZ_HIP(ctx, hipGetLastError());
+    }
+    if (half && !halfCached) {
+        ctx->hc_begin = file_begin;
+        ctx->hc_end = file_end;
+    }
     const size_t corrLds = exact ? corr_lds_bytes<double>() : corr_lds_bytes<float>();
     // windows whose prefix-sum statistics cannot be trusted (constant stretches): see SuspectList
     SuspectList suspects{nullptr, nullptr, 0, INFINITY};
@@ -1761,7 +1838,7 @@ static int compact_device_impl(sgz_context *ctx, int file_begin, int file_end, f
     if (t1 > t0) {
         hipLaunchKernelGGL(compact_kernel, dim3(t1 - t0), dim3(256), 0, ctx->stream, ctx->d_files,
                            ctx->d_tiles + t0, ctx->d_sim, ctx->d_boost, threshold, device_out,
-                           (long long)capacity, device_count, ctx->d_hflags, zero_other);
+                           (long long)capacity, device_count, ctx->d_hflags, ctx->hc_begin, ctx->hc_end, zero_other);
         SGZ_HIP(ctx, hipGetLastError());
     }
     return SGZ_OK;
@@ -1796,14 +1873,14 @@ static int compact_bounded_device_impl(sgz_context *ctx, int file_begin, int fil
     for (auto &run : ctx->runs)
         if (run.fb < need_end && (rc = ctx->wait_for_run(run, ctx->stream))) return rc;
     if (head_end < file_end) {  // tail files present: they are filtered by the smallest head bound
-        hipLaunchKernelGGL(bound_min_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->d_lokey, head_end, ctx->d_thr);
+        hipLaunchKernelGGL(bound_min_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->lokey_cur, head_end, ctx->d_thr);
         SGZ_HIP(ctx, hipGetLastError());
     }
     const int t0 = ctx->tile_begin[file_begin], t1 = ctx->tile_begin[file_end];
     if (launched) *launched = t1 > t0;
     if (t1 > t0) {
         hipLaunchKernelGGL(compact_bounded_kernel, dim3(t1 - t0), dim3(256), 0, ctx->stream, ctx->d_files,
-                           ctx->d_tiles + t0, ctx->d_sim, ctx->d_boost, ctx->d_lokey, ctx->d_thr, head_end, device_out,
+                           ctx->d_tiles + t0, ctx->d_sim, ctx->d_boost, ctx->lokey_cur, ctx->d_thr, head_end, device_out,
                            (long long)capacity, device_count, ctx->d_hflags, zero_other);
         SGZ_HIP(ctx, hipGetLastError());
     }

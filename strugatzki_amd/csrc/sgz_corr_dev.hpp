@@ -119,9 +119,15 @@ __device__ __forceinline__ WindowRecords window_records(const HalfPrefix &hp, un
     return WindowRecords{hp.pre[o + (unsigned)L - 1], hp.pre[o > 0 ? o - 1 : 0]};
 }
 
+// cT: centring constant of the loudness channel of this file's image; relErrT / relErrS: relative error of the
+// cross terms of the two channel groups.  Half-precision values below 2^-14 round with an absolute error of up to
+// 2^-25 instead of a relative one: over a whole window that moves a normalised cross term by at most
+// 2^-25 (1 / sd_b + sqrt(1 + (dm / sd_b)^2) / sd_a), which is added.
 __device__ __forceinline__ WindowCoeffs window_coeffs(const CorrParams &cp, const HalfPrefix &hp, unsigned o,
-                                                      const WindowRecords &rec, float relErr, float &boostOut)
+                                                      const WindowRecords &rec, double cT, float relErrT,
+                                                      float relErrS, float &boostOut)
 {
+    constexpr float kSubAbs = 2.9802322e-8f;  // 2^-25
     const double nTd = (double)cp.L, nSd = (double)cp.L * (double)(cp.numCh - 1);
     const double rnT = 1.0 / nTd, rnS = 1.0 / nSd;  // wave-uniform: one division each, not one per window
     const unsigned l1 = o > 0 ? o - 1 : 0, h1 = o + (unsigned)cp.L - 1;
@@ -151,7 +157,7 @@ __device__ __forceinline__ WindowCoeffs window_coeffs(const CorrParams &cp, cons
     const double varT = d[1] * rnT - dmTd * dmTd;
     const double dmSd = d[2] * rnS;
     const double varS = d[3] * rnS - dmSd * dmSd;
-    const float avgF = (float)(cp.kT + dmTd);
+    const float avgF = (float)(cT + dmTd);
     const float kLn2 = 0.6931471805599453f, kLog2e = 1.4426950408889634f;
     const float lnAvg = __builtin_amdgcn_logf(avgF) * kLn2;  // avg <= 0: NaN / -inf, the window reads as gated
     const float boost = __builtin_amdgcn_exp2f(((float)cp.lnAvgIn - lnAvg) * (kLog2e / 0.6f));
@@ -167,7 +173,8 @@ __device__ __forceinline__ WindowCoeffs window_coeffs(const CorrParams &cp, cons
             const float dv = (E[1] + 2.0f * fabsf(dm) * E[0]) * rn;
             wc.a = (cp.w / ((float)cp.aStdT * (float)nTd)) * rsd;
             wc.c = wc.a * dm * (float)cp.sumAT;
-            const float eh = relErr * __builtin_amdgcn_sqrtf(1.0f + r * r);
+            const float q = __builtin_amdgcn_sqrtf(1.0f + r * r);
+            const float eh = relErrT * q + kSubAbs * (rsd + q / (float)cp.aStdT);
             errT = var > 0.0f && 2.0f * dv <= var ? eh + (1.0f + eh) * dv * (rsd * rsd) + fabsf(wc.a * (float)cp.sumAT) * E[0] * rn / cp.w
                                     : INFINITY;
         }
@@ -179,7 +186,8 @@ __device__ __forceinline__ WindowCoeffs window_coeffs(const CorrParams &cp, cons
             const float dv = (E[3] + 2.0f * fabsf(dm) * E[2]) * rn;
             wc.b = ((1.0f - cp.w) / ((float)cp.aStdS * (float)nSd)) * rsd;
             wc.c += wc.b * dm * (float)cp.sumAS;
-            const float eh = relErr * __builtin_amdgcn_sqrtf(1.0f + r * r);
+            const float q = __builtin_amdgcn_sqrtf(1.0f + r * r);
+            const float eh = relErrS * q + kSubAbs * (rsd + q / (float)cp.aStdS);
             errS = var > 0.0f && 2.0f * dv <= var
                        ? eh + (1.0f + eh) * dv * (rsd * rsd) + fabsf(wc.b * (float)cp.sumAS) * E[2] * rn / (1.0f - cp.w)
                        : INFINITY;

@@ -41,9 +41,18 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int kHThreads = kHWaves * 64;
 constexpr int kHSlabFloats = kHTileW + kHTileW / 8;  // one partial sum per window of a tile, skewed (see reduce)
-// Two half-precision roundings (target and database value, 2^-11 each) per product, with some room for the
-// fp32 summation.
-constexpr float kHalfRelErr = 1.0e-3f;
+
+// Relative error of a cross term of `channels` channels, against sum |a'| |b|.  Two half-precision roundings per
+// product (target and database value, 2^-11 each: (1 + 2^-11)^2 - 1 = 2^-10 + 2^-22; the product of two
+// half-precision numbers is exact in fp32).  The sums are fp32: an output element goes through
+// channels * ceil(S2 / 8) matrix instructions in sequence, each of which may round its 32-term sum and the
+// accumulation several times (counted as 6 roundings of 2^-24), then through the 8 additions of the cross-wave
+// sum.  The term grows with the target length: 5e-5 at 2 584 frames, 2.3e-4 at 12 500.
+float half_rel_err(int channels, int S2)
+{
+    const double steps = (double)channels * (double)((S2 + 7) / 8);
+    return (float)(std::ldexp(1.0, -10) + std::ldexp(1.0, -22) + (6.0 * steps + 8.0) * std::ldexp(1.0, -24)) * 1.0001f;
+}
 
 // One staged channel: XU 16-byte units of database frames, then the two target copies (LAd dwords each),
 // each part rounded up to whole 1 KiB pieces, the unit one wave-wide direct-to-LDS load fills
@@ -72,9 +81,9 @@ size_t half_lds_bytes(const HalfGeom &hg) { return 2 * half_buf_bytes(hg.XU, hg.
 // the phase, so no registers hold data in flight.
 __global__ __launch_bounds__(kHThreads, 4) void corr_mfma_kernel(
     const FileDesc *__restrict__ files, const TileDesc *__restrict__ tiles, const _Float16 *__restrict__ planarH,
-    const double *__restrict__ prefix, const double *__restrict__ tbase, const uint32_t *__restrict__ aimg,
+    const float4 *__restrict__ prefix, const double *__restrict__ tbase, const uint32_t *__restrict__ aimg,
     CorrParams cp, HalfGeom hg, float *__restrict__ simOut, float *__restrict__ boostOut, float *__restrict__ loOut,
-    int *__restrict__ lokey, int *__restrict__ hflags)
+    int *__restrict__ lokey, int *__restrict__ lokeyNext, int *__restrict__ hflags)
 {
     constexpr int NB = kHNB;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -224,7 +233,7 @@ __global__ __launch_bounds__(kHThreads, 4) void corr_mfma_kernel(
     // the part of the bounds that does not depend on the cross terms is evaluated here, after the matrix work,
     // so that it holds no registers during it.
     HalfPrefix hp;
-    hp.pre = reinterpret_cast<const float4 *>(prefix + fd.prefix_off);
+    hp.pre = prefix + fd.prefix_off / 4;  // (prefix_off counts four values per frame)
     hp.tbase = tbase + fd.tbase_off;
     hp.nptiles = fd.nptiles;
     hp.tileShift = cp.prepTileShift;
@@ -266,7 +275,7 @@ __global__ __launch_bounds__(kHThreads, 4) void corr_mfma_kernel(
         if (o < fd.num_windows) {
             float sim, lo;
             float boost;
-            const WindowCoeffs wc = window_coeffs(cph, hp, (unsigned)o, rec[k], kHalfRelErr, boost);
+            const WindowCoeffs wc = window_coeffs(cph, hp, (unsigned)o, rec[k], (double)fd.cT, hg.relErrT, hg.relErrS, boost);
             window_bounds(wc, red_read(redT4, wdw), red_read(redS4, wdw), sim, lo);
             boostOut[fd.win_off + o] = boost;
             simOut[fd.win_off + o] = sim;
@@ -296,6 +305,9 @@ __global__ __launch_bounds__(kHThreads, 4) void corr_mfma_kernel(
         }
         atomicMax(&lokey[td.file], bound_key(best));
         if (bad) atomicOr(&hflags[td.file], 2);
+        // the run after this one folds its bounds into the other array: the file's first tile resets its entry
+        // there (nothing reads that array before then: kernels of one stream run in order)
+        if (td.o0 == 0) lokeyNext[td.file] = bound_key(-INFINITY);
     }
 }
 
@@ -314,6 +326,7 @@ static bool half_geom(int L, HalfGeom &hg)
     hg.S2 = S2;
     hg.LAd = LAd;
     hg.XU = XU;
+    hg.relErrT = hg.relErrS = 0.0f;  // set with the target (they depend on the channel count)
     if (half_lds_bytes(hg) > 160 * 1024) return false;
     return true;
 }
@@ -352,6 +365,8 @@ int half_screen_set_target(sgz_context *ctx, const std::vector<double> &aprime, 
     }
     hg.sumAT = sumT;
     hg.sumAS = sumS;
+    hg.relErrT = half_rel_err(1, hg.S2);
+    hg.relErrS = half_rel_err(numCh - 1, hg.S2);
     int rc;
     if ((rc = ensure(ctx, ctx->d_aimg_h, ctx->aimg_h_cap, img.size()))) return rc;
     SGZ_HIP(ctx, hipMemcpy(ctx->d_aimg_h, img.data(), img.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
@@ -367,13 +382,26 @@ int half_screen_launch(sgz_context *ctx, int tile_begin, int tile_end, hipStream
     const size_t ldsBytes = half_lds_bytes(hg);
     const _Float16 *planarH = reinterpret_cast<const _Float16 *>(ctx->d_planar_h);
     const uint32_t *aimg = reinterpret_cast<const uint32_t *>(ctx->d_aimg_h);
+    // the array of per-file bounds this run folds into must hold -inf everywhere: the previous run reset it,
+    // unless it covered other files than this one does
+    const int nf = (int)ctx->files.size();
+    const int par = ctx->lokey_parity;
+    int *lokey = ctx->d_lokey + (size_t)par * nf, *lokeyNext = ctx->d_lokey + (size_t)(1 - par) * nf;
+    if (!ctx->lokey_clean[par])
+        SGZ_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(lokey), (int)0x807fffff, (size_t)nf, stream));
+    const bool whole = tile_begin == 0 && tile_end == (int)ctx->h_tiles_h.size();
+    ctx->lokey_clean[par] = false;
+    ctx->lokey_clean[1 - par] = whole || ctx->lokey_clean[1 - par];
+    ctx->lokey_cur = lokey;
+    ctx->lokey_parity = 1 - par;
     auto kern = corr_mfma_kernel;
     if (ldsBytes > 64 * 1024)
         SGZ_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
     hipExtLaunchKernelGGL(kern, dim3(tile_end - tile_begin), dim3(kHThreads), ldsBytes, stream, start, stop, 0,
-                          ctx->d_files, ctx->d_tiles_h + tile_begin, planarH, ctx->d_prefix, ctx->d_tbase, aimg, ctx->cp,
-                          hg, ctx->d_sim, ctx->d_boost, ctx->d_lo, ctx->d_lokey, ctx->d_hflags);
+                          ctx->d_files, ctx->d_tiles_h + tile_begin, planarH,
+                          reinterpret_cast<const float4 *>(ctx->d_prefix_h), ctx->d_tbase_h, aimg, ctx->cp, hg, ctx->d_sim,
+                          ctx->d_boost, ctx->d_lo, lokey, lokeyNext, ctx->d_hflags);
     SGZ_HIP(ctx, hipGetLastError());
     return SGZ_OK;
 }

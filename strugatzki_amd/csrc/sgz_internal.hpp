@@ -30,6 +30,9 @@ struct FileDesc {
     long long nptiles;       // prep tiles that hold frames of this file
     long long win_off;       // offset of this file's windows in the dense sim / boost arrays
     long long num_windows;
+    // centring constants of the file's half-precision image (normalised mean of the loudness channel and of the
+    // other channels over the whole file): written on the device by file_const_kernel, never read on the host
+    float cT, cS;
 };
 
 struct TileDesc {
@@ -73,6 +76,9 @@ struct HalfGeom {
     int LAd;   // dwords per shifted copy of one target channel (LAd % 32 == 16)
     int XU;    // 16-byte units of one staged channel block of database frames
     double sumAT, sumAS;  // sums of the half-precision target values
+    // relative error of a cross term formed from half-precision operands with fp32 sums (loudness channel, other
+    // channels): see half_rel_err
+    float relErrT, relErrS;
 };
 
 struct DbFile {
@@ -145,8 +151,20 @@ struct sgz_context {
     float *d_lo = nullptr;                   // lower bounds of the half-precision screening run
     size_t lo_cap = 0;
     int lo_begin = 0, lo_end = 0;            // files whose d_sim / d_lo hold bounds of the latest such run
-    int *d_lokey = nullptr;                  // per file: largest lower bound of that run, as an ordered integer key
+    // per file: largest lower bound of a half-precision run, as an ordered integer key.  Two arrays of one entry
+    // per file: a run folds its bounds into one of them and resets the other for the run after it.
+    int *d_lokey = nullptr;
     size_t lokey_cap = 0;
+    int lokey_parity = 0;                    // array the next run writes
+    bool lokey_clean[2] = {false, false};    // that array holds the key of -inf everywhere
+    int *lokey_cur = nullptr;                // array of the latest run
+    // The half-precision preparation (image, prefix records, tile bases, range flags, centring constants) depends on
+    // database, norms and target LENGTH only: kept for files [hc_begin, hc_end) until the layout is rebuilt.
+    float *d_prefix_h = nullptr;             // per frame: in-tile inclusive sums of (t, t^2, sum s, sum s^2), fp32
+    size_t prefix_h_cap = 0;
+    double *d_tbase_h = nullptr;             // tile bases of those sums
+    size_t tbase_h_cap = 0;
+    int hc_begin = 0, hc_end = 0;
     float *d_thr = nullptr;                  // smallest of the head files' bounds (filter of the tail files)
     size_t thr_cap = 0;
     sgz_candidate *h_pinned = nullptr;       // pinned staging of the first candidate transfer

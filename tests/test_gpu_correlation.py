@@ -175,6 +175,94 @@ def test_screening_f16_is_an_upper_bound(ctx, L, frames):
         assert abs(float(c["sim"]) - float(sims[c["file"]][c["offset"]])) <= 1.2e-7
 
 
+@pytest.mark.parametrize("L,frames", [(8000, 9300), (12498, 13400)])
+def test_screening_f16_bound_at_long_targets(ctx, L, frames):
+    """The fp32 summation part of the bound grows with the target length (an output element passes through
+    numCh * ceil(S2 / 8) matrix instructions): the longest target the matrix-core kernel's LDS takes (12 498
+    frames, 145 s) and one at 8 000 frames.  The data sit close to one level with a ripple of 1e-3, so that the
+    cross terms are sums of many small products of both signs: the regime in which summation error is largest
+    against the result."""
+    ts, nf = 5, 2
+    rng = np.random.default_rng(L)
+    db = synth_db(nf, frames, make_plants(1, L, nf, frames, ts))
+    norms = norms_default()
+    ripple = (rng.standard_normal((frames, NUM_CH)) * 1e-3).astype(np.float32)
+    db[1] = (np.float32(0.4) + ripple) * (norms[:, 1] - norms[:, 0]) + norms[:, 0]  # normalises to 0.4 + ripple
+    tgt = synth_target(ts, L)
+    _, sims, boosts = O.correlation_run(corr_config(ts, L, num_matches=2), tgt, norms, db)
+    _load(ctx, db, norms)
+    ctx.corr_set_target(tgt[ts:ts + L], 0.5, 8.0)
+    assert ctx.screen_f16_available
+    ctx.corr_run_screen_f16(0, nf)
+    for f in range(nf):
+        gs, _ = ctx.corr_read_dense(f)
+        open_ = np.isfinite(sims[f]) & (boosts[f] <= 8.0 * (1 - 1e-4))
+        d = gs.astype(np.float64) - sims[f]
+        assert open_.any() and np.all(d[open_] >= 0.0)
+    import strugatzki_amd as S
+    got = S.search(ctx, S.SearchParams(2, 1, 0, STEP))
+    want, _, _ = O.correlation_run(corr_config(ts, L, num_matches=2), tgt, norms, db, dense=False)
+    assert [(g.file, g.start, g.stop) for g in got] == [(w.file, w.start, w.stop) for w in want]
+
+
+def test_screening_f16_bound_with_values_in_the_subnormal_range(ctx):
+    """Centred values below 6e-5 are subnormal in half precision and round with an absolute, not a relative
+    error: files that sit within 1e-5 .. 1e-4 of their own mean level."""
+    L, ts, nf, frames = 300, 11, 3, 2500
+    rng = np.random.default_rng(5)
+    norms = norms_default()
+    db = synth_db(nf, frames, make_plants(1, L, nf, frames, ts))
+    for f, amp in ((1, 3e-5), (2, 1e-4)):
+        x = np.float32(0.5) + (rng.standard_normal((frames, NUM_CH)) * amp).astype(np.float32)
+        db[f] = x * (norms[:, 1] - norms[:, 0]) + norms[:, 0]
+    tgt = synth_target(ts, L)
+    _, sims, boosts = O.correlation_run(corr_config(ts, L, num_matches=2), tgt, norms, db)
+    _load(ctx, db, norms)
+    ctx.corr_set_target(tgt[ts:ts + L], 0.5, 8.0)
+    ctx.corr_run_screen_f16(0, nf)
+    for f in range(nf):
+        gs, _ = ctx.corr_read_dense(f)
+        open_ = np.isfinite(sims[f]) & (boosts[f] <= 8.0 * (1 - 1e-4))
+        d = gs.astype(np.float64) - sims[f]
+        assert open_.any() and np.all(d[open_] >= 0.0)
+    import strugatzki_amd as S
+    got = S.search(ctx, S.SearchParams(3, 1, 0, STEP))
+    exact = S.search(ctx, S.SearchParams(3, 1, 0, STEP, screen=False))
+    assert [(g.file, g.start, g.stop) for g in got] == [(e.file, e.start, e.stop) for e in exact]
+
+
+def test_new_target_of_the_same_length_reuses_the_half_precision_preparation(ctx):
+    """Image, prefix records and centring constants of the half-precision path depend on database, norms and
+    target length only: a second target of the same length (searched without a new preparation) and a return to
+    the first one give the oracle's lists; changing the norms or the database builds them anew."""
+    import strugatzki_amd as S
+    L, nf, frames = 120, 8, 1500
+    norms = norms_default()
+    db = synth_db(nf, frames, make_plants(3, L, nf, frames, 17))
+    tgt = synth_target(17, 4 * L)
+    _load(ctx, db, norms)
+    for ts in (17, 200, 17):
+        ctx.corr_set_target(tgt[ts:ts + L], 0.5, 8.0)
+        got = S.search(ctx, S.SearchParams(4, 1, 0, STEP))
+        want, _, _ = O.correlation_run(corr_config(ts, L, num_matches=4), tgt, norms, db, dense=False)
+        assert [(g.file, g.start, g.stop) for g in got] == [(w.file, w.start, w.stop) for w in want]
+        assert all(abs(g.sim - w.sim) <= 1.2e-7 for g, w in zip(got, want))
+    # general path: exact head run + half-precision tail run, twice (the tail's preparation is kept, the head's
+    # exact run must not disturb it)
+    for ts in (200, 17):
+        ctx.corr_set_target(tgt[ts:ts + L], 0.5, 8.0)
+        got = S.search(ctx, S.SearchParams(4, 2, 0, STEP))
+        want, _, _ = O.correlation_run(corr_config(ts, L, num_matches=4, num_per_file=2), tgt, norms, db, dense=False)
+        assert [(g.file, g.start, g.stop) for g in got] == [(w.file, w.start, w.stop) for w in want]
+    norms2 = norms.copy()
+    norms2[:, 1] += np.float32(0.25)
+    ctx.set_norms(norms2)
+    ctx.corr_set_target(tgt[17:17 + L], 0.5, 8.0)
+    got = S.search(ctx, S.SearchParams(4, 1, 0, STEP))
+    want, _, _ = O.correlation_run(corr_config(17, L, num_matches=4), tgt, norms2, db, dense=False)
+    assert [(g.file, g.start, g.stop) for g in got] == [(w.file, w.start, w.stop) for w in want]
+
+
 def test_screening_f16_needs_norms(ctx):
     import strugatzki_amd as S
     from strugatzki_amd import _native as N
