@@ -935,16 +935,21 @@ __global__ __launch_bounds__(256) void compact_bounded_kernel(const FileDesc *__
 }
 
 // ---------------------------------------------------------------------------
-// Exact re-evaluation of listed windows, straight from the raw frames with the
-// reference's own two-pass arithmetic (MathUtil.stat then MathUtil.correlate,
-// impl/MathUtil.scala:29-62, 177-196): fp32 normalise, fp64 mean, fp64 sums of
-// (b - mean)^2 and of (a - aMean)(b - bMean).
+// Exact re-evaluation of listed windows, straight from the raw frames: fp32 normalise with the IEEE divide
+// (MathUtil.normalize, impl/MathUtil.scala:132-152), every sum in fp64.  What MathUtil.stat and
+// MathUtil.correlate (impl/MathUtil.scala:29-62, 177-196) compute in two passes over the window --
+// mean, then sum (b - mean)^2 and sum (a - aMean)(b - mean) -- comes from ONE pass over values shifted by a
+// sample of the window itself, m0 = the window's first value of the channel group:
+//     S = sum (b - m0),  Q = sum (b - m0)^2,  X = sum (a - aMean)(b - m0)
+//     mean = m0 + S / n,  sum (b - mean)^2 = Q - S^2 / n,  sum (a - aMean)(b - mean) = X - (S / n) sum (a - aMean)
+// b - m0 is exact in fp64 (a difference of two fp32 values), and because m0 lies inside the window's range the
+// subtraction Q - S^2 / n loses no more than a two-pass evaluation does: a constant window gives exactly 0
+// (the reference's NaN similarity), a nearly constant one its tiny variance to 1e-15 relative.  The window is
+// read once instead of twice.
 //
 // A window is cut into `slices` runs of frames; one 256-thread workgroup takes
 // one (window, slice) pair, so that a short list still fills the GPU:
-//   rescore_sum_kernel    partial sums of the normalised values        -> part[.][0..1]
-//   rescore_cross_kernel  mean from all partial sums (fixed order), then partial
-//                         sums of squares and cross terms              -> part[.][2..5]
+//   rescore_pass_kernel   partial sums S, Q, X of both channel groups   -> part[.][0..5]
 //   rescore_final_kernel  one thread per window: totals in slice order, sim, boost
 // Thread t of the first (256 / numCh) * numCh threads owns channel t % numCh and
 // every (256 / numCh)-th frame of the slice: consecutive threads read consecutive
@@ -980,7 +985,19 @@ struct RescoreGeom {
     int sliceFrames;  // frames per slice (the last one may be shorter)
 };
 
-template <bool kCross>
+// The shift of a window's channel group: its first normalised value (loudness: channel 0, others: channel 1).
+__device__ __forceinline__ void window_shift(const float *__restrict__ first, const float *__restrict__ normTab,
+                                             int normEnabled, double &m0T, double &m0S)
+{
+    float vT = first[0], vS = first[1];
+    if (normEnabled) {
+        vT = (vT - normTab[0]) / normTab[SGZ_MAX_CHANNELS];
+        vS = (vS - normTab[1]) / normTab[SGZ_MAX_CHANNELS + 1];
+    }
+    m0T = (double)vT;
+    m0S = (double)vS;
+}
+
 __global__ __launch_bounds__(kRsThreads) void rescore_pass_kernel(
     const FileDesc *__restrict__ files, const float *__restrict__ tframes /* normalised target [L][numCh] */,
     const float *__restrict__ normTab /* min[64], max - min[64] */, int normEnabled, CorrParams cp, RescoreGeom rg,
@@ -1002,7 +1019,6 @@ __global__ __launch_bounds__(kRsThreads) void rescore_pass_kernel(
     const bool isT = c == 0;
     const float mn = active ? normTab[c] : 0.0f, dv = active ? normTab[SGZ_MAX_CHANNELS + c] : 1.0f;
     const double aMean = isT ? aMeanT : aMeanS;
-    const double nT = (double)L, nS = (double)L * (double)(numCh - 1);
     for (long long w = blockIdx.x; w < work; w += gridDim.x) {
         const long long ci = w / rg.slices;
         const int g = (int)(w - ci * rg.slices);
@@ -1011,16 +1027,10 @@ __global__ __launch_bounds__(kRsThreads) void rescore_pass_kernel(
         const int K = active && i0 < fl ? (fl - i0 + rows - 1) / rows : 0;     // values of this thread
         const sgz_candidate cd = cands[ci];
         const FileDesc fd = files[cd.file];
+        double m0T, m0S;
+        window_shift(fd.raw + (long long)cd.offset * numCh, normTab, normEnabled, m0T, m0S);
+        const double m0 = isT ? m0T : m0S;
         const float *raw = fd.raw + ((long long)cd.offset + f0) * numCh + tid;
-        double bMean = 0.0;
-        if (kCross) {
-            double sT = 0.0, sS = 0.0;
-            for (int k = 0; k < rg.slices; k++) {  // slice order: the same total in every workgroup
-                sT += part[(ci * rg.slices + k) * kRsParts + 0];
-                sS += part[(ci * rg.slices + k) * kRsParts + 1];
-            }
-            bMean = isT ? sT / nT : sS / nS;
-        }
         const float *tn = tframes + (long long)f0 * numCh + tid;
         double s = 0.0, q = 0.0, x = 0.0;
         // batches of U loads in flight; the last batch repeats the thread's final value and skips it in the
@@ -1031,40 +1041,32 @@ __global__ __launch_bounds__(kRsThreads) void rescore_pass_kernel(
             for (int u = 0; u < U; u++) {
                 const int kk = min(k + u, K - 1);
                 v[u] = raw[kk * stride];
-                if (kCross) af[u] = tn[kk * stride];
+                af[u] = tn[kk * stride];
             }
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 if (normEnabled) v[u] = (v[u] - mn) / dv;
                 const bool live = k + u < K;
-                if (kCross) {
-                    const double d = live ? (double)v[u] - bMean : 0.0;
-                    q += d * d;
-                    x += ((double)af[u] - aMean) * d;
-                } else {
-                    s += live ? (double)v[u] : 0.0;
-                }
+                const double d = live ? (double)v[u] - m0 : 0.0;
+                s += d;
+                q += d * d;
+                x += ((double)af[u] - aMean) * d;
             }
         }
         double *out = part + w * kRsParts;
-        if (kCross) {
-            const double qT = block_sum_256(isT ? q : 0.0, scratch);
-            const double qS = block_sum_256(isT ? 0.0 : q, scratch);
-            const double xT = block_sum_256(isT ? x : 0.0, scratch);
-            const double xS = block_sum_256(isT ? 0.0 : x, scratch);
-            if (tid == 0) {
-                out[2] = qT;
-                out[3] = qS;
-                out[4] = xT;
-                out[5] = xS;
-            }
-        } else {
-            const double sT = block_sum_256(isT ? s : 0.0, scratch);
-            const double sS = block_sum_256(isT ? 0.0 : s, scratch);
-            if (tid == 0) {
-                out[0] = sT;
-                out[1] = sS;
-            }
+        const double sT = block_sum_256(isT ? s : 0.0, scratch);
+        const double sS = block_sum_256(isT ? 0.0 : s, scratch);
+        const double qT = block_sum_256(isT ? q : 0.0, scratch);
+        const double qS = block_sum_256(isT ? 0.0 : q, scratch);
+        const double xT = block_sum_256(isT ? x : 0.0, scratch);
+        const double xS = block_sum_256(isT ? 0.0 : x, scratch);
+        if (tid == 0) {
+            out[0] = sT;
+            out[1] = sS;
+            out[2] = qT;
+            out[3] = qS;
+            out[4] = xT;
+            out[5] = xS;
         }
     }
 }
@@ -1080,7 +1082,9 @@ struct HostReport {
     unsigned long long seq;         // value the host waits for
 };
 
-__global__ __launch_bounds__(256) void rescore_final_kernel(CorrParams cp, RescoreGeom rg,
+__global__ __launch_bounds__(256) void rescore_final_kernel(const FileDesc *__restrict__ files,
+                                                            const float *__restrict__ normTab, int normEnabled,
+                                                            CorrParams cp, RescoreGeom rg,
                                                             sgz_candidate *__restrict__ cands,
                                                             const unsigned long long *__restrict__ count,
                                                             long long capacity, int truncatedOk,
@@ -1094,18 +1098,28 @@ __global__ __launch_bounds__(256) void rescore_final_kernel(CorrParams cp, Resco
         for (int k = 0; k < rg.slices; k++)
 #pragma unroll
             for (int j = 0; j < kRsParts; j++) t[j] += part[(ci * rg.slices + k) * kRsParts + j];
-        const double bMeanT = t[0] / nT;
-        const float avgF = (float)bMeanT;
+        sgz_candidate c = cands[ci];
+        double m0T, m0S;
+        window_shift(files[c.file].raw + (long long)c.offset * cp.numCh, normTab, normEnabled, m0T, m0S);
+        const double dT = t[0] / nT, dS = t[1] / nS;  // mean - m0
+        const float avgF = (float)(m0T + dT);
         const double lnAvgB = log((double)avgF);
         const float boost = (float)exp((cp.lnAvgIn - lnAvgB) / 0.6);
         float sim = 0.0f;
         if (boost <= cp.maxBoost) {
             float temporal = 0.0f, spectral = 0.0f;
-            if (cp.w > 0.0f) temporal = (float)(t[4] / (cp.aStdT * sqrt(t[2] / nT) * nT));
-            if (cp.w < 1.0f) spectral = (float)(t[5] / (cp.aStdS * sqrt(t[3] / nS) * nS));
+            if (cp.w > 0.0f) {
+                double var = t[2] / nT - dT * dT;
+                if (var < 0.0) var = 0.0;  // rounding of an (almost) constant window; NaN stays NaN
+                temporal = (float)((t[4] - dT * cp.sumAT) / (cp.aStdT * sqrt(var) * nT));
+            }
+            if (cp.w < 1.0f) {
+                double var = t[3] / nS - dS * dS;
+                if (var < 0.0) var = 0.0;
+                spectral = (float)((t[5] - dS * cp.sumAS) / (cp.aStdS * sqrt(var) * nS));
+            }
             sim = temporal * cp.w + spectral * (1.0f - cp.w);
         }
-        sgz_candidate c = cands[ci];
         c.sim = sim;
         c.boost = boost;
         cands[ci] = c;
@@ -1938,17 +1952,13 @@ static int rescore_device_impl(sgz_context *ctx, sgz_candidate *device_cands, in
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
     const int grid = (int)std::min<long long>((long long)capacity * rg.slices, 8ll * cus);
     const float *tframes = ctx->d_tnorm + perWindow;
-    hipLaunchKernelGGL(rescore_pass_kernel<false>, dim3(grid), dim3(kRsThreads), 0, ctx->stream, ctx->d_files, tframes,
-                       normtab, ctx->norm.enabled, ctx->cp, rg, ctx->aMeanT, ctx->aMeanS, device_cands, device_count,
-                       (long long)capacity, (int)truncated_ok, part);
-    SGZ_HIP(ctx, hipGetLastError());
-    hipLaunchKernelGGL(rescore_pass_kernel<true>, dim3(grid), dim3(kRsThreads), 0, ctx->stream, ctx->d_files, tframes,
+    hipLaunchKernelGGL(rescore_pass_kernel, dim3(grid), dim3(kRsThreads), 0, ctx->stream, ctx->d_files, tframes,
                        normtab, ctx->norm.enabled, ctx->cp, rg, ctx->aMeanT, ctx->aMeanS, device_cands, device_count,
                        (long long)capacity, (int)truncated_ok, part);
     SGZ_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(rescore_final_kernel, dim3((int)std::min<int64_t>((capacity + 255) / 256, 64)), dim3(256), 0,
-                       ctx->stream, ctx->cp, rg, device_cands, device_count, (long long)capacity, (int)truncated_ok,
-                       part, hr);
+                       ctx->stream, ctx->d_files, normtab, ctx->norm.enabled, ctx->cp, rg, device_cands, device_count,
+                       (long long)capacity, (int)truncated_ok, part, hr);
     SGZ_HIP(ctx, hipGetLastError());
     return SGZ_OK;
 }

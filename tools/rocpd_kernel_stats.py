@@ -1,0 +1,24 @@
+"""Per-kernel time summary (calls, total, average, min, max in microseconds) from a rocprofv3 result database
+(rocpd sqlite, the default output of `rocprofv3 --kernel-trace --stats`), written as CSV.
+usage: rocpd_kernel_stats.py RESULTS.db [OUT.csv]"""
+import csv
+import sqlite3
+import sys
+
+
+def main() -> int:
+    db = sqlite3.connect(sys.argv[1])
+    rows = db.execute(
+        "select name, count(*), sum(end - start), avg(end - start), min(end - start), max(end - start) "
+        "from kernels group by name order by 3 desc").fetchall()
+    total = sum(r[2] for r in rows) or 1
+    out = csv.writer(open(sys.argv[2], "w", newline="") if len(sys.argv) > 2 else sys.stdout)
+    out.writerow(["kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "percent"])
+    for name, n, tot, avg, mn, mx in rows:
+        out.writerow([name.split("(")[0][:90], n, f"{tot / 1e3:.1f}", f"{avg / 1e3:.2f}", f"{mn / 1e3:.2f}", f"{mx / 1e3:.2f}",
+                      f"{100.0 * tot / total:.2f}"])
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
