@@ -118,6 +118,9 @@ SGZ_API int64_t sgz_db_file_frames(const sgz_context *ctx, int file);
 /* Copies the raw frames of a database file back to the host. */
 SGZ_API int sgz_db_read_file(sgz_context *ctx, int file, float *frames_out);
 
+/* Copies `count` raw frames of a database file, starting at frame `first`, back to the host. */
+SGZ_API int sgz_db_read_frames(sgz_context *ctx, int file, int64_t first, int64_t count, float *frames_out);
+
 /* Per-channel (min, max) pairs, norms[2*ch], norms[2*ch+1]; NULL switches
  * normalisation off.  Replaces the feat_norms.aif read of
  * impl/FeatureCorrelationImpl.scala:61-71 and MathUtil.normalize
@@ -139,6 +142,34 @@ SGZ_API int sgz_corr_set_target(sgz_context *ctx, const float *frames, int num_f
  * as the reference does over the file's frames followed by what earlier files of
  * this context left in the L-frame ring (:154, :190-195); an empty file has 0. */
 SGZ_API int64_t sgz_corr_num_windows(const sgz_context *ctx, int file);
+
+/* What the reference's one ring of L = target_frames frames (impl/FeatureCorrelationImpl.scala:154) holds when the
+ * loop reaches a file with fewer than L frames: such a file overwrites the first positions only and is scored
+ * once over its own frames followed by whatever earlier files left behind (:190-195).  For files of the given
+ * frame counts, visited in this order, the function lists where the frames behind each short file's own come
+ * from: run = `count` ring positions of file `file` starting at position `dest`, holding frames `src_frame` ..
+ * of file `src_file` (-1: never written, i.e. the zeros of the fresh buffer).  Pure host arithmetic.  Returns the
+ * number of runs, also when it exceeds `capacity` (then only the first `capacity` are written).  A database
+ * that is spread over several contexts calls it with the frame counts of ALL files in global order and hands
+ * each short file's frames to the context that holds it (sgz_corr_set_ring_image), so that every context
+ * scores the file as a single loop over all files would. */
+typedef struct sgz_ring_run {
+    int32_t file;
+    int32_t dest;
+    int32_t src_file;
+    int32_t count;
+    int64_t src_frame;
+} sgz_ring_run;
+SGZ_API int64_t sgz_corr_ring_runs(const int64_t *num_frames, int num_files, int target_frames, sgz_ring_run *out,
+                                   int64_t capacity);
+/* Ring contents for database file `file` of this context, which has fewer frames than the target: `frames`
+ * holds the raw frames of ring positions [own frames, L), num_frames = L - own frames of them.  Replaces what
+ * the context would derive from its own earlier files; NULL removes it.  Forgotten by sgz_db_reset.  A run
+ * whose target length does not fit fails with SGZ_E_STATE. */
+SGZ_API int sgz_corr_set_ring_image(sgz_context *ctx, int file, const float *frames, int num_frames);
+/* One raw frame (num_channels values) that normalises to exactly 0 under the context's norms: what a ring position
+ * nobody has written yet holds. */
+SGZ_API int sgz_norm_zero_frame(const sgz_context *ctx, float *frame_out);
 
 /* The sliding passes that follow stop `frames` frames before the end of every
  * database file: what the punch-in pass of a search with punch-out does with
@@ -319,6 +350,21 @@ SGZ_API int sgz_sel_feed_gathered(sgz_selector *sel, const sgz_candidate *blocks
 SGZ_API int sgz_corr_search(sgz_context *ctx, int target_frames, int num_matches, int num_per_file,
                             int64_t min_spacing, int step_size, int screen_mode, int over_bounds, int64_t capacity,
                             float margin, sgz_match *matches_out, int out_capacity, int *count_out);
+
+/* sgz_corr_search over a database that is spread over several contexts, one per GPU of the node (the loop over
+ * all files of impl/FeatureCorrelationImpl.scala:152-246, cut by file; one host thread drives each context).
+ * Every context holds its own files, has the same norms and the same target set; global_ids[c][i] = position of
+ * context c's file i in the iteration order over all files (ascending in i; all contexts together hold
+ * 0 .. num_files_total - 1 once each).  Files shorter than the target are first given the ring contents the single
+ * loop would show them (sgz_corr_ring_runs, frames fetched from the contexts that hold them).  numPerFile = 1 with
+ * half-precision screening available: every context finds the exact maxima of its files, the host merges and
+ * replays; otherwise, and whenever that route cannot decide: exact kernel everywhere, dense replay of the first
+ * numMatches files, threshold compaction of the rest.  matches_out: file = global index.  The result equals that
+ * of one context holding all files in global order. */
+SGZ_API int sgz_corr_search_multi(sgz_context *const *ctxs, int num_ctx, const int32_t *const *global_ids,
+                                  int num_files_total, int target_frames, int num_matches, int num_per_file,
+                                  int64_t min_spacing, int step_size, int64_t capacity, sgz_match *matches_out,
+                                  int out_capacity, int *count_out);
 
 /* Feeds the exactly re-scored candidates of sgz_corr_compact_bounded (sorted by
  * (file, offset), files 0 .. num_files-1, the first head_files of them head

@@ -54,6 +54,9 @@ class Plant(C.Structure):
     ]
 
 
+RING_RUN_DTYPE = np.dtype([("file", np.int32), ("dest", np.int32), ("src_file", np.int32), ("count", np.int32),
+                           ("src_frame", np.int64)])
+
 CANDIDATE_DTYPE = np.dtype(
     [("file", np.int32), ("offset", np.int32), ("sim", np.float32), ("boost", np.float32)]
 )
@@ -75,6 +78,12 @@ SIGNATURES = {
     "sgz_db_num_files": (C.c_int, [_vp]),
     "sgz_db_file_frames": (C.c_int64, [_vp, C.c_int]),
     "sgz_db_read_file": (C.c_int, [_vp, C.c_int, _vp]),
+    "sgz_db_read_frames": (C.c_int, [_vp, C.c_int, C.c_int64, C.c_int64, _vp]),
+    "sgz_corr_ring_runs": (C.c_int64, [_vp, C.c_int, C.c_int, _vp, C.c_int64]),
+    "sgz_corr_set_ring_image": (C.c_int, [_vp, C.c_int, _vp, C.c_int]),
+    "sgz_norm_zero_frame": (C.c_int, [_vp, _vp]),
+    "sgz_corr_search_multi": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int,
+                                        C.c_int64, _vp, C.c_int, _vp]),
     "sgz_set_norms": (C.c_int, [_vp, _vp]),
     "sgz_corr_set_target": (C.c_int, [_vp, _vp, C.c_int, C.c_float, C.c_float]),
     "sgz_corr_num_windows": (C.c_int64, [_vp, C.c_int]),

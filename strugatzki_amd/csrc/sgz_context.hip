@@ -67,6 +67,10 @@ void sgz_destroy(sgz_context *ctx)
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+    for (auto &slot : ctx->pin_pool) {
+        (void)hipStreamDestroy(slot.stream);
+        (void)hipHostFree(slot.pin);
+    }
     for (float *p : ctx->stale_images) (void)hipFree(p);
     for (auto &r : ctx->runs) (void)hipEventDestroy(r.done);
     for (auto &e : ctx->event_pool) (void)hipEventDestroy(e);
@@ -132,7 +136,9 @@ int sgz_synchronize(sgz_context *ctx)
 
 // Large transfers between pageable host memory and the device go through several pinned staging buffers, one
 // thread and stream each: a single pageable copy is bound by one core's page faults and memcpy (about 9 GB/s to
-// the host, 27 GB/s from it), well below the link.  Synchronous; work queued on ctx->stream is waited for first.
+// the host, 27 GB/s from it), well below the link.  The buffers and streams are made on first use and kept with
+// the context (allocating 256 MB of pinned memory costs more than the copy it serves).  Synchronous; work queued
+// on ctx->stream is waited for first.
 int sgz::copy_large(sgz_context *ctx, void *dst, const void *src, size_t bytes, bool to_host)
 {
     constexpr size_t kChunk = (size_t)32 << 20;
@@ -143,33 +149,40 @@ int sgz::copy_large(sgz_context *ctx, void *dst, const void *src, size_t bytes, 
         return SGZ_OK;
     }
     SGZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->pin_pool.empty()) {
+        for (int t = 0; t < kThreads; t++) {
+            sgz_context::PinSlot slot;
+            if (hipHostMalloc(&slot.pin, kChunk, hipHostMallocDefault) != hipSuccess ||
+                hipStreamCreateWithFlags(&slot.stream, hipStreamNonBlocking) != hipSuccess) {
+                if (slot.pin) (void)hipHostFree(slot.pin);
+                break;
+            }
+            ctx->pin_pool.push_back(slot);
+        }
+        if (ctx->pin_pool.empty()) return ctx->fail(SGZ_E_HIP, "no pinned staging memory for a large copy");
+    }
     const size_t chunks = (bytes + kChunk - 1) / kChunk;
     std::atomic<size_t> next{0};
     std::atomic<int> failed{0};
-    auto worker = [&]() {
-        void *pin = nullptr;
-        hipStream_t st = nullptr;
-        if (hipSetDevice(ctx->device) != hipSuccess || hipHostMalloc(&pin, kChunk, hipHostMallocDefault) != hipSuccess ||
-            hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
+    auto worker = [&](sgz_context::PinSlot slot) {
+        if (hipSetDevice(ctx->device) != hipSuccess) {
             failed = 1;
-        } else {
-            for (size_t c = next++; c < chunks && !failed; c = next++) {
-                const size_t off = c * kChunk, len = std::min(kChunk, bytes - off);
-                if (!to_host) std::memcpy(pin, (const char *)src + off, len);
-                const hipError_t e = to_host ? hipMemcpyAsync(pin, (const char *)src + off, len, hipMemcpyDeviceToHost, st)
-                                             : hipMemcpyAsync((char *)dst + off, pin, len, hipMemcpyHostToDevice, st);
-                if (e != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
-                    failed = 1;
-                    break;
-                }
-                if (to_host) std::memcpy((char *)dst + off, pin, len);
-            }
+            return;
         }
-        if (st) (void)hipStreamDestroy(st);
-        if (pin) (void)hipHostFree(pin);
+        for (size_t c = next++; c < chunks && !failed; c = next++) {
+            const size_t off = c * kChunk, len = std::min(kChunk, bytes - off);
+            if (!to_host) std::memcpy(slot.pin, (const char *)src + off, len);
+            const hipError_t e = to_host ? hipMemcpyAsync(slot.pin, (const char *)src + off, len, hipMemcpyDeviceToHost, slot.stream)
+                                         : hipMemcpyAsync((char *)dst + off, slot.pin, len, hipMemcpyHostToDevice, slot.stream);
+            if (e != hipSuccess || hipStreamSynchronize(slot.stream) != hipSuccess) {
+                failed = 1;
+                break;
+            }
+            if (to_host) std::memcpy((char *)dst + off, slot.pin, len);
+        }
     };
     std::vector<std::thread> pool;
-    for (int t = 0; t < kThreads; t++) pool.emplace_back(worker);
+    for (const auto &slot : ctx->pin_pool) pool.emplace_back(worker, slot);
     for (auto &t : pool) t.join();
     if (failed) return ctx->fail(SGZ_E_HIP, "large copy between host and device failed");
     return SGZ_OK;

@@ -1195,53 +1195,54 @@ int build_layout(sgz_context *ctx)
     while ((1ll << ctx->cp.prepTileShift) < prepTileFrames) ctx->cp.prepTileShift++;
     // The reference keeps one ring of L frames across all files (impl/FeatureCorrelationImpl.scala:154): a file
     // with fewer than L frames overwrites the first positions only and is scored once, over its own frames
-    // followed by whatever earlier files left in the rest of the ring (:190-195).  ring[p] = which frame of which
-    // file position p holds (file -1: never written, 0 after normalisation); such a file is given a private
-    // L-frame image assembled from those sources.
-    struct RingSrc {
-        int file;
-        long long frame;
-    };
-    std::vector<RingSrc> ring((size_t)L, RingSrc{-1, 0});
+    // followed by whatever earlier files left in the rest of the ring (:190-195).  Such a file is given a private
+    // L-frame image: its own frames, then either what the caller supplied (sgz_corr_set_ring_image: the
+    // database is spread over several contexts) or what this context's earlier files leave behind
+    // (sgz_corr_ring_runs over its own sequence of files).
     for (float *p : ctx->stale_images) SGZ_HIP(ctx, hipFree(p));
     ctx->stale_images.clear();
+    std::vector<long long> passFrames((size_t)nf);
+    // a pass that stops tail_trim frames before the end of every file (the punch-in pass of a search with
+    // punch-out, :182-185) neither scores nor leaves in the ring what lies behind that point
+    for (int f = 0; f < nf; f++) passFrames[(size_t)f] = std::max<long long>(ctx->files[f].frames - ctx->tail_trim, 0);
+    const std::vector<sgz_ring_run> runs = ring_runs(passFrames.data(), nf, L);
+    size_t runPos = 0;
+    const size_t rowBytes = sizeof(float) * (size_t)ctx->numCh;
     for (int f = 0; f < nf; f++) {
         FileDesc &fd = ctx->h_files[f];
         fd.raw = ctx->files[f].d_raw;
-        // a pass that stops tail_trim frames before the end of every file (the punch-in pass of a search with
-        // punch-out, :182-185) neither scores nor leaves in the ring what lies behind that point
-        fd.frames = std::max<long long>(ctx->files[f].frames - ctx->tail_trim, 0);
+        fd.frames = passFrames[(size_t)f];
         const long long own = fd.frames;
         if (own > 0 && own < L) {
-            const size_t rowBytes = sizeof(float) * (size_t)ctx->numCh;
             float *img = nullptr;
             SGZ_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&img), rowBytes * (size_t)L));
             ctx->stale_images.push_back(img);
             SGZ_HIP(ctx, hipMemcpyAsync(img, fd.raw, rowBytes * (size_t)own, hipMemcpyDeviceToDevice, ctx->stream));
-            for (long long p = own; p < L;) {
-                const RingSrc src = ring[(size_t)p];
-                long long q = p + 1;
-                while (q < L && ring[(size_t)q].file == src.file &&
-                       (src.file < 0 || ring[(size_t)q].frame == src.frame + (q - p)))
-                    q++;
-                if (src.file < 0) {  // raw values that normalise to exactly 0
-                    std::vector<float> fill((size_t)(q - p) * ctx->numCh);
+            const auto given = ctx->ring_images.find(f);
+            if (given != ctx->ring_images.end()) {
+                if ((long long)given->second.size() != (L - own) * ctx->numCh)
+                    return ctx->fail(SGZ_E_STATE, "the ring image set for file " + std::to_string(f) +
+                                                      " does not fit the target length");
+                SGZ_HIP(ctx, hipMemcpy(img + own * ctx->numCh, given->second.data(), rowBytes * (size_t)(L - own),
+                                       hipMemcpyHostToDevice));
+            }
+            for (; runPos < runs.size() && runs[runPos].file == f; runPos++) {
+                if (given != ctx->ring_images.end()) continue;
+                const sgz_ring_run &r = runs[runPos];
+                if (r.src_file < 0) {  // never written: raw values that normalise to exactly 0
+                    std::vector<float> fill((size_t)r.count * ctx->numCh);
                     for (size_t k = 0; k < fill.size(); k++)
                         fill[k] = ctx->norm.enabled ? ctx->norm.mn[k % (size_t)ctx->numCh] : 0.0f;
-                    SGZ_HIP(ctx, hipMemcpy(img + p * ctx->numCh, fill.data(), sizeof(float) * fill.size(),
+                    SGZ_HIP(ctx, hipMemcpy(img + (long long)r.dest * ctx->numCh, fill.data(), sizeof(float) * fill.size(),
                                            hipMemcpyHostToDevice));
                 } else {
-                    SGZ_HIP(ctx, hipMemcpyAsync(img + p * ctx->numCh,
-                                                ctx->files[(size_t)src.file].d_raw + src.frame * ctx->numCh,
-                                                rowBytes * (size_t)(q - p), hipMemcpyDeviceToDevice, ctx->stream));
+                    SGZ_HIP(ctx, hipMemcpyAsync(img + (long long)r.dest * ctx->numCh,
+                                                ctx->files[(size_t)r.src_file].d_raw + r.src_frame * ctx->numCh,
+                                                rowBytes * (size_t)r.count, hipMemcpyDeviceToDevice, ctx->stream));
                 }
-                p = q;
             }
             fd.raw = img;
             fd.frames = L;
-            for (long long p = 0; p < own; p++) ring[(size_t)p] = RingSrc{f, p};
-        } else if (own >= L) {
-            for (long long p = 0; p < L; p++) ring[(size_t)p] = RingSrc{f, ((own - 1 - p) / L) * L + p};
         }
         fd.num_windows = fd.frames >= L ? fd.frames - L + 1 : 0;
         const long long ntiles = (fd.num_windows + kTileW - 1) / kTileW;
@@ -1365,6 +1366,7 @@ int sgz_db_reset(sgz_context *ctx, int num_channels)
     for (auto &f : ctx->files)
         if (f.owned && f.d_raw) SGZ_HIP(ctx, hipFree(f.d_raw));
     ctx->files.clear();
+    ctx->ring_images.clear();
     ctx->numCh = num_channels;
     ctx->layout_dirty = true;
     ctx->have_target = false;
@@ -1471,6 +1473,41 @@ int sgz_db_read_file(sgz_context *ctx, int file, float *frames_out)
     if (f.frames)
         SGZ_HIP(ctx, hipMemcpy(frames_out, f.d_raw, sizeof(float) * (size_t)f.frames * ctx->numCh,
                                hipMemcpyDeviceToHost));
+    return SGZ_OK;
+}
+
+int sgz_db_read_frames(sgz_context *ctx, int file, int64_t first, int64_t count, float *frames_out)
+{
+    if (!ctx) return SGZ_E_ARG;
+    if (file < 0 || file >= (int)ctx->files.size()) return ctx->fail(SGZ_E_ARG, "bad file index");
+    const DbFile &f = ctx->files[file];
+    if (first < 0 || count < 0 || first + count > f.frames || (count > 0 && !frames_out))
+        return ctx->fail(SGZ_E_ARG, "frames outside the file / no buffer");
+    SGZ_HIP(ctx, hipSetDevice(ctx->device));
+    SGZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (count)
+        SGZ_HIP(ctx, hipMemcpy(frames_out, f.d_raw + first * ctx->numCh, sizeof(float) * (size_t)count * ctx->numCh,
+                               hipMemcpyDeviceToHost));
+    return SGZ_OK;
+}
+
+int sgz_corr_set_ring_image(sgz_context *ctx, int file, const float *frames, int num_frames)
+{
+    if (!ctx) return SGZ_E_ARG;
+    if (file < 0 || file >= (int)ctx->files.size()) return ctx->fail(SGZ_E_ARG, "bad file index");
+    if (num_frames < 0 || (num_frames > 0 && !frames)) return ctx->fail(SGZ_E_ARG, "bad ring image");
+    if (!frames)
+        ctx->ring_images.erase(file);
+    else
+        ctx->ring_images[file].assign(frames, frames + (size_t)num_frames * ctx->numCh);
+    ctx->layout_dirty = true;
+    return SGZ_OK;
+}
+
+int sgz_norm_zero_frame(const sgz_context *ctx, float *frame_out)
+{
+    if (!ctx || !frame_out || ctx->numCh == 0) return SGZ_E_ARG;
+    for (int c = 0; c < ctx->numCh; c++) frame_out[c] = ctx->norm.enabled ? ctx->norm.mn[c] : 0.0f;
     return SGZ_OK;
 }
 

@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "sgz_internal.hpp"
@@ -190,6 +191,274 @@ __global__ __launch_bounds__(64 * kMaxFramesPerBlock) void extract_kernel(const 
     }
 }
 
+// ---------------------------------------------------------------------------
+// extract1024_kernel: the same computation for fftSize 1024 (the reference's default), restructured for
+// instruction count -- the general kernel above spends about 3 000 wave instructions per frame, most of them
+// in nine radix-2 stages that each go through LDS and in the serial per-band weight loops.
+//   * FFT of the 512 packed complex points: three radix-8 passes (Stockham autosort).  A lane keeps 8 points in
+//     registers; a pass multiplies them by twiddles, runs an 8-point butterfly in registers and hands the
+//     results to the next pass through LDS (two exchanges in all).  The last pass leaves Z[lane + 64 r] in the
+//     lane's registers, in natural order.
+//   * real-FFT unpack and power per bin from Z[k] (register) and Z[512 - k] (LDS).
+//   * band energies by segments between neighbouring band edges: lane s sums, over the bins of segment s, the
+//     rising weights (band s) and the falling weights (band s - 1) in one loop, so a band costs half as many
+//     serial steps and no weight loads.
+//   * DCT: 16 coefficients x 4 quarter sums per sweep over the wave.
+// Values agree with the general kernel to fp32 rounding (different order of summation).
+// ---------------------------------------------------------------------------
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// Lane s <= 42 walks segment s = the bins in [e_s, e_{s+1}], or the first part of it: the 21 longest segments are
+// cut in two and lanes 43 .. 63 take the second parts, so that the longest walk is half as long.
+struct SegTable {
+    int b0[64], cnt[64];   // first bin and number of bins of the lane's run
+    int other[64];         // lanes <= 42: the lane that walks the rest of this segment, or -1
+    float aw[kBands];      // A-weighting at the band centre, dB
+};
+
+__device__ __forceinline__ f2 cmulv(f2 a, f2 b)
+{
+    return f2{fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x)};
+}
+__device__ __forceinline__ f2 mul_neg_i(f2 a) { return f2{a.y, -a.x}; }
+// 8-point DFT, natural order in and out
+__device__ __forceinline__ void fft8(f2 (&v)[8])
+{
+    constexpr float s = 0.70710678118654752f;
+    const f2 a0 = v[0] + v[4], a4 = v[0] - v[4];
+    const f2 a1 = v[1] + v[5], d5 = v[1] - v[5];
+    const f2 a2 = v[2] + v[6], a6 = mul_neg_i(v[2] - v[6]);
+    const f2 a3 = v[3] + v[7], d7 = v[3] - v[7];
+    const f2 a5 = f2{d5.x + d5.y, d5.y - d5.x} * s;    // * e^{-i pi / 4}
+    const f2 a7 = f2{d7.y - d7.x, -d7.x - d7.y} * s;   // * e^{-3 i pi / 4}
+    const f2 b0 = a0 + a2, b2 = a0 - a2;
+    const f2 b1 = a1 + a3, b3 = mul_neg_i(a1 - a3);
+    const f2 b4 = a4 + a6, b6 = a4 - a6;
+    const f2 b5 = a5 + a7, b7 = mul_neg_i(a5 - a7);
+    v[0] = b0 + b1;
+    v[4] = b0 - b1;
+    v[2] = b2 + b3;
+    v[6] = b2 - b3;
+    v[1] = b4 + b5;
+    v[5] = b4 - b5;
+    v[3] = b6 + b7;
+    v[7] = b6 - b7;
+}
+
+constexpr int kFastFft = 1024, kFastM = 512;
+constexpr int kFastWaves = 7;                   // frames per workgroup: 4 workgroups of 39 KB LDS per CU
+// A frame's exchange buffer: 8 points of padding per 64 (index i sits at i + 8 (i / 64)), and one more slot
+// that holds a second copy of Z[0] (see the unpack step).
+constexpr int kFastZ = kFastM + 8 * 8 + 8;
+
+// Tables of the fftSize 1024 kernel, made on the host: laid out so that a lane's eight reads of a pass are one
+// base address plus compile-time offsets.
+struct FastTables {
+    const float2 *tw2;    // [r][kk]   e^{-2 pi i r kk / 64},  r < 8, kk < 8
+    const float2 *tw3;    // [r][lane] e^{-2 pi i r lane / 512}
+    const float2 *twU;    // [k]       e^{-2 pi i k / 1024},   k < 512
+    const float2 *hann2;  // [n]       (hann[2 n], hann[2 n + 1])
+    const float2 *wgt;    // [bin]     (rising weight in its segment, falling weight), 513 bins
+    const float *dct;     // [numCoeffs][kBands]
+};
+
+template <bool kMono>
+__global__ __launch_bounds__(64 * kFastWaves) void extract1024_kernel(const float *__restrict__ pcm, FastTables tb,
+                                                                    SegTable st, ExtractParams p,
+                                                                    float *__restrict__ out)
+{
+    __shared__ f2 tw2[64];
+    __shared__ f2 wgt[kFastM + 8];
+    __shared__ f2 zbuf[kFastWaves][kFastZ];
+    extern __shared__ __attribute__((aligned(16))) float dctL[];  // [numCoeffs][kBands]
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: addresses stay scalar
+    if (threadIdx.x < 64) tw2[threadIdx.x] = f2{tb.tw2[threadIdx.x].x, tb.tw2[threadIdx.x].y};
+    for (int n = threadIdx.x; n <= kFastM; n += 64 * kFastWaves) wgt[n] = f2{tb.wgt[n].x, tb.wgt[n].y};
+    for (int n = threadIdx.x; n < p.numCoeffs * kBands; n += 64 * kFastWaves) dctL[n] = tb.dct[n];
+    f2 *z = zbuf[wv];
+    auto waveSync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    const long long i = (long long)blockIdx.x * kFastWaves + wv;  // output frame
+    const bool live = i < p.numOut;
+    const long long k = i + 1;
+    const long long s0 = (k - p.overlap) * p.step;
+    const bool analysed = live && k >= p.overlap && s0 + kFastFft <= p.numFrames;
+    const int numCh = p.numCoeffs + 1;
+
+    // 1. load + mix down + window: point n = lane + 64 r holds x[2 n] + i x[2 n + 1]
+    f2 v[8];
+    if (analysed) {
+        const float *base = pcm + s0 * (kMono ? 1 : p.numChannels);  // scalar
+        const f2 *hw = reinterpret_cast<const f2 *>(tb.hann2);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int n = lane + 64 * r;
+            f2 x;
+            if (kMono) {
+                x = *reinterpret_cast<const f2 *>(base + 2 * n);
+            } else {
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const float *fr = base + (2 * n + h) * p.numChannels;
+                    float xs;
+                    if (p.channels == 1) xs = fr[0];
+                    else if (p.channels == 2) xs = fr[p.numChannels - 1];
+                    else {
+                        xs = 0.0f;
+                        for (int c = 0; c < p.numChannels; c++) xs += fr[c];
+                    }
+                    x[h] = xs;
+                }
+            }
+            v[r] = x * hw[n];
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 8; r++) v[r] = f2{0.0f, 0.0f};
+    }
+    // the twiddles of the third pass and of the unpack step come straight from memory into registers (requested
+    // now, used much later: the vector memory path is idle otherwise, the LDS is the busiest unit of this kernel)
+    f2 t3[8], tU[8];
+    {
+        const f2 *g3 = reinterpret_cast<const f2 *>(tb.tw3) + lane, *gU = reinterpret_cast<const f2 *>(tb.twU) + lane;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            t3[r] = g3[64 * r];
+            tU[r] = gU[64 * r];
+        }
+    }
+    __syncthreads();  // the tables are complete
+
+    // 2. three radix-8 passes: sub-transform lengths 1 -> 8 -> 64 -> 512.
+    //    First exchange: result r of lane l is point 8 l + r of the next pass, which lane j reads as point
+    //    j + 64 r' = 8 (j / 8 + 8 r') + j % 8.  Stored as [r][l] with a row stride of 68: writes are consecutive
+    //    over the lanes, and the reads (row j % 8, column j / 8 + 8 r') fall on 4 (j % 8) + j / 8 modulo 32,
+    //    distinct within each half of the wave -- no bank conflicts either way.
+    //    Later exchanges, padded positions: lane + 64 r -> lane + 72 r;  64 (lane / 8) + lane % 8 + 8 r -> the
+    //    same + 8 (lane / 8).
+    f2 *zA = z + lane;
+    const f2 *zA2 = z + 68 * (lane & 7) + (lane >> 3);
+    f2 *zB = z + lane;
+    f2 *zC = z + 72 * (lane >> 3) + (lane & 7);
+    fft8(v);
+#pragma unroll
+    for (int r = 0; r < 8; r++) zA[68 * r] = v[r];
+    waveSync();
+#pragma unroll
+    for (int r = 0; r < 8; r++) v[r] = zA2[8 * r];
+    {
+        const f2 *t2 = tw2 + (lane & 7);
+#pragma unroll
+        for (int r = 1; r < 8; r++) v[r] = cmulv(v[r], t2[8 * r]);
+    }
+    fft8(v);
+    waveSync();  // everyone has read the first exchange
+#pragma unroll
+    for (int r = 0; r < 8; r++) zC[8 * r] = v[r];
+    waveSync();
+#pragma unroll
+    for (int r = 0; r < 8; r++) v[r] = zB[72 * r];
+#pragma unroll
+    for (int r = 1; r < 8; r++) v[r] = cmulv(v[r], t3[r]);
+    fft8(v);  // v[r] = Z[lane + 64 r]
+
+    // 3. spectrum of the real signal: X[k] = (Z[k] + conj Z[M-k]) / 2 - i w^k (Z[k] - conj Z[M-k]) / 2; power.
+    //    k = lane + 64 r pairs with M - k = (64 - lane) + 64 (7 - r): register 7 - r of lane 64 - lane, fetched
+    //    across the lanes; lane 0 pairs 64 r with 64 (8 - r), its own register 8 - r (and Z[0] with itself).
+    float pw[8];
+    {
+        const int src = (64 - lane) & 63;
+        f2 zmAll[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++)  // all sixteen fetches first, one wait for the lot
+            zmAll[r] = f2{__shfl(v[7 - r].x, src, 64), __shfl(v[7 - r].y, src, 64)};
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const f2 own = v[r == 0 ? 0 : 8 - r];
+            const f2 zm = lane == 0 ? own : zmAll[r];
+            const f2 zk = v[r];
+            const f2 e = f2{zk.x + zm.x, zk.y - zm.y};
+            const f2 o = f2{zk.x - zm.x, zk.y + zm.y};
+            const f2 t = cmulv(o, tU[r]);
+            const float xr = e.x + t.y, xi = e.y - t.x;
+            pw[r] = fmaf(xr, xr, xi * xi) * (0.25f * p.norm);  // (the two halves of e and o are folded in here)
+        }
+    }
+    const float z0r = __shfl(v[0].x, 0, 64), z0i = __shfl(v[0].y, 0, 64);
+    waveSync();  // all reads of the exchange buffer are done: it now takes the power spectrum
+    float *P = reinterpret_cast<float *>(z);
+#pragma unroll
+    for (int r = 0; r < 8; r++) P[lane + 64 * r] = pw[r];
+    if (lane == 0) P[kFastM] = (z0r - z0i) * (z0r - z0i) * p.norm;  // the Nyquist bin
+    waveSync();
+
+    // 4. band energies: lane s walks the bins of segment s = [e_s, e_{s+1}] once; they rise in band s and fall in
+    //    band s - 1 (weights per bin from the table: a bin that sits exactly on e_s belongs to the segment before
+    //    it and has a falling weight of 0 here)
+    float rise = 0.0f, fall = 0.0f;
+    {
+        const int b0 = st.b0[lane], cnt = st.cnt[lane];
+        const float *Pb = P + b0;
+        const f2 *wb = wgt + b0;
+#pragma unroll 4
+        for (int t = 0; t < cnt; t++) {
+            const float x = Pb[t];
+            const f2 w = wb[t];
+            rise = fmaf(w.x, x, rise);
+            fall = fmaf(w.y, x, fall);
+        }
+        // the rest of a segment that was cut in two (fixed order: first part + second part)
+        const int other = lane <= kBands ? st.other[lane] : -1;
+        const float r2 = __shfl(rise, other < 0 ? lane : other, 64), f2nd = __shfl(fall, other < 0 ? lane : other, 64);
+        if (other >= 0) {
+            rise += r2;
+            fall += f2nd;
+        }
+    }
+    const float fallNext = __shfl_down(fall, 1, 64);
+    float db = 0.0f, sone = 0.0f;
+    if (analysed && lane < kBands) {
+        const float e = rise + fallNext;
+        db = 100.0f + 10.0f * log10f(e + 1e-10f);
+        if (db < 0.0f) db = 0.0f;
+        float phon = db + st.aw[lane];
+        if (phon < 0.0f) phon = 0.0f;
+        sone = exp2f((phon - 40.0f) * 0.1f);
+    }
+    float loud = sone;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) loud += __shfl_xor(loud, off, 64);
+
+    // 5. DCT-II: the dB values go through LDS; lane (c, q) = (lane % 16, lane / 16) sums a quarter of the bands
+    waveSync();
+    if (lane < kBands) P[kFastM + 8 + lane] = db;
+    waveSync();
+    float *o = out + i * numCh;
+    for (int c0 = 0; c0 < p.numCoeffs; c0 += 16) {
+        const int c = c0 + (lane & 15), q = lane >> 4;
+        float part = 0.0f;
+        if (c < p.numCoeffs) {
+            const int j0 = 11 * q, j1 = min(j0 + 11, kBands);
+            for (int j = j0; j < j1; j++) part = fmaf(dctL[c * kBands + j], P[kFastM + 8 + j], part);
+        }
+        part += __shfl_xor(part, 16, 64);
+        part += __shfl_xor(part, 32, 64);
+        if (analysed && lane < 16 && c < p.numCoeffs) o[1 + c] = 0.5f + 0.5f * (part * (1.0f / kBands)) * 0.01f;
+    }
+    if (live) {
+        if (analysed) {
+            if (lane == 0) o[0] = loud * (1.0f / 32.0f);
+        } else if (lane < numCh) {
+            o[lane] = 0.0f;  // no FFT frame has completed yet
+        }
+    }
+}
+
 double melOfHz(double f) { return 2595.0 * std::log10(1.0 + f / 700.0); }
 double hzOfMel(double m) { return 700.0 * (std::pow(10.0, m / 2595.0) - 1.0); }
 double aWeightDb(double f)
@@ -290,6 +559,65 @@ int sgz_extract(sgz_context *ctx, const float *pcm, int64_t num_frames, int num_
         }
     }
 
+    // segments between neighbouring band edges and the other tables of the fftSize 1024 kernel
+    SegTable st;
+    std::vector<float2> fastTab;  // tw2[64], tw3[512], twU[512], hann2[512], wgt[513 (+7)]
+    const bool fast = fft_size == kFastFft && !std::getenv("SGZ_EXTRACT_GENERAL");
+    if (fast) {
+        const double mHi = melOfHz(sample_rate * 0.5);
+        double e[kBands + 2];
+        for (int j = 0; j < kBands + 2; j++) e[j] = hzOfMel(mHi * j / (kBands + 1)) * fft_size / sample_rate;
+        fastTab.assign(64 + 3 * 512 + 520, make_float2(0.0f, 0.0f));
+        float2 *tw2 = fastTab.data(), *tw3 = tw2 + 64, *twU = tw3 + 512, *hann2 = twU + 512, *wgt = hann2 + 512;
+        for (int r = 0; r < 8; r++)
+            for (int kk = 0; kk < 8; kk++) {
+                const double a = -2.0 * M_PI * r * kk / 64.0;
+                tw2[8 * r + kk] = make_float2((float)std::cos(a), (float)std::sin(a));
+            }
+        for (int r = 0; r < 8; r++)
+            for (int l = 0; l < 64; l++) {
+                const double a = -2.0 * M_PI * r * l / 512.0;
+                tw3[64 * r + l] = make_float2((float)std::cos(a), (float)std::sin(a));
+            }
+        for (int k = 0; k < 512; k++) {
+            twU[k] = tw[(size_t)k];
+            hann2[k] = make_float2(hann[(size_t)2 * k], hann[(size_t)2 * k + 1]);
+        }
+        for (int l = 0; l < 64; l++) {
+            st.b0[l] = st.cnt[l] = 0;
+            st.other[l] = -1;
+        }
+        for (int sg = 0; sg <= kBands; sg++) {
+            const float e0 = (float)e[sg], e1 = (float)e[sg + 1];
+            st.b0[sg] = (int)std::ceil(e0);
+            // a bin exactly on e0 is the last bin of the segment before (weight 1 there, none here)
+            if (sg > 0 && (float)st.b0[sg] == e0) st.b0[sg]++;
+            const int b1 = std::min((int)std::floor(e1), M);
+            st.cnt[sg] = std::max(b1 - st.b0[sg] + 1, 0);
+            // the weights of the general kernel's table, bin by bin: rising in band sg, falling in band sg - 1
+            // (none for a bin exactly on e0: that one belongs to the segment before)
+            for (int b = st.b0[sg]; b <= b1; b++) {
+                const float fb = (float)b;
+                const float wr = e1 > e0 ? (fb - e0) / (e1 - e0) : 0.0f;
+                const float wf = (e1 > e0 && fb > e0) ? (e1 - fb) / (e1 - e0) : 0.0f;
+                wgt[b] = make_float2(sg < kBands && wr > 0.0f ? wr : 0.0f, sg > 0 && wf > 0.0f ? wf : 0.0f);
+            }
+        }
+        for (int j = 0; j < kBands; j++) st.aw[j] = bt.aw[j];
+        // the spare lanes 43 .. 63 take the second halves of the longest segments
+        for (int l = kBands + 1; l < 64; l++) {
+            int longest = 0;
+            for (int sg = 1; sg <= kBands; sg++)
+                if (st.other[sg] < 0 && st.cnt[sg] > st.cnt[longest]) longest = sg;
+            if (st.other[longest] >= 0 || st.cnt[longest] < 2) break;
+            const int first = (st.cnt[longest] + 1) / 2;
+            st.b0[l] = st.b0[longest] + first;
+            st.cnt[l] = st.cnt[longest] - first;
+            st.cnt[longest] = first;
+            st.other[longest] = l;
+        }
+    }
+
     DevBuf dPcm, dTw, dHann, dDct, dOut, dBandW;
     const size_t pcmBytes = sizeof(float) * (size_t)num_frames * num_channels;
     const size_t outBytes = sizeof(float) * (size_t)nOut * (num_coeffs + 1);
@@ -300,8 +628,11 @@ int sgz_extract(sgz_context *ctx, const float *pcm, int64_t num_frames, int num_
     SGZ_HIP(ctx, hipMalloc(&dOut.p, outBytes));
     SGZ_HIP(ctx, hipMalloc(&dBandW.p, sizeof(float) * bandW.size()));
     SGZ_HIP(ctx, hipMemcpyAsync(dBandW.p, bandW.data(), sizeof(float) * bandW.size(), hipMemcpyHostToDevice, ctx->stream));
-    // (one pageable copy: 27 GB/s; staging it through parallel pinned buffers was slower at this size)
-    SGZ_HIP(ctx, hipMemcpyAsync(dPcm.p, pcm, pcmBytes, hipMemcpyHostToDevice, ctx->stream));
+    // (a single pageable copy runs at 27 GB/s; long inputs go through the context's parallel pinned staging)
+    {
+        const int crc = sgz::copy_large(ctx, dPcm.p, pcm, pcmBytes, false);
+        if (crc) return crc;
+    }
     SGZ_HIP(ctx, hipMemcpyAsync(dTw.p, tw.data(), sizeof(float2) * tw.size(), hipMemcpyHostToDevice, ctx->stream));
     SGZ_HIP(ctx, hipMemcpyAsync(dHann.p, hann.data(), sizeof(float) * hann.size(), hipMemcpyHostToDevice, ctx->stream));
     SGZ_HIP(ctx, hipMemcpyAsync(dDct.p, dct.data(), sizeof(float) * dct.size(), hipMemcpyHostToDevice, ctx->stream));
@@ -319,10 +650,31 @@ int sgz_extract(sgz_context *ctx, const float *pcm, int64_t num_frames, int num_
     SGZ_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(extract_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const unsigned grid = (unsigned)((nOut + kFramesPerBlock - 1) / kFramesPerBlock);
+    DevBuf dFast;
+    FastTables ft{};
+    if (fast) {
+        SGZ_HIP(ctx, hipMalloc(&dFast.p, sizeof(float2) * fastTab.size()));
+        SGZ_HIP(ctx, hipMemcpyAsync(dFast.p, fastTab.data(), sizeof(float2) * fastTab.size(), hipMemcpyHostToDevice,
+                                    ctx->stream));
+        ft.tw2 = (const float2 *)dFast.p;
+        ft.tw3 = ft.tw2 + 64;
+        ft.twU = ft.tw3 + 512;
+        ft.hann2 = ft.twU + 512;
+        ft.wgt = ft.hann2 + 512;
+        ft.dct = (const float *)dDct.p;
+    }
     SGZ_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    hipLaunchKernelGGL(extract_kernel, dim3(grid), dim3(64 * kFramesPerBlock), lds, ctx->stream,
-                       (const float *)dPcm.p, (const float2 *)dTw.p, (const float *)dHann.p, (const float *)dDct.p, (const float *)dBandW.p, bt,
-                       p, (float *)dOut.p);
+    const size_t fastLds = sizeof(float) * (size_t)num_coeffs * kBands;
+    if (fast && num_channels == 1)
+        hipLaunchKernelGGL(extract1024_kernel<true>, dim3((unsigned)((nOut + kFastWaves - 1) / kFastWaves)),
+                           dim3(64 * kFastWaves), fastLds, ctx->stream, (const float *)dPcm.p, ft, st, p, (float *)dOut.p);
+    else if (fast)
+        hipLaunchKernelGGL(extract1024_kernel<false>, dim3((unsigned)((nOut + kFastWaves - 1) / kFastWaves)),
+                           dim3(64 * kFastWaves), fastLds, ctx->stream, (const float *)dPcm.p, ft, st, p, (float *)dOut.p);
+    else
+        hipLaunchKernelGGL(extract_kernel, dim3(grid), dim3(64 * kFramesPerBlock), lds, ctx->stream,
+                           (const float *)dPcm.p, (const float2 *)dTw.p, (const float *)dHann.p, (const float *)dDct.p,
+                           (const float *)dBandW.p, bt, p, (float *)dOut.p);
     SGZ_HIP(ctx, hipGetLastError());
     SGZ_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     ctx->ev_valid = true;

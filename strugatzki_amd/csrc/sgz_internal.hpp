@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <map>
 #include <string>
 #include <utility>
 #include <vector>
@@ -122,6 +123,7 @@ struct sgz_context {
     std::vector<sgz::PrepTile> h_ptiles;
     std::vector<int> ptile_begin;
     std::vector<float *> stale_images;       // L-frame images of files shorter than the target (see build_layout)
+    std::map<int, std::vector<float>> ring_images;  // caller-supplied ring contents behind a short file's own frames
     std::vector<sgz::TileDesc> h_tiles_h;    // tiles of the matrix-core screening kernel
     std::vector<int> tile_h_begin;
     sgz::TileDesc *d_tiles_h = nullptr;
@@ -198,6 +200,11 @@ struct sgz_context {
     std::vector<Run> runs;
     std::vector<hipEvent_t> event_pool;
     hipStream_t copy_stream = nullptr;       // device-to-host result copies
+    struct PinSlot {                         // staging of large copies from / to pageable memory (copy_large)
+        void *pin = nullptr;
+        hipStream_t stream = nullptr;
+    };
+    std::vector<PinSlot> pin_pool;
     hipStream_t screen_stream = nullptr;     // screening runs (overlap with exact runs on `stream`)
 
     // Kernel timing: a ring of event pairs, one pair per run (ev0 / ev1 = the pair of the latest run), so that
@@ -235,6 +242,9 @@ int half_screen_launch(sgz_context *ctx, int tile_begin, int tile_end, hipStream
 
 // sgz_corr.hip: address of the device's scratch array of sgz_corr_rescore_device_noalloc (device must be current)
 int noalloc_scratch_init(sgz_context *ctx);
+
+// sgz_select.cpp: sgz_corr_ring_runs as a vector
+std::vector<sgz_ring_run> ring_runs(const long long *frames, int num_files, int L);
 
 // sgz_context.hip: synchronous copy between pageable host memory and the device, staged in parallel when large
 int copy_large(sgz_context *ctx, void *dst, const void *src, size_t bytes, bool to_host);

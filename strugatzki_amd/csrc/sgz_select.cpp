@@ -19,6 +19,10 @@
 
 #include "strugatzki_amd.h"
 
+namespace sgz {
+std::vector<sgz_ring_run> ring_runs(const long long *frames, int num_files, int L);
+}
+
 namespace {
 
 // Total order of java.lang.Float.compare: -0.0 < +0.0, NaN == NaN > +inf.
@@ -393,3 +397,59 @@ int sgz_segm_select(const float *sims, int64_t n, int af_start, int half_win, in
 }
 
 }  // extern "C"
+
+// The reference keeps one ring of L frames across all files (impl/FeatureCorrelationImpl.scala:154): a file with
+// fewer than L frames overwrites the first positions only (:190-195).  ring[p] = which frame of which file
+// position p holds (file -1: never written).
+extern "C" int64_t sgz_corr_ring_runs(const int64_t *num_frames, int num_files, int target_frames, sgz_ring_run *out,
+                                      int64_t capacity)
+{
+    if (num_files < 0 || target_frames < 1 || (num_files > 0 && !num_frames) || capacity < 0 || (capacity > 0 && !out))
+        return SGZ_E_ARG;
+    const int L = target_frames;
+    struct Src {
+        int file;
+        int64_t frame;
+    };
+    std::vector<Src> ring((size_t)L, Src{-1, 0});
+    // a file of L or more frames rewrites every position: only the last one before a short file matters
+    int pending = -1;
+    auto settle = [&]() {
+        if (pending < 0) return;
+        const int64_t own = num_frames[pending];
+        for (int p = 0; p < L; p++) ring[(size_t)p] = Src{pending, ((own - 1 - p) / L) * L + p};
+        pending = -1;
+    };
+    int64_t n = 0;
+    for (int f = 0; f < num_files; f++) {
+        const int64_t own = num_frames[f];
+        if (own >= L) {
+            pending = f;
+        } else if (own > 0) {
+            settle();
+            for (int64_t p = own; p < L;) {
+                const Src src = ring[(size_t)p];
+                int64_t q = p + 1;
+                while (q < L && ring[(size_t)q].file == src.file && (src.file < 0 || ring[(size_t)q].frame == src.frame + (q - p))) q++;
+                if (n < capacity) out[n] = sgz_ring_run{f, (int32_t)p, src.file, (int32_t)(q - p), src.file < 0 ? 0 : src.frame};
+                n++;
+                p = q;
+            }
+            for (int64_t p = 0; p < own; p++) ring[(size_t)p] = Src{f, p};
+        }
+    }
+    return n;
+}
+
+std::vector<sgz_ring_run> sgz::ring_runs(const long long *frames, int num_files, int L)
+{
+    std::vector<int64_t> fr((size_t)num_files);
+    for (int f = 0; f < num_files; f++) fr[(size_t)f] = frames[f];
+    std::vector<sgz_ring_run> runs;
+    const int64_t n = sgz_corr_ring_runs(fr.data(), num_files, L, nullptr, 0);
+    if (n > 0) {
+        runs.resize((size_t)n);
+        sgz_corr_ring_runs(fr.data(), num_files, L, runs.data(), n);
+    }
+    return runs;
+}

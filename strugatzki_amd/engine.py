@@ -105,6 +105,24 @@ class Context:
         self._check(lib.sgz_db_read_file(self._h, file, N.ptr(out)))
         return out
 
+    def db_read_frames(self, file: int, first: int, count: int) -> np.ndarray:
+        out = np.empty((count, self.num_channels), dtype=np.float32)
+        self._check(lib.sgz_db_read_frames(self._h, file, first, count, N.ptr(out)))
+        return out
+
+    def corr_set_ring_image(self, file: int, frames: np.ndarray | None) -> None:
+        """Ring contents behind the own frames of a file shorter than the target (sgz_corr_set_ring_image)."""
+        if frames is None:
+            self._check(lib.sgz_corr_set_ring_image(self._h, file, None, 0))
+            return
+        a = _as_frames(frames, self.num_channels)
+        self._check(lib.sgz_corr_set_ring_image(self._h, file, N.ptr(a), a.shape[0]))
+
+    def norm_zero_frame(self) -> np.ndarray:
+        out = np.zeros(self.num_channels, dtype=np.float32)
+        self._check(lib.sgz_norm_zero_frame(self._h, N.ptr(out)))
+        return out
+
     def set_norms(self, norms: np.ndarray | None) -> None:
         """norms: [numCh][2] (min, max) or None."""
         if norms is None:
@@ -395,6 +413,38 @@ class Selector:
         arr = (N.Match * max(self.num_matches, 1))()
         n = lib.sgz_sel_result(self._h, arr, self.num_matches)
         return [arr[i] for i in range(n)]
+
+
+def ring_runs(num_frames: Sequence[int], target_frames: int) -> np.ndarray:
+    """Where the ring contents behind the own frames of every file shorter than the target come from, for files
+    of the given frame counts in iteration order (sgz_corr_ring_runs): records of N.RING_RUN_DTYPE."""
+    fr = np.ascontiguousarray(num_frames, dtype=np.int64)
+    n = lib.sgz_corr_ring_runs(N.ptr(fr), len(fr), target_frames, None, 0)
+    if n < 0:
+        raise N.NativeError(n, "sgz_corr_ring_runs")
+    out = np.zeros(max(n, 1), dtype=N.RING_RUN_DTYPE)
+    lib.sgz_corr_ring_runs(N.ptr(fr), len(fr), target_frames, N.ptr(out), n)
+    return out[:n]
+
+
+def search_multi(contexts: Sequence[Context], global_ids: Sequence[Sequence[int]], num_matches: int, num_per_file: int,
+                 min_spacing: int, step_size: int, capacity: int = 1 << 16) -> list[N.Match]:
+    """One search over a database spread over several contexts (one per GPU), from one process
+    (sgz_corr_search_multi).  Every context has the same norms and target set; global_ids[c][i] = position of
+    context c's file i in the iteration order over all files."""
+    n = len(contexts)
+    handles = (C.c_void_p * n)(*[c._h for c in contexts])
+    arrays = [np.ascontiguousarray(g, dtype=np.int32) for g in global_ids]
+    ptrs = (C.c_void_p * n)(*[a.ctypes.data if len(a) else None for a in arrays])
+    total = int(sum(len(a) for a in arrays))
+    out = (N.Match * max(num_matches, 1))()
+    cnt = C.c_int(0)
+    rc = lib.sgz_corr_search_multi(handles, n, ptrs, total, contexts[0].target_frames, num_matches, num_per_file,
+                                   min_spacing, step_size, capacity, out, num_matches, C.byref(cnt))
+    if rc != N.SGZ_OK:
+        msgs = "; ".join(lib.sgz_last_error(c._h).decode() for c in contexts)
+        raise N.NativeError(rc, msgs)
+    return [out[i] for i in range(cnt.value)]
 
 
 def segm_select(sims: np.ndarray, af_start: int, half_win: int, step_size: int, num_breaks: int,

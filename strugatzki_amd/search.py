@@ -216,9 +216,87 @@ def _rank_maps(ctx: Context, local_to_global: Sequence[int], group) -> dict:
         offsets = np.zeros(world + 1, dtype=np.int64)
         offsets[1:] = np.cumsum([len(m) for m in per_rank])
         flat = np.ascontiguousarray(np.concatenate(per_rank) if per_rank else np.zeros(0), dtype=np.int32)
+        # frame counts of every rank's files (for the ring contents of files shorter than the target)
+        fr = torch.zeros((max(width, 1),), dtype=torch.int64, device=dev)
+        fr[: len(local_to_global)] = torch.tensor([ctx.file_frames(i) for i in range(len(local_to_global))],
+                                                  dtype=torch.int64, device=dev)
+        frs = [torch.empty_like(fr) for _ in range(world)]
+        dist.all_gather(frs, fr, group=group)
+        frames = {}
+        owner = {}
+        for r, (m, f) in enumerate(zip(per_rank, frs)):
+            f = f.cpu().numpy()
+            for i, g in enumerate(m):
+                frames.setdefault(int(g), int(f[i]))  # (replicated files: the same everywhere)
+                owner.setdefault(int(g), (r, i))
         cache.clear()
-        cache[key] = dict(per_rank=per_rank, flat=flat, offsets=offsets)
+        cache[key] = dict(per_rank=per_rank, flat=flat, offsets=offsets, frames=frames, owner=owner, ring_for=None)
     return cache[key]
+
+
+def _exchange_ring_images(ctx: Context, local_to_global: Sequence[int], group) -> None:
+    """Files shorter than the target are scored over their own frames followed by what earlier files of the
+    reference's single loop left in its ring (impl/FeatureCorrelationImpl.scala:154, 190-195).  With the files
+    spread over ranks those frames may live elsewhere: every rank works out the same list of source runs
+    (ring_runs over the frame counts of all files in global order), the ranks all-gather the runs' frames
+    (each rank fills in the runs it holds), and every rank hands its short files their ring contents
+    (Context.corr_set_ring_image).  One collective, and only when the database holds such a file; done once per
+    (placement, target length)."""
+    import torch
+    import torch.distributed as dist
+
+    from .engine import ring_runs
+
+    maps = _rank_maps(ctx, local_to_global, group)
+    L = ctx.target_frames
+    if maps["ring_for"] == L:
+        return
+    maps["ring_for"] = L
+    frames = maps["frames"]
+    nfiles = len(frames)
+    if sorted(frames) != list(range(nfiles)):
+        return  # not a dense global numbering: the caller's own affair
+    counts = [frames[g] for g in range(nfiles)]
+    if not any(0 < c < L for c in counts):
+        return
+    runs = ring_runs(counts, L)
+    rank = dist.get_rank(group)
+    world = dist.get_world_size(group)
+    nch = ctx.num_channels
+    total = int(runs["count"].sum())
+    mine = np.zeros((max(total, 1), nch), dtype=np.float32)
+    pos = 0
+    spans = []
+    for r in runs:
+        n = int(r["count"])
+        spans.append((pos, n))
+        src = int(r["src_file"])
+        if src >= 0 and maps["owner"][src][0] == rank:
+            mine[pos:pos + n] = ctx.db_read_frames(maps["owner"][src][1], int(r["src_frame"]), n)
+        pos += n
+    on_gpu = dist.get_backend(group) != "gloo"
+    t = torch.from_numpy(mine)
+    if on_gpu:
+        t = t.to(torch.device("cuda", torch.cuda.current_device()))
+    parts = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(parts, t, group=group)
+    parts = [q.cpu().numpy() for q in parts]
+    zero = ctx.norm_zero_frame()
+    local_of = {int(g): i for i, g in enumerate(local_to_global)}
+    k = 0
+    while k < len(runs):
+        g = int(runs[k]["file"])
+        own = counts[g]
+        img = np.zeros((L - own, nch), dtype=np.float32)
+        while k < len(runs) and int(runs[k]["file"]) == g:
+            r = runs[k]
+            p0, n = spans[k]
+            src = int(r["src_file"])
+            d = int(r["dest"]) - own
+            img[d:d + n] = zero if src < 0 else parts[maps["owner"][src][0]][p0:p0 + n]
+            k += 1
+        if g in local_of:
+            ctx.corr_set_ring_image(local_of[g], img)
 
 
 def _exchange_buffers(ctx: Context, cap: int, world: int, on_gpu: bool):
@@ -371,6 +449,8 @@ def search_sharded(ctx: Context, p: SearchParams, head_global: Sequence[int], ta
     search over bounds for numPerFile = 1."""
     nh, nt = len(head_global), len(tail_global)
     assert ctx.num_files == nh + nt
+    if num_files_total is not None and num_files_total > 0:
+        _exchange_ring_images(ctx, list(head_global) + list(tail_global), group)
     mode = _screen_mode(ctx, p) if p.screen else None
     if (p.screen and p.screen_head and p.num_per_file == 1 and p.num_matches >= 1 and mode == "f16"
             and num_files_total is not None and num_files_total > 0):  # (nothing rank-dependent: a collective follows)

@@ -40,7 +40,9 @@ def fuzz(port: int, rank: int, world: int, backend: str, cases: int, seed: int) 
         for case in range(cases):
             L = int(rng.choice([16, 40, 96, 150]))
             nf = int(rng.integers(1, 11))
-            frames = [int(rng.integers(L, 4 * L + 600)) for _ in range(nf)]
+            # (one case in three holds files shorter than the target: their ring contents come from other ranks)
+            lo = max(1, L // 3) if case % 3 == 2 else L
+            frames = [int(rng.integers(lo, 4 * L + 600)) for _ in range(nf)]
             ts = int(rng.integers(0, 20))
             nm, npf = int(rng.integers(1, 6)), int(rng.choice([1, 1, 2, 3]))
             sp = int(rng.choice([0, 0, 10 * STEP]))

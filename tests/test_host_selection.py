@@ -142,3 +142,47 @@ def test_selector_rejects_bad_arguments():
         Selector(-1, 1, 0, STEP, 10)
     with pytest.raises(ValueError):
         Selector(1, 1, 0, 0, 10)
+
+
+def _ring_by_simulation(counts, L):
+    """The reference's ring, written frame by frame (impl/FeatureCorrelationImpl.scala:186-195, 242-245): the first
+    round of a file reads min(frames, L) frames to position 0, every later frame goes to readOff, which advances
+    modulo L.  Returns, per file shorter than L, what positions [own, L) hold when the file is scored."""
+    ring = [(-1, 0)] * L
+    out = {}
+    for f, n in enumerate(counts):
+        if n <= 0:
+            continue
+        first = min(n, L)
+        for p in range(first):
+            ring[p] = (f, p)
+        if n < L:
+            out[f] = list(ring[n:])
+        read_off, frame = first % L, first
+        while frame < n:
+            ring[read_off] = (f, frame)
+            read_off = (read_off + 1) % L
+            frame += 1
+    return out
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_ring_runs_equal_a_frame_by_frame_simulation_of_the_reference_ring(seed):
+    from strugatzki_amd.engine import ring_runs
+    rng = np.random.default_rng(seed)
+    L = int(rng.integers(1, 40))
+    counts = [int(rng.choice([0, 1, L - 1, L, L + 1, 2 * L, 3 * L + 2, int(rng.integers(0, 5 * L + 3))]))
+              for _ in range(int(rng.integers(1, 14)))]
+    counts = [max(c, 0) for c in counts]
+    want = _ring_by_simulation(counts, L)
+    runs = ring_runs(counts, L)
+    got = {}
+    for r in runs:
+        cells = got.setdefault(int(r["file"]), {})
+        for k in range(int(r["count"])):
+            src = int(r["src_file"])
+            cells[int(r["dest"]) + k] = (src, int(r["src_frame"]) + k if src >= 0 else 0)
+    assert set(got) == set(want)
+    for f, cells in want.items():
+        own = counts[f]
+        assert [got[f][own + k] for k in range(L - own)] == cells
