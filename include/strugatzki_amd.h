@@ -118,6 +118,11 @@ SGZ_API int64_t sgz_db_file_frames(const sgz_context *ctx, int file);
 /* Copies the raw frames of a database file back to the host. */
 SGZ_API int sgz_db_read_file(sgz_context *ctx, int file, float *frames_out);
 
+/* A label the caller attaches to the database it has loaded into the context (for instance the list of files
+ * with their sizes and modification times), so that a later call can tell whether the resident files are the
+ * ones it needs.  sgz_db_reset and every sgz_db_add_* clear it.  sgz_db_tag returns "" when there is none. */
+SGZ_API int sgz_db_set_tag(sgz_context *ctx, const char *tag);
+SGZ_API const char *sgz_db_tag(const sgz_context *ctx);
 /* Copies `count` raw frames of a database file, starting at frame `first`, back to the host. */
 SGZ_API int sgz_db_read_frames(sgz_context *ctx, int file, int64_t first, int64_t count, float *frames_out);
 
@@ -467,6 +472,12 @@ typedef int (*sgz_progress_fn)(double progress, void *user);
  * with sgz_free_string.  Replaces impl/FeatureCorrelationImpl.body() (:32-412). */
 SGZ_API int sgz_run_correlation_xml(sgz_context *ctx, const char *config_xml, sgz_progress_fn cb, void *user,
                                     char **result_xml);
+/* sgz_run_correlation_xml with the database dealt over num_ctx contexts (one per GPU of the node; files round
+ * robin in iteration order) and searched by sgz_corr_search_multi: the same <matches>.  Like the single-context
+ * call it leaves the files resident: a later call over the same database (same feature files, sizes and
+ * modification times; sgz_db_tag) skips reading and uploading them.  A search with <punchOut> runs on ctxs[0]. */
+SGZ_API int sgz_run_correlation_xml_multi(sgz_context *const *ctxs, int num_ctx, const char *config_xml,
+                                          sgz_progress_fn cb, void *user, char **result_xml);
 /* FeatureSegmentation.run: <segmentation> in (FeatureSegmentation.scala:179-189),
  * "<breaks>" of <break> elements out.  Replaces impl/FeatureSegmentationImpl.body(). */
 SGZ_API int sgz_run_segmentation_xml(sgz_context *ctx, const char *config_xml, sgz_progress_fn cb, void *user,
@@ -506,6 +517,23 @@ SGZ_API int sgz_config_roundtrip_xml(const char *kind, const char *xml, char **o
  * e.g. FeatureCorrelation.scala:168-206). */
 SGZ_API int sgz_default_config_xml(const char *kind, char **out_xml);
 
+/* secsToFrames of the reference's command line (Strugatzki.scala:143): (secs * sample_rate + 0.5).toLong. */
+SGZ_API int64_t sgz_secs_to_frames(double secs, double sample_rate);
+/* The seconds-based options of `strugatzki -c` (Strugatzki.scala:101-176) as the <correlate> document
+ * sgz_run_correlation_xml takes: spans, minimum / maximum fill duration and spacing converted with
+ * sgz_secs_to_frames at the sample rate of the input's audio file (sample_rate <= 0: read from the file the
+ * meta file names, :140-141), with the reference's checks ("Punch in span is empty", "Minimum duration is
+ * zero", ...: SGZ_E_ARG).  has_out = 0: no punch-out span. */
+SGZ_API int sgz_correlate_config_from_seconds(const char *database_dir, const char *meta_input, double sample_rate,
+                                              double in_start, double in_stop, double in_temp, int has_out,
+                                              double out_start, double out_stop, double out_temp, double dur_min,
+                                              double dur_max, double boost_max, int num_matches, int num_per_file,
+                                              double spacing, int normalize, char **out_xml);
+/* Writes interleaved float frames as 32-bit float audio of the given type: "aiff" (AIFF-C fl32), "wav" (RIFF-WAVE,
+ * IEEE float) or "next" (NeXT/Sun): the output types CrossSimilarity's <outputType> can name
+ * (CrossSimilarity.scala:55,213; impl/CrossSimilarityImpl.scala:87-88). */
+SGZ_API int sgz_write_float_audio(const char *path, const char *type, const float *frames, int64_t num_frames,
+                                  int num_channels, double sample_rate);
 /* Writes interleaved float frames as a 32-bit float AIFF-C, the feature file
  * format (impl/NonRealtimeProcessor.scala:164-165). */
 SGZ_API int sgz_write_float_aiff(const char *path, const float *frames, int64_t num_frames, int num_channels,

@@ -175,6 +175,11 @@ constexpr const char *kNormalizeName = "feat_norms.aif";
 // descending similarity.  With punchOut the spans of the matches run from the punch-in to the punch-out offset.
 std::vector<Match> runFeatureCorrelation(sgz_context *ctx, const FeatureCorrelationConfig &cfg,
                                          const Observer &obs = nullptr);
+// The same search with the database dealt over several contexts (one per GPU of the node, files round robin in
+// iteration order): same result.  A context that still holds its share from an earlier call (same files, sizes,
+// modification times) is not loaded again.  A search with punchOut runs on the first context alone.
+std::vector<Match> runFeatureCorrelationMulti(const std::vector<sgz_context *> &ctxs, const FeatureCorrelationConfig &cfg,
+                                              const Observer &obs = nullptr);
 
 // impl/FeatureSegmentationImpl.body(): breaks in ascending similarity.
 std::vector<Break> runFeatureSegmentation(sgz_context *ctx, const FeatureSegmentationConfig &cfg,
@@ -216,5 +221,14 @@ AudioData readAudioFile(const std::string &path);
 // Writes a 32-bit float AIFF-C ("fl32", big endian), the format the reference
 // produces for feature files (impl/NonRealtimeProcessor.scala:164-165).
 void writeFloatAiff(const std::string &path, const AudioData &data);
+// 32-bit float RIFF-WAVE (format tag 3) and NeXT/Sun (encoding 6); writeFloatAudio picks by the logical name of
+// the reference's AudioFileType ("aiff", "wav", "next"), as CrossSimilarity's <outputType> holds it.
+void writeFloatWave(const std::string &path, const AudioData &data);
+void writeFloatNext(const std::string &path, const AudioData &data);
+void writeFloatAudio(const std::string &path, const AudioData &data, const std::string &type);
+
+// The reference's command line takes times in seconds and turns them into sample frames with
+// (s * sampleRate + 0.5).toLong (Strugatzki.scala:143): truncation towards zero, NaN -> 0, saturating.
+int64_t secsToFrames(double secs, double sampleRate);
 
 }  // namespace strugatzki

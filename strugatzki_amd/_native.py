@@ -79,6 +79,9 @@ SIGNATURES = {
     "sgz_db_file_frames": (C.c_int64, [_vp, C.c_int]),
     "sgz_db_read_file": (C.c_int, [_vp, C.c_int, _vp]),
     "sgz_db_read_frames": (C.c_int, [_vp, C.c_int, C.c_int64, C.c_int64, _vp]),
+    "sgz_db_set_tag": (C.c_int, [_vp, C.c_char_p]),
+    "sgz_db_tag": (C.c_char_p, [_vp]),
+    "sgz_run_correlation_xml_multi": (C.c_int, [_vp, C.c_int, C.c_char_p, _vp, _vp, C.POINTER(_vp)]),
     "sgz_corr_ring_runs": (C.c_int64, [_vp, C.c_int, C.c_int, _vp, C.c_int64]),
     "sgz_corr_set_ring_image": (C.c_int, [_vp, C.c_int, _vp, C.c_int]),
     "sgz_norm_zero_frame": (C.c_int, [_vp, _vp]),
@@ -152,6 +155,12 @@ SIGNATURES = {
     "sgz_config_roundtrip_xml": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(_vp)]),
     "sgz_default_config_xml": (C.c_int, [C.c_char_p, C.POINTER(_vp)]),
     "sgz_write_float_aiff": (C.c_int, [C.c_char_p, _vp, C.c_int64, C.c_int, C.c_double]),
+    "sgz_write_float_audio": (C.c_int, [C.c_char_p, C.c_char_p, _vp, C.c_int64, C.c_int, C.c_double]),
+    "sgz_secs_to_frames": (C.c_int64, [C.c_double, C.c_double]),
+    "sgz_correlate_config_from_seconds": (C.c_int, [C.c_char_p, C.c_char_p, C.c_double, C.c_double, C.c_double,
+                                                    C.c_double, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
+                                                    C.c_double, C.c_double, C.c_int, C.c_int, C.c_double, C.c_int,
+                                                    C.POINTER(_vp)]),
     "sgz_read_audio_file": (
         C.c_int,
         [C.c_char_p, _vp, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_double)],

@@ -1,5 +1,5 @@
-// Audio / feature file I/O: AIFF, AIFF-C and RIFF-WAVE readers, AIFF-C "fl32"
-// writer.  Feature files are float AIFFs with numCoeffs+1 interleaved channels
+// Audio / feature file I/O: AIFF, AIFF-C, RIFF-WAVE and NeXT/Sun readers; AIFF-C "fl32",
+// WAVE IEEE-float and NeXT/Sun float writers.  Feature files are float AIFFs with numCoeffs+1 interleaved channels
 // at the feature rate (reference: impl/NonRealtimeProcessor.scala:164-165; read
 // back at impl/FeatureCorrelationImpl.scala:62-67,81-89,169,195).
 #include <cmath>
@@ -228,6 +228,50 @@ AudioData readWav(Reader &r)
     return a;
 }
 
+// NeXT / Sun ".snd": big-endian header (magic, data offset, data size, encoding, rate, channels), then samples
+AudioData readNext(Reader &r)
+{
+    r.p = 4;
+    const uint32_t offset = r.be32(), size = r.be32(), enc = r.be32(), rate = r.be32(), ch = r.be32();
+    AudioData a;
+    a.numChannels = (int)ch;
+    a.sampleRate = (double)rate;
+    int bits;
+    Fmt fmt = Fmt::Int;
+    switch (enc) {
+        case 2: bits = 8; break;
+        case 3: bits = 16; break;
+        case 4: bits = 24; break;
+        case 5: bits = 32; break;
+        case 6: bits = 32; fmt = Fmt::Float32; break;
+        case 7: bits = 64; fmt = Fmt::Float64; break;
+        default: throw Error(SGZ_E_IO, "unsupported NeXT encoding in " + r.path);
+    }
+    if (a.numChannels < 1 || offset < 24 || offset > r.d.size()) throw Error(SGZ_E_IO, "bad NeXT header: " + r.path);
+    size_t bytes = r.d.size() - offset;
+    if (size != 0xFFFFFFFFu && size < bytes) bytes = size;
+    const size_t fb = (size_t)a.numChannels * (bits / 8);
+    a.numFrames = (int64_t)(bytes / fb);
+    const size_t count = (size_t)a.numFrames * a.numChannels;
+    a.frames.resize(count);
+    if (count) decode(&r.d[offset], count, bits, fmt, true, false, a.frames.data());
+    return a;
+}
+
+void checkData(const AudioData &a)
+{
+    if (a.numChannels < 1 || a.numFrames < 0 || a.frames.size() != (size_t)a.numFrames * a.numChannels)
+        throw Error(SGZ_E_ARG, "inconsistent AudioData");
+}
+
+void writeAll(const std::string &path, const std::vector<unsigned char> &o)
+{
+    std::ofstream f(path, std::ios::binary | std::ios::trunc);
+    if (!f) throw Error(SGZ_E_IO, "cannot create " + path);
+    f.write(reinterpret_cast<const char *>(o.data()), (std::streamsize)o.size());
+    if (!f) throw Error(SGZ_E_IO, "cannot write " + path);
+}
+
 }  // namespace
 
 AudioData readAudioFile(const std::string &path)
@@ -237,7 +281,78 @@ AudioData readAudioFile(const std::string &path)
     const std::string magic(reinterpret_cast<const char *>(r.d.data()), 4);
     if (magic == "FORM") return readAiff(r);
     if (magic == "RIFF") return readWav(r);
+    if (magic == ".snd" && r.d.size() >= 24) return readNext(r);
     throw Error(SGZ_E_IO, "unknown audio file format: " + path);
+}
+
+// RIFF-WAVE, IEEE float (format tag 3), with the fact chunk non-PCM formats carry
+void writeFloatWave(const std::string &path, const AudioData &a)
+{
+    checkData(a);
+    std::vector<unsigned char> o;
+    auto le32 = [&](uint32_t v) {
+        for (int s = 0; s <= 24; s += 8) o.push_back((unsigned char)(v >> s));
+    };
+    auto le16 = [&](uint16_t v) {
+        o.push_back((unsigned char)v);
+        o.push_back((unsigned char)(v >> 8));
+    };
+    auto tag = [&](const char *t) { o.insert(o.end(), t, t + 4); };
+    const uint32_t dataBytes = (uint32_t)(a.frames.size() * 4);
+    const uint32_t rate = (uint32_t)(a.sampleRate + 0.5);  // the format holds an integer rate
+    tag("RIFF");
+    le32(4 + (8 + 16) + (8 + 4) + (8 + dataBytes));
+    tag("WAVE");
+    tag("fmt ");
+    le32(16);
+    le16(3);
+    le16((uint16_t)a.numChannels);
+    le32(rate);
+    le32(rate * (uint32_t)a.numChannels * 4);
+    le16((uint16_t)(a.numChannels * 4));
+    le16(32);
+    tag("fact");
+    le32(4);
+    le32((uint32_t)a.numFrames);
+    tag("data");
+    le32(dataBytes);
+    const size_t base = o.size();
+    o.resize(base + dataBytes);
+    std::memcpy(o.data() + base, a.frames.data(), dataBytes);  // little endian hosts only (as the GPU is)
+    writeAll(path, o);
+}
+
+// NeXT / Sun, 32-bit float (encoding 6)
+void writeFloatNext(const std::string &path, const AudioData &a)
+{
+    checkData(a);
+    std::vector<unsigned char> o;
+    auto be32 = [&](uint32_t v) {
+        for (int s = 24; s >= 0; s -= 8) o.push_back((unsigned char)(v >> s));
+    };
+    const uint32_t dataBytes = (uint32_t)(a.frames.size() * 4);
+    o.insert(o.end(), {'.', 's', 'n', 'd'});
+    be32(28);  // header + 4 bytes of (empty) annotation
+    be32(dataBytes);
+    be32(6);
+    be32((uint32_t)(a.sampleRate + 0.5));
+    be32((uint32_t)a.numChannels);
+    be32(0);
+    for (size_t i = 0; i < a.frames.size(); i++) {
+        uint32_t u;
+        std::memcpy(&u, &a.frames[i], 4);
+        be32(u);
+    }
+    writeAll(path, o);
+}
+
+// `type`: the logical names of the reference's AudioFileType ids, as CrossSimilarity's <outputType> holds them
+void writeFloatAudio(const std::string &path, const AudioData &a, const std::string &type)
+{
+    if (type == "aiff") writeFloatAiff(path, a);
+    else if (type == "wav" || type == "wave") writeFloatWave(path, a);
+    else if (type == "next" || type == "au") writeFloatNext(path, a);
+    else throw Error(SGZ_E_ARG, "output type '" + type + "' cannot be written (aiff, wav and next can)");
 }
 
 void writeFloatAiff(const std::string &path, const AudioData &a)
@@ -292,6 +407,15 @@ void writeFloatAiff(const std::string &path, const AudioData &a)
     if (!f) throw Error(SGZ_E_IO, "cannot create " + path);
     f.write(reinterpret_cast<const char *>(o.data()), (std::streamsize)o.size());
     if (!f) throw Error(SGZ_E_IO, "cannot write " + path);
+}
+
+int64_t secsToFrames(double secs, double sampleRate)
+{
+    const double v = secs * sampleRate + 0.5;
+    if (v != v) return 0;  // Double.NaN.toLong
+    if (v >= 9223372036854775807.0) return INT64_MAX;
+    if (v <= -9223372036854775808.0) return INT64_MIN;
+    return (int64_t)v;  // towards zero, as .toLong
 }
 
 }  // namespace strugatzki

@@ -1366,6 +1366,7 @@ int sgz_db_reset(sgz_context *ctx, int num_channels)
     for (auto &f : ctx->files)
         if (f.owned && f.d_raw) SGZ_HIP(ctx, hipFree(f.d_raw));
     ctx->files.clear();
+    ctx->db_tag.clear();
     ctx->ring_images.clear();
     ctx->numCh = num_channels;
     ctx->layout_dirty = true;
@@ -1398,6 +1399,7 @@ int sgz_db_add_file(sgz_context *ctx, const float *frames, int64_t num_frames)
     SGZ_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&f.d_raw), bytes ? bytes : 4));
     if (bytes) SGZ_HIP(ctx, hipMemcpy(f.d_raw, frames, bytes, hipMemcpyHostToDevice));
     ctx->files.push_back(f);
+    ctx->db_tag.clear();
     ctx->layout_dirty = true;
     return SGZ_OK;
 }
@@ -1415,6 +1417,7 @@ int sgz_db_add_file_device(sgz_context *ctx, const float *device_frames, int64_t
     f.owned = false;
     f.d_raw = const_cast<float *>(device_frames);
     ctx->files.push_back(f);
+    ctx->db_tag.clear();
     ctx->layout_dirty = true;
     return SGZ_OK;
 }
@@ -1451,6 +1454,7 @@ int sgz_db_add_synthetic(sgz_context *ctx, uint64_t seed, int64_t file_id, int64
     SGZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (d_pl) SGZ_HIP(ctx, hipFree(d_pl));
     ctx->files.push_back(f);
+    ctx->db_tag.clear();
     ctx->layout_dirty = true;
     return SGZ_OK;
 }
@@ -1475,6 +1479,15 @@ int sgz_db_read_file(sgz_context *ctx, int file, float *frames_out)
                                hipMemcpyDeviceToHost));
     return SGZ_OK;
 }
+
+int sgz_db_set_tag(sgz_context *ctx, const char *tag)
+{
+    if (!ctx) return SGZ_E_ARG;
+    ctx->db_tag = tag ? tag : "";
+    return SGZ_OK;
+}
+
+const char *sgz_db_tag(const sgz_context *ctx) { return ctx ? ctx->db_tag.c_str() : ""; }
 
 int sgz_db_read_frames(sgz_context *ctx, int file, int64_t first, int64_t count, float *frames_out)
 {
@@ -1515,14 +1528,18 @@ int sgz_set_norms(sgz_context *ctx, const float *norms)
 {
     if (!ctx) return SGZ_E_ARG;
     if (ctx->numCh == 0) return ctx->fail(SGZ_E_STATE, "sgz_db_reset has not been called");
-    std::memset(&ctx->norm, 0, sizeof ctx->norm);
+    NormParams nrm;
+    std::memset(&nrm, 0, sizeof nrm);
     if (norms) {
-        ctx->norm.enabled = 1;
+        nrm.enabled = 1;
         for (int c = 0; c < ctx->numCh; c++) {
-            ctx->norm.mn[c] = norms[2 * c];
-            ctx->norm.d[c] = norms[2 * c + 1] - norms[2 * c];
+            nrm.mn[c] = norms[2 * c];
+            nrm.d[c] = norms[2 * c + 1] - norms[2 * c];
         }
     }
+    // the same norms again (a caller that sets them with every query): everything derived from them stays valid
+    if (ctx->d_normtab && std::memcmp(&nrm, &ctx->norm, sizeof nrm) == 0) return SGZ_OK;
+    ctx->norm = nrm;
     ctx->have_target = false;  // target statistics depend on the norms
     ctx->layout_dirty = true;  // so do the images of files shorter than the target
     SGZ_HIP(ctx, hipSetDevice(ctx->device));

@@ -116,7 +116,20 @@ void writePng(const std::string &path, const int32_t *rgb, int w, int h)
 // -----------------------------------------------------------------------------
 std::vector<Match> runFeatureCorrelation(sgz_context *ctx, const FeatureCorrelationConfig &cfg, const Observer &obs)
 {
-    if (!ctx) throw Error(SGZ_E_ARG, "null context");
+    return runFeatureCorrelationMulti(std::vector<sgz_context *>{ctx}, cfg, obs);
+}
+
+// The same over several contexts (one per GPU of the node): the compatible database files are dealt round robin,
+// in iteration order, to the contexts; each keeps its share resident.  A context that still holds exactly these
+// files from an earlier call (same paths, sizes and modification times: sgz_db_tag) is not loaded again, so a
+// service that answers many queries against one database pays the file reads and the upload once.
+std::vector<Match> runFeatureCorrelationMulti(const std::vector<sgz_context *> &ctxsIn, const FeatureCorrelationConfig &cfg,
+                                              const Observer &obs)
+{
+    if (ctxsIn.empty()) throw Error(SGZ_E_ARG, "no context");
+    for (sgz_context *c : ctxsIn)
+        if (!c) throw Error(SGZ_E_ARG, "null context");
+    sgz_context *ctx = ctxsIn[0];
     if (cfg.numMatches < 0 || cfg.numPerFile < 0) throw Error(SGZ_E_ARG, "numMatches / numPerFile must be >= 0");
     const FeatureExtractionConfig extrIn = FeatureExtractionConfig::fromXMLFile(cfg.metaInput);  // :35
     if (extrIn.fftOverlap < 1 || extrIn.fftSize < extrIn.fftOverlap) throw Error(SGZ_E_ARG, "bad fftSize / fftOverlap");
@@ -157,21 +170,42 @@ std::vector<Match> runFeatureCorrelation(sgz_context *ctx, const FeatureCorrelat
     if (L < 1 || start < 0 || (int64_t)stop > afIn.numFrames)
         throw Error(SGZ_E_IO, "punchIn span lies outside the input feature file");
 
-    check(ctx, sgz_db_reset(ctx, numCh));
-    std::vector<int> dbIndex;  // database entries that made it to the GPU
-    for (size_t i = 0; i < extrDBs.size(); i++) {
-        checkAborted(obs, 0.5 * (double)i / (double)std::max<size_t>(extrDBs.size(), 1));  // :164
-        const AudioData af = readAudioFile(extrDBs[i].featureOutput);  // :169
-        if (af.numChannels != numCh)
-            throw Error(SGZ_E_IO, "feature file " + extrDBs[i].featureOutput + " has the wrong number of channels");
-        check(ctx, sgz_db_add_file(ctx, af.frames.data(), af.numFrames));
-        dbIndex.push_back((int)i);
+    // the punch-out pairing needs the dense similarities of both targets in one place: one context
+    const std::vector<sgz_context *> ctxs = cfg.punchOut ? std::vector<sgz_context *>{ctx} : ctxsIn;
+    const int nctx = (int)ctxs.size();
+    const int nf = (int)extrDBs.size();
+    std::vector<std::vector<int32_t>> ids((size_t)nctx);
+    for (int g = 0; g < nf; g++) ids[(size_t)(g % nctx)].push_back(g);
+    for (int c = 0; c < nctx; c++) {
+        // what this context should hold, as a label
+        std::string tag = "correlate|" + std::to_string(numCh) + "|" + std::to_string(nctx) + "|" + std::to_string(c);
+        for (int32_t g : ids[(size_t)c]) {
+            const std::string &path = extrDBs[(size_t)g].featureOutput;
+            std::error_code e1, e2;
+            const auto sz = fs::file_size(path, e1);
+            const auto tm = fs::last_write_time(path, e2);
+            tag += "|" + path + ":" + (e1 ? "?" : std::to_string(sz)) + ":" +
+                   (e2 ? "?" : std::to_string(tm.time_since_epoch().count()));
+        }
+        const char *have = sgz_db_tag(ctxs[(size_t)c]);
+        if (have && tag == have) continue;  // resident already
+        check(ctxs[(size_t)c], sgz_db_reset(ctxs[(size_t)c], numCh));
+        for (size_t k = 0; k < ids[(size_t)c].size(); k++) {
+            const int g = ids[(size_t)c][k];
+            checkAborted(obs, 0.5 * (double)g / (double)std::max(nf, 1));  // :164
+            const AudioData af = readAudioFile(extrDBs[(size_t)g].featureOutput);  // :169
+            if (af.numChannels != numCh)
+                throw Error(SGZ_E_IO, "feature file " + extrDBs[(size_t)g].featureOutput + " has the wrong number of channels");
+            check(ctxs[(size_t)c], sgz_db_add_file(ctxs[(size_t)c], af.frames.data(), af.numFrames));
+        }
+        check(ctxs[(size_t)c], sgz_db_set_tag(ctxs[(size_t)c], tag.c_str()));
     }
-    check(ctx, sgz_set_norms(ctx, cfg.normalize ? norms.data() : nullptr));
-    check(ctx, sgz_corr_set_target(ctx, afIn.frames.data() + (size_t)start * numCh, L, cfg.punchIn.temporalWeight,
-                                   cfg.maxBoost));
+    for (sgz_context *c : ctxs) {
+        check(c, sgz_set_norms(c, cfg.normalize ? norms.data() : nullptr));
+        check(c, sgz_corr_set_target(c, afIn.frames.data() + (size_t)start * numCh, L, cfg.punchIn.temporalWeight,
+                                     cfg.maxBoost));
+    }
 
-    const int nf = (int)dbIndex.size();
     sgz_selector *sel = sgz_sel_create(cfg.numMatches, cfg.numPerFile, cfg.minSpacing, stepSize, L);
     if (!sel) throw Error(SGZ_E_ARG, "illegal selection parameters");
     struct SelGuard {
@@ -183,7 +217,7 @@ std::vector<Match> runFeatureCorrelation(sgz_context *ctx, const FeatureCorrelat
         for (int i = 0; i < n; i++) {
             Match m;
             m.sim = raw[(size_t)i].sim;
-            m.file = extrDBs[(size_t)dbIndex[(size_t)raw[(size_t)i].file]].audioInput;  // :237
+            m.file = extrDBs[(size_t)raw[(size_t)i].file].audioInput;  // :237
             m.punch = Span::of(raw[(size_t)i].start, raw[(size_t)i].stop);
             m.boostIn = raw[(size_t)i].boost_in;
             m.boostOut = raw[(size_t)i].boost_out;
@@ -234,12 +268,24 @@ std::vector<Match> runFeatureCorrelation(sgz_context *ctx, const FeatureCorrelat
         return toMatches(raw, n);
     }
 
-    // GPU: all similarities; host: replay of the match bookkeeping in file order (sgz_search.cpp)
+    // GPU: all similarities; host: replay of the match bookkeeping in file order (sgz_search.cpp, sgz_multi.hip)
     checkAborted(obs, 0.6);
     std::vector<sgz_match> raw((size_t)std::max(cfg.numMatches, 1));
     int n = 0;
-    check(ctx, sgz_corr_search(ctx, L, cfg.numMatches, cfg.numPerFile, cfg.minSpacing, stepSize, SGZ_SCREEN_AUTO, 1,
-                               1 << 16, -1.0f, raw.data(), cfg.numMatches, &n));
+    if (nctx == 1) {
+        check(ctx, sgz_corr_search(ctx, L, cfg.numMatches, cfg.numPerFile, cfg.minSpacing, stepSize, SGZ_SCREEN_AUTO, 1,
+                                   1 << 16, -1.0f, raw.data(), cfg.numMatches, &n));
+    } else {
+        std::vector<const int32_t *> idPtrs;
+        for (auto &v : ids) idPtrs.push_back(v.empty() ? nullptr : v.data());
+        const int rc = sgz_corr_search_multi(ctxs.data(), nctx, idPtrs.data(), nf, L, cfg.numMatches, cfg.numPerFile,
+                                             cfg.minSpacing, stepSize, 1 << 16, raw.data(), cfg.numMatches, &n);
+        if (rc != SGZ_OK) {
+            std::string msg;
+            for (sgz_context *c : ctxs) msg += std::string(msg.empty() ? "" : "; ") + sgz_last_error(c);
+            throw Error(rc, msg);
+        }
+    }
     checkAborted(obs, 1.0);
     return toMatches(raw, n);
 }
@@ -337,7 +383,8 @@ void runSelfSimilarity(sgz_context *ctx, const SelfSimilarityConfig &cfg, const 
 void runCrossSimilarity(sgz_context *ctx, const CrossSimilarityConfig &cfg, const Observer &obs)
 {
     if (!ctx) throw Error(SGZ_E_ARG, "null context");
-    if (cfg.audioOutputType != "aiff") throw Error(SGZ_E_ARG, "only outputType aiff can be written");
+    if (cfg.audioOutputType != "aiff" && cfg.audioOutputType != "wav" && cfg.audioOutputType != "next")
+        throw Error(SGZ_E_ARG, "outputType '" + cfg.audioOutputType + "' cannot be written (aiff, wav and next can)");
     const FeatureExtractionConfig e1 = FeatureExtractionConfig::fromXMLFile(cfg.metaInput1);
     const FeatureExtractionConfig e2 = FeatureExtractionConfig::fromXMLFile(cfg.metaInput2);
     if (e1.fftSize != e2.fftSize || e1.fftOverlap != e2.fftOverlap || e1.numCoeffs != e2.numCoeffs)  // :39-41
@@ -386,7 +433,7 @@ void runCrossSimilarity(sgz_context *ctx, const CrossSimilarityConfig &cfg, cons
     if (n > 0) check(ctx, sgz_corr_read_dense(ctx, 0, out.frames.data(), nullptr));
     out.frames.resize((size_t)n);
     checkAborted(obs, 0.9);
-    writeFloatAiff(cfg.audioOutput, out);
+    writeFloatAudio(cfg.audioOutput, out, cfg.audioOutputType);
     notify(obs, 1.0);
 }
 
@@ -535,6 +582,22 @@ int sgz_run_correlation_xml(sgz_context *ctx, const char *config_xml, sgz_progre
     });
 }
 
+int sgz_run_correlation_xml_multi(sgz_context *const *ctxs, int num_ctx, const char *config_xml, sgz_progress_fn cb,
+                                  void *user, char **result_xml)
+{
+    if (!ctxs || num_ctx < 1 || !config_xml || !result_xml) return SGZ_E_ARG;
+    *result_xml = nullptr;
+    return guarded([&] {
+        const auto cfg = strugatzki::FeatureCorrelationConfig::fromXML(config_xml);
+        const std::vector<sgz_context *> list(ctxs, ctxs + num_ctx);
+        const auto ms = strugatzki::runFeatureCorrelationMulti(list, cfg, makeObserver(cb, user));
+        std::string o = "<matches>\n";
+        for (const auto &m : ms) o += m.toXML() + "\n";
+        o += "</matches>";
+        *result_xml = dupString(o);
+    });
+}
+
 int sgz_run_segmentation_xml(sgz_context *ctx, const char *config_xml, sgz_progress_fn cb, void *user,
                              char **result_xml)
 {
@@ -639,6 +702,70 @@ int sgz_default_config_xml(const char *kind, char **out_xml)
         else if (k == "selfsimilarity") o = strugatzki::SelfSimilarityConfig().toXML();
         else throw strugatzki::Error(SGZ_E_ARG, "unknown config kind " + k);
         *out_xml = dupString(o);
+    });
+}
+
+int64_t sgz_secs_to_frames(double secs, double sample_rate)
+{
+    return strugatzki::secsToFrames(secs, sample_rate);
+}
+
+int sgz_correlate_config_from_seconds(const char *database_dir, const char *meta_input, double sample_rate,
+                                      double in_start, double in_stop, double in_temp, int has_out, double out_start,
+                                      double out_stop, double out_temp, double dur_min, double dur_max,
+                                      double boost_max, int num_matches, int num_per_file, double spacing,
+                                      int normalize, char **out_xml)
+{
+    if (!database_dir || !meta_input || !out_xml) return SGZ_E_ARG;
+    *out_xml = nullptr;
+    return guarded([&] {
+        double sr = sample_rate;
+        if (!(sr > 0)) {  // AudioFile.readSpec(metaIn.audioInput), Strugatzki.scala:140-141
+            const auto metaIn = strugatzki::FeatureExtractionConfig::fromXMLFile(meta_input);
+            sr = strugatzki::readAudioFile(metaIn.audioInput).sampleRate;
+        }
+        auto frames = [&](double s) { return strugatzki::secsToFrames(s, sr); };
+        strugatzki::FeatureCorrelationConfig con;
+        con.databaseFolder = database_dir;
+        con.metaInput = meta_input;
+        if (has_out) {  // :145-153
+            const int64_t a = frames(out_start), b = frames(out_stop);
+            if (b - a <= 0) throw strugatzki::Error(SGZ_E_ARG, "requirement failed: Punch out span is empty");
+            strugatzki::Punch po;
+            po.span = strugatzki::Span::of(a, b);
+            po.temporalWeight = (float)out_temp;
+            con.punchOut = po;
+        }
+        const int64_t a = frames(in_start), b = frames(in_stop);  // :155-157
+        if (b - a <= 0) throw strugatzki::Error(SGZ_E_ARG, "requirement failed: Punch in span is empty");
+        con.punchIn.span = strugatzki::Span::of(a, b);
+        con.punchIn.temporalWeight = (float)in_temp;
+        const int64_t minFrames = frames(dur_min), maxFrames = frames(dur_max);  // :158-161
+        if (minFrames <= 0) throw strugatzki::Error(SGZ_E_ARG, "requirement failed: Minimum duration is zero");
+        if (maxFrames < minFrames)
+            throw strugatzki::Error(SGZ_E_ARG, "requirement failed: Maximum duration is smaller than minimum duration");
+        con.minPunch = minFrames;
+        con.maxPunch = maxFrames;
+        con.normalize = normalize != 0;
+        con.maxBoost = (float)boost_max;
+        con.numMatches = num_matches;
+        con.numPerFile = num_per_file;
+        con.minSpacing = frames(spacing);  // :175
+        *out_xml = dupString(con.toXML());
+    });
+}
+
+int sgz_write_float_audio(const char *path, const char *type, const float *frames, int64_t num_frames, int num_channels,
+                          double sample_rate)
+{
+    if (!path || !type || num_frames < 0 || num_channels < 1 || (num_frames > 0 && !frames)) return SGZ_E_ARG;
+    return guarded([&] {
+        strugatzki::AudioData a;
+        a.numChannels = num_channels;
+        a.numFrames = num_frames;
+        a.sampleRate = sample_rate;
+        a.frames.assign(frames, frames + (size_t)num_frames * num_channels);
+        strugatzki::writeFloatAudio(path, a, type);
     });
 }
 

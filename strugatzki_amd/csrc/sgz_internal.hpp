@@ -98,6 +98,7 @@ struct sgz_context {
 
     int numCh = 0;
     std::vector<sgz::DbFile> files;
+    std::string db_tag;                      // the caller's label of the loaded database (sgz_db_set_tag)
     sgz::NormParams norm{};
 
     // target

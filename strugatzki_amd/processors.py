@@ -222,10 +222,16 @@ class FeatureCorrelation:
     @staticmethod
     def run(ctx: Context, config: "FeatureCorrelation.Config", observer: Observer = None
             ) -> list["FeatureCorrelation.Match"]:
-        """Matches sorted by descending similarity (FeatureCorrelation.scala:30-33)."""
+        """Matches sorted by descending similarity (FeatureCorrelation.scala:30-33).  `ctx` may be a list of
+        contexts (one per GPU): the database is then dealt over them (sgz_run_correlation_xml_multi)."""
         out = C.c_void_p()
         cb = _callback(observer)
-        _host_check(lib.sgz_run_correlation_xml(ctx._h, config.to_xml().encode(), cb, None, C.byref(out)))
+        if isinstance(ctx, (list, tuple)):
+            handles = (C.c_void_p * len(ctx))(*[c._h for c in ctx])
+            _host_check(lib.sgz_run_correlation_xml_multi(handles, len(ctx), config.to_xml().encode(), cb, None,
+                                                          C.byref(out)))
+        else:
+            _host_check(lib.sgz_run_correlation_xml(ctx._h, config.to_xml().encode(), cb, None, C.byref(out)))
         root = ET.fromstring(_take_string(out))
         return [FeatureCorrelation.Match.from_xml(m) for m in root.findall("match")]
 

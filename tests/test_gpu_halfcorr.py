@@ -95,6 +95,23 @@ def test_cross_file_similarity(ctx):
     np.testing.assert_allclose(sim, want_sim, rtol=0, atol=1e-5)
 
 
+def test_selfsim_matrix_for_colour_schemes_the_jvm_renders(ctx):
+    """colors = psycho (the reference's default, SelfSimilarity.scala:178): the palette is a JVM-side class, so the
+    route is the similarity matrix without a raster -- accepted for any colour id, within 1e-5 of the oracle --
+    while asking the library for a psycho raster fails loudly.  (Parity of the palette itself: unpinned, third party.)"""
+    import strugatzki_amd as S
+    frames = _frames(260)
+    norms = norms_default()
+    cfg = O.SelfSimConfig(0, 0, 0, 0, 8 * STEP, 2, 0.5, 0, 1.0, 1.0, 0, 1, STEP, NUM_CH - 1)
+    ext, d, af_start, _ = O.selfsim_geometry(cfg, frames.shape[0], frames.shape[0])
+    want_sim, _ = O.selfsim_run(cfg, frames, None, norms, want_img=False)
+    sim, img = ctx.selfsim(frames, None, norms, af_start, 8, d, ext, 0.5, colors=1, want_img=False)
+    assert img is None
+    np.testing.assert_allclose(sim, want_sim, rtol=0, atol=1e-5)
+    with pytest.raises(S.NativeError):
+        ctx.selfsim(frames, None, norms, af_start, 8, d, ext, 0.5, colors=1, want_img=True)
+
+
 def test_selfsim_rejects_bad_arguments(ctx):
     import strugatzki_amd as S
     frames = _frames(100)

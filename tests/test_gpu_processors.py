@@ -63,6 +63,44 @@ def test_feature_correlation_from_files(ctx, tmp_path, num_matches, num_per_file
     assert seen and seen[-1] == 1.0 and seen == sorted(seen)
 
 
+def test_feature_correlation_keeps_the_database_resident_and_runs_on_several_contexts(tmp_path):
+    """A second query against the same folder finds the files on the GPU (no per-file progress of a load); touching
+    a file loads again.  Two and three contexts (files dealt round robin) return the single-context list."""
+    import strugatzki_amd as S
+    L, ts = 64, 11
+    db_dir, in_meta, db, tgt, norms, plants = _make_db(tmp_path, L=L, ts=ts)
+    mk = lambda t0, nm, npf: FeatureCorrelation.Config(db_dir, in_meta, FeatureCorrelation.Punch(
+        Span(t0 * STEP, (t0 + L) * STEP), 0.5), None, 22050, 88200, True, 8.0, nm, npf, 0)
+    with S.Context(0) as c0:
+        seen = []
+        first = FeatureCorrelation.run(c0, mk(ts, 5, 1), lambda p: seen.append(p) or True)
+        assert any(p < 0.5 for p in seen)  # the load reports one step per file
+        tag = P.N.lib.sgz_db_tag(c0._h)
+        assert tag and db_dir.encode() in tag
+        seen = []
+        again = FeatureCorrelation.run(c0, mk(ts, 5, 1), lambda p: seen.append(p) or True)
+        assert seen == [0.6, 1.0] and again == first
+        other = FeatureCorrelation.run(c0, mk(ts + 3, 5, 2))  # another query, same resident files
+        want, _, _ = O.correlation_run(corr_config(ts + 3, L, num_matches=5, num_per_file=2), tgt, norms, db,
+                                       dense=False)
+        assert [(m.punch.start, m.punch.stop) for m in other] == [(w.start, w.stop) for w in want]
+        os.utime(os.path.join(db_dir, "snd001_feat.aif"), ns=(1, 1))
+        seen = []
+        FeatureCorrelation.run(c0, mk(ts, 5, 1), lambda p: seen.append(p) or True)
+        assert any(p < 0.5 for p in seen)  # a changed file: loaded anew
+        for n in (2, 3):
+            ctxs = [S.Context(0) for _ in range(n)]
+            try:
+                for nm, npf in ((5, 1), (6, 3)):
+                    assert FeatureCorrelation.run(ctxs, mk(ts, nm, npf)) == FeatureCorrelation.run(c0, mk(ts, nm, npf))
+                seen = []
+                FeatureCorrelation.run(ctxs, mk(ts, 5, 1), lambda p: seen.append(p) or True)
+                assert seen == [0.6, 1.0]
+            finally:
+                for c in ctxs:
+                    c.close()
+
+
 @pytest.mark.parametrize("num_matches,num_per_file,min_punch,max_punch", [(4, 1, 20, 60), (6, 2, 5, 200)])
 def test_feature_correlation_punch_out_from_files(ctx, tmp_path, num_matches, num_per_file, min_punch, max_punch):
     """punchIn + punchOut: spans run from the punch-in to the punch-out offset, sim = sqrt(inSim * outSim)."""
@@ -135,8 +173,15 @@ def test_cross_similarity_from_files(ctx, tmp_path, swap):
     np.testing.assert_allclose(got[:, 0], want, rtol=0, atol=1e-5)
     assert int(np.argmax(got[:, 0])) == int(np.argmax(want))
     assert seen and seen[-1] == 1.0
+    # the other output types the reference's <outputType> can name (CrossSimilarity.scala:55, 213)
+    for typ, name in (("wav", "xsim.wav"), ("next", "xsim.au")):
+        out2 = os.path.join(d, name)
+        P.CrossSimilarity.run(ctx, P.CrossSimilarity.Config(d, cfg.metaInput1, cfg.metaInput2, out2, typ, cfg.span1,
+                                                            cfg.span2, 0.5, True, 8.0))
+        got2, rate2 = P.read_audio_file(out2)
+        assert np.array_equal(got2, got) and rate2 == round(RATE)  # (these formats hold an integer rate)
     with pytest.raises(P.N.NativeError):
-        P.CrossSimilarity.run(ctx, P.CrossSimilarity.Config(d, m_short, m_long, out, "wav"))
+        P.CrossSimilarity.run(ctx, P.CrossSimilarity.Config(d, m_short, m_long, out, "ircam"))
 
 
 def test_feature_stats(ctx, tmp_path):
