@@ -197,13 +197,25 @@ struct SelfSimArgs {
     int inv;
     float *simOut;                   // [imgExt][imgExt]; between two passes: the weighted first part, upper triangle
     int wantSim;                     // the last pass writes the matrix
+    int keepUpper;                   // the last pass writes at least the half with y >= x (wantSim, or for the list)
     int *imgOut;
     float wT;                        // temporal weight of the whole similarity
-    // pixels whose gray level the certified error of the similarity could change: listed by the last pass,
-    // evaluated in the reference's own order by selfsim_fix_kernel
+    // pixels whose gray level the certified error of the similarity could change: listed by selfsim_list_kernel,
+    // evaluated as the reference does by selfsim_fix_kernel
     unsigned long long *fixCount;
     int2 *fixList;
     long long fixCap;
+    // of those, the few whose quotient needs the reference's own order of additions (selfsim_seq_kernel)
+    unsigned int *seqCount;
+    struct SelfSimSeq *seqList;
+    unsigned int seqCap;
+};
+
+struct SelfSimSeq {
+    int px, py;
+    float temporal, spectral;  // the group that is certain already
+    int redo;                  // bit 0: temporal, bit 1: spectral to be evaluated in sequence
+    int pad;
 };
 
 // Largest error of a similarity that left selfsim_pixel as "sure": 8e-6 from the fp32 product sums (both groups,
@@ -395,21 +407,13 @@ __global__ __launch_bounds__(256, 2) void selfsim_tile_kernel(SelfSimArgs g)
             float sim = part * g.wThis;
             const long long up = (long long)px * g.imgExt + py;
             if (!g.first) sim = g.simOut[up] + sim;
-            if (!g.last || g.wantSim) g.simOut[up] = sim;
+            if (!g.last || g.keepUpper) g.simOut[up] = sim;
             if (g.last) {
                 lds[pxl * kRow + pyl] = sim;
                 // (the raster's row is imgExt - 1 - y: of the two pixels that show this value, the one whose
                 // neighbours along y lie in the same row)
-                if (g.imgOut) {
-                    const int colr = gray_color(sim, g.warp, g.scale, g.inv);
-                    g.imgOut[(long long)(g.imgExt - 1 - px) * g.imgExt + py] = colr;
-                    // the colour map is monotonic: the level is certain when both ends of the error interval agree
-                    if (gray_color(sim - kSsSimErr, g.warp, g.scale, g.inv) !=
-                        gray_color(sim + kSsSimErr, g.warp, g.scale, g.inv)) {
-                        const unsigned long long slot = atomicAdd(g.fixCount, 1ull);
-                        if ((long long)slot < g.fixCap) g.fixList[slot] = make_int2(px, py);
-                    }
-                }
+                if (g.imgOut)
+                    g.imgOut[(long long)(g.imgExt - 1 - px) * g.imgExt + py] = gray_color(sim, g.warp, g.scale, g.inv);
             }
         }
         if (!g.last) continue;
@@ -427,27 +431,201 @@ __global__ __launch_bounds__(256, 2) void selfsim_tile_kernel(SelfSimArgs g)
     }
 }
 
-// The listed pixels (or, without a list, every pixel with y >= x) in the reference's own order of operations
+// Lists the pixels (x, y >= x) whose gray level is not certain: the colour map is monotonic, so the level is
+// certain when both ends of the similarity's error interval map to the same one.  A workgroup per tile of
+// 128 x 128 pixels, so that neighbours in the list are neighbours in the matrix (selfsim_fix_kernel then finds
+// the frames of both windows in cache); hits are collected in LDS and appended with one atomic on the global
+// counter per tile.
+__global__ __launch_bounds__(256) void selfsim_list_kernel(SelfSimArgs g)
+{
+    constexpr int kLocal = 4096;
+    __shared__ int hits[kLocal];
+    __shared__ int count;
+    __shared__ unsigned long long base;
+    const int tileX = blockIdx.x % g.tilesEdge, tileY = blockIdx.x / g.tilesEdge;
+    if (tileY < tileX) return;
+    const int tid = threadIdx.x, X0 = tileX * kSsTile, Y0 = tileY * kSsTile;
+    if (tid == 0) count = 0;
+    __syncthreads();
+    const int col = tid & (kSsTile - 1), py = Y0 + col;
+    for (int r0 = tid >> 7; r0 < kSsTile; r0 += 16) {  // eight rows in flight
+        float sim[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int px = X0 + r0 + 2 * u;
+            sim[u] = (py < g.imgExt && py >= px) ? g.simOut[(long long)px * g.imgExt + py] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int px = X0 + r0 + 2 * u;
+            if (py < g.imgExt && py >= px &&
+                gray_color(sim[u] - kSsSimErr, g.warp, g.scale, g.inv) !=
+                    gray_color(sim[u] + kSsSimErr, g.warp, g.scale, g.inv)) {
+                const int mine = atomicAdd(&count, 1);
+                if (mine < kLocal) {
+                    hits[mine] = (r0 + 2 * u) | (col << 8);
+                } else {
+                    const unsigned long long slot = atomicAdd(g.fixCount, 1ull);
+                    if (slot < (unsigned long long)g.fixCap) g.fixList[slot] = make_int2(px, py);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int n = min(count, kLocal);
+    if (n == 0) return;
+    if (tid == 0) base = atomicAdd(g.fixCount, (unsigned long long)n);
+    __syncthreads();
+    for (int i = tid; i < n; i += 256)
+        if (base + (unsigned long long)i < (unsigned long long)g.fixCap)
+            g.fixList[base + (unsigned long long)i] = make_int2(X0 + (hits[i] & 255), Y0 + (hits[i] >> 8));
+}
+
+// Quotient of correlateHalf (impl/MathUtil.scala:80-99) from one-pass sums over values shifted by one of the
+// window's own (d = v - m0): S = sum d over both halves, Q = sum d^2, X = sum da db give
+//     sum (v - mean)^2 = Q - S^2 / 2n,   sum (a - mean)(b - mean) = X - S^2 / 4n.
+// Returns it before its rounding to float and, in `tol`, a bound on how far the sequential evaluation in the
+// reference's order can be from it: the sums carry at most g = (3 t + 8) 2^-53 relative to Q each (t = the terms
+// one lane added up), which the subtraction amplifies by Q / var (at most 1 + 2n, about 2 for ordinary windows):
+// 4 g (Q / var) (1 + |r|); the sequential two-pass sums over 2n terms: 4 n 2^-53 (1 + |r|); doubled.  tol is NaN
+// when the bound does not apply (no variance, non-finite values).
+__device__ __forceinline__ double shifted_quotient(double S, double Q, double X, int n, int laneTerms, double &tol)
+{
+    const double n2 = 2.0 * n;
+    const double var = Q - S * S / n2, cross = X - S * S / (2.0 * n2);
+    const double stdDev = sqrt(var / n2);
+    const double r = cross / (stdDev * stdDev * n);
+    const double u53 = 1.1102230246251565e-16;
+    const double g = (3.0 * laneTerms + 8.0) * u53;
+    tol = var > 0.0 ? 2.0 * (4.0 * g * (Q / var) + 4.0 * n * u53) * (1.0 + fabs(r)) : NAN;
+    return r;
+}
+
+// v of another lane of the same row of 16: kCtrl 0xB1 / 0x4E = the lane 1 / 2 apart (quad permutations 1,0,3,2 and
+// 2,3,0,1), 0x141 / 0x140 = the mirror image within 8 / 16 lanes.
+template <int kCtrl>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), kCtrl, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), kCtrl, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+// float(v) when every fp64 value within tol of v rounds to the same float (then the sequential evaluation, which
+// lies in that interval, rounds to it as well); false otherwise.
+__device__ __forceinline__ bool certain_float(double v, double tol, float &out)
+{
+    out = (float)v;
+    if (!(fabs(v) < 1.0e300 && tol < 1.0e300)) return false;  // also NaN
+    return __float_as_int((float)(v - tol)) == __float_as_int((float)(v + tol));
+}
+
+// The listed pixels (or, without a list, every pixel with y >= x) as the reference computes them
 // (impl/SelfSimilarityImpl.scala:143-150, MathUtil.correlateHalf): similarity, gray level, both mirror positions.
+// One wave per pixel.  The frames of a channel are dealt over the lanes, eight channels (32 loads a lane) in
+// flight, both channel groups in the same pass; a quotient so close to where fp32 rounding flips that the changed
+// order of operations could matter is left to selfsim_seq_kernel (a few in 10^4), which evaluates it in the
+// reference's own order.
 __global__ __launch_bounds__(256) void selfsim_fix_kernel(SelfSimArgs g, const int2 *__restrict__ list,
                                                           const unsigned long long *__restrict__ count, long long total)
 {
+    const int lane = threadIdx.x & 63;
     const long long n = list ? min((long long)*count, g.fixCap) : total;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const long long step = (long long)gridDim.x * 4;
+    const bool doT = g.wT > 0.0f, doS = g.wT < 1.0f;
+    const int chEnd = doS ? g.numCh : 1, H = g.H;
+    long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    int2 next = make_int2(0, 0);
+    if (list && i < n) next = list[i];
+    for (; i < n; i += step) {
         int px, py;
         if (list) {
-            px = list[i].x;
-            py = list[i].y;
+            px = next.x;
+            py = next.y;
+            if (i + step < n) next = list[i + step];  // on its way while this pixel is worked on
         } else {
             px = (int)(i / g.imgExt);
             py = (int)(i - (long long)px * g.imgExt);
             if (py < px) continue;
         }
+        // the same for every lane: said so, the addresses below are scalar work
+        px = __builtin_amdgcn_readfirstlane(px);
+        py = __builtin_amdgcn_readfirstlane(py);
         const long long left = (long long)g.afStart + (long long)px * g.decim;
         const long long right = (long long)g.afStart + (long long)py * g.decim;
+        // shifts: the first value of each group's window
+        const float m0Tf = g.x1[left], m0Sf = g.x1[g.frames1 + left];
+        const double m0T = (double)m0Tf, m0S = (double)m0Sf;
+        double ST = 0.0, QT = 0.0, XT = 0.0, SS = 0.0, QS = 0.0, XS = 0.0;
+        for (int kb = lane; kb < H; kb += 128) {
+            const bool far = kb + 64 < H;
+            for (int cb = 0; cb < chEnd; cb += 8) {
+                float a[2][8], b[2][8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int c = cb + u;
+                    const bool have = c < chEnd;
+                    const float fill = c == 0 ? m0Tf : m0Sf;  // a value equal to the shift adds nothing to any sum
+                    const float *pa = g.x1 + (long long)c * g.frames1 + left + kb;
+                    const float *pb = g.x2 + (long long)c * g.frames2 + right + kb;
+                    a[0][u] = have ? pa[0] : fill;
+                    b[0][u] = have ? pb[0] : fill;
+                    a[1][u] = have && far ? pa[64] : fill;
+                    b[1][u] = have && far ? pb[64] : fill;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+#pragma unroll
+                    for (int j = 0; j < 2; j++) {
+                        if (cb + u == 0) {
+                            const double da = (double)a[j][u] - m0T, db = (double)b[j][u] - m0T;
+                            ST += da + db;
+                            QT = fma(da, da, fma(db, db, QT));
+                            XT = fma(da, db, XT);
+                        } else {
+                            const double da = (double)a[j][u] - m0S, db = (double)b[j][u] - m0S;
+                            SS += da + db;
+                            QS = fma(da, da, fma(db, db, QS));
+                            XS = fma(da, db, XS);
+                        }
+                    }
+                }
+            }
+        }
+        // butterflies of all six sums side by side: within a row of 16 lanes by lane permutations in the
+        // registers (partners 1 and 2 apart, then the mirror image within 8 and within 16), across rows by shuffles
+        auto fold = [&](auto partner) {
+            const double s0 = partner(ST), s1 = partner(QT), s2 = partner(XT);
+            const double s3 = partner(SS), s4 = partner(QS), s5 = partner(XS);
+            ST += s0, QT += s1, XT += s2, SS += s3, QS += s4, XS += s5;
+        };
+        fold([](double v) { return dpp_f64<0xB1>(v); });
+        fold([](double v) { return dpp_f64<0x4E>(v); });
+        fold([](double v) { return dpp_f64<0x141>(v); });
+        fold([](double v) { return dpp_f64<0x140>(v); });
+        fold([](double v) { return __shfl_xor(v, 16); });
+        fold([](double v) { return __shfl_xor(v, 32); });
+        const int laneSteps = 2 * ((H + 127) / 128);
         float temporal = 0.0f, spectral = 0.0f;
-        if (g.wT > 0.0f) temporal = correlate_half_dev(g.x1, g.frames1, left, g.x2, g.frames2, right, g.H, 0, 0, 1);
-        if (g.wT < 1.0f) spectral = correlate_half_dev(g.x1, g.frames1, left, g.x2, g.frames2, right, g.H, 0, 1, g.numCh);
+        double tol;
+        int redo = 0;
+        if (doT && !certain_float(shifted_quotient(ST, QT, XT, H, laneSteps, tol), tol, temporal)) redo |= 1;
+        if (doS && !certain_float(shifted_quotient(SS, QS, XS, (g.numCh - 1) * H, laneSteps * (g.numCh - 1), tol), tol,
+                                  spectral))
+            redo |= 2;
+        if (redo) {
+            unsigned int slot = 0;
+            if (lane == 0) slot = atomicAdd(g.seqCount, 1u);
+            slot = __shfl(slot, 0);
+            if (slot < g.seqCap) {
+                if (lane == 0) g.seqList[slot] = SelfSimSeq{px, py, temporal, spectral, redo, 0};
+                continue;
+            }
+            // the list is full: here and now, however long the walk through global memory takes
+            if (redo & 1) temporal = correlate_half_exact(g.x1, g.frames1, left, g.x2, g.frames2, right, H, 0, 1);
+            if (redo & 2) spectral = correlate_half_exact(g.x1, g.frames1, left, g.x2, g.frames2, right, H, 1, g.numCh);
+        }
+        if (lane != 0) continue;
         const float sim = temporal * g.wT + spectral * (1.0f - g.wT);
         const int colr = gray_color(sim, g.warp, g.scale, g.inv);
         g.imgOut[(long long)(g.imgExt - 1 - px) * g.imgExt + py] = colr;
@@ -455,6 +633,48 @@ __global__ __launch_bounds__(256) void selfsim_fix_kernel(SelfSimArgs g, const i
         if (g.wantSim) {
             g.simOut[(long long)px * g.imgExt + py] = sim;
             g.simOut[(long long)py * g.imgExt + px] = sim;
+        }
+    }
+}
+
+// The pixels selfsim_fix_kernel left over: correlateHalf in the reference's order, one wave per pixel.  The
+// additions of that order depend on each other, so what counts is the latency of a value: the window of the
+// group is staged in LDS first (ldsFloats = 2 * channels * H of the larger group, 0 when that does not fit; the
+// walk then reads global memory).
+__global__ __launch_bounds__(64) void selfsim_seq_kernel(SelfSimArgs g, int ldsFloats)
+{
+    extern __shared__ float win[];
+    const unsigned int n = min(*g.seqCount, g.seqCap);
+    const int lane = threadIdx.x, H = g.H;
+    for (unsigned int i = blockIdx.x; i < n; i += gridDim.x) {
+        const SelfSimSeq e = g.seqList[i];
+        const long long left = (long long)g.afStart + (long long)e.px * g.decim;
+        const long long right = (long long)g.afStart + (long long)e.py * g.decim;
+        float part[2] = {e.temporal, e.spectral};
+        for (int group = 0; group < 2; group++) {
+            if (!(e.redo & (1 << group))) continue;
+            const int c0 = group, c1 = group == 0 ? 1 : g.numCh;
+            if (2 * (c1 - c0) * H <= ldsFloats) {
+                __syncthreads();
+                for (int c = c0; c < c1; c++)
+                    for (int k = lane; k < H; k += 64) {
+                        win[(c - c0) * 2 * H + k] = g.x1[(long long)c * g.frames1 + left + k];
+                        win[(c - c0) * 2 * H + H + k] = g.x2[(long long)c * g.frames2 + right + k];
+                    }
+                __syncthreads();
+                part[group] = correlate_half_dev(win, 2 * H, 0, win, 2 * H, H, H, 0, 0, c1 - c0);
+            } else {
+                part[group] = correlate_half_exact(g.x1, g.frames1, left, g.x2, g.frames2, right, H, c0, c1);
+            }
+        }
+        if (lane != 0) continue;
+        const float sim = part[0] * g.wT + part[1] * (1.0f - g.wT);
+        const int colr = gray_color(sim, g.warp, g.scale, g.inv);
+        g.imgOut[(long long)(g.imgExt - 1 - e.px) * g.imgExt + e.py] = colr;
+        g.imgOut[(long long)(g.imgExt - 1 - e.py) * g.imgExt + e.px] = colr;
+        if (g.wantSim) {
+            g.simOut[(long long)e.px * g.imgExt + e.py] = sim;
+            g.simOut[(long long)e.py * g.imgExt + e.px] = sim;
         }
     }
 }
@@ -575,7 +795,7 @@ int sgz_selfsim_run(sgz_context *ctx, const float *frames1, int64_t num_frames1,
     const size_t pix = (size_t)img_ext * img_ext;
     // the reference skips a group whose weight is 0 (:143-145)
     const bool doT = temporal_weight > 0.0f, doS = temporal_weight < 1.0f || !doT;
-    if (sim_out || (doT && doS)) SGZ_HIP(ctx, hipMalloc(&simd.p, pix * sizeof(float)));
+    if (sim_out || img_out || (doT && doS)) SGZ_HIP(ctx, hipMalloc(&simd.p, pix * sizeof(float)));
     if (img_out) SGZ_HIP(ctx, hipMalloc(&imgd.p, pix * sizeof(int32_t)));
     DevBuf st1, st2, cols1, cols2;
     const unsigned gt = (unsigned)((img_ext + kSsTile - 1) / kSsTile);
@@ -620,6 +840,7 @@ int sgz_selfsim_run(sgz_context *ctx, const float *frames1, int64_t num_frames1,
     a.inv = color_inv;
     a.simOut = (float *)simd.p;
     a.wantSim = sim_out ? 1 : 0;
+    a.keepUpper = (sim_out || img_out) ? 1 : 0;
     a.imgOut = (int *)imgd.p;
     a.wT = temporal_weight;
     // Gray levels are integer work: a pixel whose level the similarity's error bound could change is listed and
@@ -634,11 +855,22 @@ int sgz_selfsim_run(sgz_context *ctx, const float *frames1, int64_t num_frames1,
     a.fixCount = nullptr;
     a.fixList = nullptr;
     a.fixCap = fixCap;
+    DevBuf seqd;
+    a.seqCount = nullptr;
+    a.seqList = nullptr;
+    a.seqCap = 1u << 20;
+    // LDS of selfsim_seq_kernel: both halves of the larger channel group, when 64 KB hold them
+    const size_t seqWin = 2 * (size_t)std::max(1, num_channels - 1) * half_win;
+    const int seqLds = seqWin * sizeof(float) <= 65536 ? (int)seqWin : 0;
     if (img_out) {
         SGZ_HIP(ctx, hipMalloc(&fixd.p, sizeof(int2) * (size_t)(fixCap + 1)));
         SGZ_HIP(ctx, hipMemsetAsync(fixd.p, 0, sizeof(int2), ctx->stream));
         a.fixCount = reinterpret_cast<unsigned long long *>(fixd.p);
         a.fixList = reinterpret_cast<int2 *>(fixd.p) + 1;
+        SGZ_HIP(ctx, hipMalloc(&seqd.p, sizeof(SelfSimSeq) * ((size_t)a.seqCap + 1)));
+        SGZ_HIP(ctx, hipMemsetAsync(seqd.p, 0, sizeof(SelfSimSeq), ctx->stream));
+        a.seqCount = reinterpret_cast<unsigned int *>(seqd.p);
+        a.seqList = reinterpret_cast<SelfSimSeq *>(seqd.p) + 1;
     }
     if (doT) {
         a.c0 = 0;
@@ -659,17 +891,23 @@ int sgz_selfsim_run(sgz_context *ctx, const float *frames1, int64_t num_frames1,
         SGZ_HIP(ctx, hipGetLastError());
     }
     if (img_out) {
+        hipLaunchKernelGGL(selfsim_list_kernel, dim3(gt * gt), dim3(256), 0, ctx->stream, a);
+        SGZ_HIP(ctx, hipGetLastError());
         hipLaunchKernelGGL(selfsim_fix_kernel, dim3(2048), dim3(256), 0, ctx->stream, a, (const int2 *)a.fixList,
                            (const unsigned long long *)a.fixCount, 0ll);
         SGZ_HIP(ctx, hipGetLastError());
         unsigned long long listed = 0;
         SGZ_HIP(ctx, hipMemcpyAsync(&listed, a.fixCount, sizeof listed, hipMemcpyDeviceToHost, ctx->stream));
         SGZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (listed > (unsigned long long)fixCap) {  // more than the list holds: every pixel in the reference's order
+        if (listed > (unsigned long long)fixCap) {  // more than the list holds: every pixel that way
+            SGZ_HIP(ctx, hipMemsetAsync(a.seqCount, 0, sizeof(unsigned int), ctx->stream));
             hipLaunchKernelGGL(selfsim_fix_kernel, dim3(8192), dim3(256), 0, ctx->stream, a, (const int2 *)nullptr,
                                (const unsigned long long *)nullptr, (long long)pix);
             SGZ_HIP(ctx, hipGetLastError());
         }
+        hipLaunchKernelGGL(selfsim_seq_kernel, dim3(4096), dim3(64), (size_t)seqLds * sizeof(float), ctx->stream, a,
+                           seqLds);
+        SGZ_HIP(ctx, hipGetLastError());
     }
     int rc;
     if (sim_out && (rc = copy_large(ctx, sim_out, simd.p, pix * sizeof(float), true))) return rc;

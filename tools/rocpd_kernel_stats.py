@@ -6,6 +6,22 @@ import sqlite3
 import sys
 
 
+def short(name: str) -> str:
+    """Kernel name without the anonymous namespace, the return type and the argument list."""
+    name = name.replace("(anonymous namespace)::", "")
+    if name.startswith("void "):
+        name = name[5:]
+    depth = 0
+    for i, ch in enumerate(name):
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            return name[:i][:90]
+    return name[:90]
+
+
 def main() -> int:
     db = sqlite3.connect(sys.argv[1])
     rows = db.execute(
@@ -15,7 +31,7 @@ def main() -> int:
     out = csv.writer(open(sys.argv[2], "w", newline="") if len(sys.argv) > 2 else sys.stdout)
     out.writerow(["kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "percent"])
     for name, n, tot, avg, mn, mx in rows:
-        out.writerow([name.split("(")[0][:90], n, f"{tot / 1e3:.1f}", f"{avg / 1e3:.2f}", f"{mn / 1e3:.2f}", f"{mx / 1e3:.2f}",
+        out.writerow([short(name), n, f"{tot / 1e3:.1f}", f"{avg / 1e3:.2f}", f"{mn / 1e3:.2f}", f"{mx / 1e3:.2f}",
                       f"{100.0 * tot / total:.2f}"])
     return 0
 
