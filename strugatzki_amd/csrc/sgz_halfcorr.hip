@@ -209,6 +209,7 @@ struct SelfSimArgs {
     unsigned int *seqCount;
     struct SelfSimSeq *seqList;
     unsigned int seqCap;
+    int forceSeq;  // test knob: every listed pixel goes that way
 };
 
 struct SelfSimSeq {
@@ -613,6 +614,7 @@ __global__ __launch_bounds__(256) void selfsim_fix_kernel(SelfSimArgs g, const i
         if (doS && !certain_float(shifted_quotient(SS, QS, XS, (g.numCh - 1) * H, laneSteps * (g.numCh - 1), tol), tol,
                                   spectral))
             redo |= 2;
+        if (g.forceSeq) redo = (doT ? 1 : 0) | (doS ? 2 : 0);
         if (redo) {
             unsigned int slot = 0;
             if (lane == 0) slot = atomicAdd(g.seqCount, 1u);
@@ -859,6 +861,11 @@ int sgz_selfsim_run(sgz_context *ctx, const float *frames1, int64_t num_frames1,
     a.seqCount = nullptr;
     a.seqList = nullptr;
     a.seqCap = 1u << 20;
+    a.forceSeq = 0;
+    if (const char *e = std::getenv("SGZ_SELFSIM_SEQ")) {  // test knob: "force[,capacity]"
+        a.forceSeq = std::strncmp(e, "force", 5) == 0;
+        if (const char *c = std::strchr(e, ',')) a.seqCap = (unsigned)std::max(0ll, std::atoll(c + 1));
+    }
     // LDS of selfsim_seq_kernel: both halves of the larger channel group, when 64 KB hold them
     const size_t seqWin = 2 * (size_t)std::max(1, num_channels - 1) * half_win;
     const int seqLds = seqWin * sizeof(float) <= 65536 ? (int)seqWin : 0;

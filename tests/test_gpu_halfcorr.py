@@ -83,6 +83,25 @@ def test_selfsim_image_when_the_fix_list_overflows(ctx, monkeypatch):
     assert np.array_equal(sim, want_sim)  # (then the similarities are the reference-order ones as well)
 
 
+@pytest.mark.parametrize("knob,corr_frames,num_frames,decim", [("force", 6, 300, 1), ("force,5", 6, 300, 1),
+                                                              ("force", 700, 2300, 16)])
+def test_selfsim_pixels_that_need_the_sequential_order(ctx, monkeypatch, knob, corr_frames, num_frames, decim):
+    """A quotient too close to an fp32 rounding boundary is evaluated in the reference's order of additions by a
+    kernel of its own (through LDS; from global memory when the window is larger than LDS, here 700 frames; by
+    the first kernel itself when their list is full, here 5 entries).  Rare on real data, so forced here for every
+    pixel (SGZ_SELFSIM_SEQ, with a fix list of 3 entries so that every pixel is looked at)."""
+    frames = _frames(num_frames)
+    norms = norms_default()
+    cfg = O.SelfSimConfig(0, 0, 0, 0, corr_frames * STEP, decim, 0.5, 0, 1.0, 1.0, 0, 1, STEP, NUM_CH - 1)
+    ext, d, af_start, _ = O.selfsim_geometry(cfg, frames.shape[0], frames.shape[0])
+    want_sim, want_img = O.selfsim_run(cfg, frames, None, norms)
+    monkeypatch.setenv("SGZ_SELFSIM_FIX_CAP", "3")
+    monkeypatch.setenv("SGZ_SELFSIM_SEQ", knob)
+    sim, img = ctx.selfsim(frames, None, norms, af_start, corr_frames, d, ext, 0.5)
+    assert ext > 50 and np.array_equal(img, want_img)
+    assert np.array_equal(sim, want_sim)
+
+
 def test_cross_file_similarity(ctx):
     """metaInput2: left windows from file 1, right windows from file 2 (impl/SelfSimilarityImpl.scala:131-141)."""
     f1, f2 = _frames(200, 3), _frames(180, 9)
