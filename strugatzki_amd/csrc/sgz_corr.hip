@@ -1186,6 +1186,16 @@ int build_layout(sgz_context *ctx)
     ctx->h_tiles_h.clear();
     ctx->tile_h_begin.assign(nf + 1, 0);
     const bool halfOk = ctx->hg.S2 > 0;
+    if (halfOk) {  // tile width of the matrix-core kernel for these files and this target
+        std::vector<long long> nw((size_t)nf);
+        for (int f = 0; f < nf; f++) {
+            const long long fr = std::max<long long>(ctx->files[f].frames - ctx->tail_trim, 0);
+            nw[(size_t)f] = fr >= L ? fr - L + 1 : (fr > 0 ? 1 : 0);
+        }
+        int rcp;
+        if ((rcp = half_screen_pick_tile(ctx, nw.data(), nf))) return rcp;
+    }
+    const long long kHTileW = 256ll * (halfOk ? ctx->hg.NB : kHNB);
     ctx->tile_begin.assign(nf + 1, 0);
     ctx->ptile_begin.assign(nf + 1, 0);
     ctx->prep_cb = pick_prep_cb(ctx->numCh);

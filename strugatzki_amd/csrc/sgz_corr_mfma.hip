@@ -11,9 +11,12 @@
 // (one "step" s: kk = 32 s .. 32 s + 31) with the 32 x 16 slice of X of one
 // column tile (16 chunks).  The operand of tile t at step s is the operand of
 // tile t + 1 at step s - 8, so wave q of a workgroup takes the steps
-// s = q, q + 8, q + 16, ... and keeps a sliding window of kHNB operands in
+// s = q, q + 8, q + 16, ... and keeps a sliding window of NB operands in
 // registers: every step costs one 16-byte LDS read of database frames and one
-// target operand for kHNB matrix instructions.
+// target operand for NB matrix instructions.  NB (the width of a workgroup's tile,
+// 256 NB windows) is a template parameter: which width wastes the fewest matrix
+// instructions on the empty end of a file's last tile, and fills the last round of
+// workgroups best, depends on the file lengths and the target (half_screen_pick_tile).
 //
 // The products are half precision (11 significant bits), the sums fp32; window
 // means and std-devs still come from the fp64 prefix sums.  The result is a
@@ -25,7 +28,9 @@
 #include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -40,7 +45,8 @@ using half8 = __attribute__((ext_vector_type(8))) _Float16;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int kHThreads = kHWaves * 64;
-constexpr int kHSlabFloats = kHTileW + kHTileW / 8;  // one partial sum per window of a tile, skewed (see reduce)
+// one partial sum per window of a tile, skewed (see reduce)
+__host__ __device__ constexpr int half_slab_floats(int NB) { return NB * 256 + NB * 32; }
 
 // Relative error of a cross term of `channels` channels, against sum |a'| |b|.  Two half-precision roundings per
 // product (target and database value, 2^-11 each: (1 + 2^-11)^2 - 1 = 2^-10 + 2^-22; the product of two
@@ -59,19 +65,23 @@ float half_rel_err(int channels, int S2)
 // (+1 KiB: the operand requests of the step past the last one stay inside the buffer).
 __host__ __device__ constexpr int half_x_pieces(int XU) { return (XU + 63) >> 6; }
 __host__ __device__ constexpr int half_a_pieces(int LAd) { return (LAd / 2 + 63) >> 6; }
-__host__ __device__ constexpr size_t half_buf_bytes(int XU, int LAd)
+__host__ __device__ constexpr size_t half_buf_bytes(int XU, int LAd, int NB)
 {
     const size_t bytes = (size_t)1024 * (half_x_pieces(XU) + half_a_pieces(LAd) + 1);
     // once a buffer's channel is consumed it holds two slabs of partial sums and a few words
-    const size_t sums = 2 * kHSlabFloats * sizeof(float) + 1024;
+    const size_t sums = 2 * half_slab_floats(NB) * sizeof(float) + 1024;
     return bytes > sums ? bytes : sums;
 }
 
 typedef __attribute__((address_space(3))) void lds_void;
 
-size_t half_lds_bytes(const HalfGeom &hg) { return 2 * half_buf_bytes(hg.XU, hg.LAd); }
+size_t half_lds_bytes(const HalfGeom &hg) { return 2 * half_buf_bytes(hg.XU, hg.LAd, hg.NB); }
 
-// Workgroup = 8 waves, one tile of kHTileW consecutive windows of one file.
+// Workgroups per CU a variant is built for: up to 5 column tiles per wave the loop fits 80 registers and three
+// workgroups share a CU (when their LDS does, too), above that two.
+constexpr int half_wgs_per_cu(int NB) { return NB <= 5 ? 3 : 2; }
+
+// Workgroup = 8 waves, one tile of 256 NB consecutive windows of one file.
 // Per channel the workgroup stages (double buffered) the frames
 // [o0, o0 + 8 XU) of the file in natural order and the two dword-aligned
 // copies of the target channel (even shifts read copy 0, odd shifts copy 1,
@@ -79,20 +89,21 @@ size_t half_lds_bytes(const HalfGeom &hg) { return 2 * half_buf_bytes(hg.XU, hg.
 // (buffer_load_dwordx4 ... lds: per-lane source offset, destination = wave-uniform
 // base + 16 * lane), issued a phase ahead and retired by the barrier that ends
 // the phase, so no registers hold data in flight.
-__global__ __launch_bounds__(kHThreads, 4) void corr_mfma_kernel(
+template <int NB>
+__global__ __launch_bounds__(kHThreads, 2 * half_wgs_per_cu(NB)) void corr_mfma_kernel(
     const FileDesc *__restrict__ files, const TileDesc *__restrict__ tiles, const _Float16 *__restrict__ planarH,
     const float4 *__restrict__ prefix, const double *__restrict__ tbase, const uint32_t *__restrict__ aimg,
     CorrParams cp, HalfGeom hg, float *__restrict__ simOut, float *__restrict__ boostOut, float *__restrict__ loOut,
     int *__restrict__ lokey, int *__restrict__ lokeyNext, int *__restrict__ hflags)
 {
-    constexpr int NB = kHNB;
+    constexpr int kHTileW = NB * 256, kHSlabFloats = half_slab_floats(NB);
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
     const TileDesc td = tiles[blockIdx.x];
     const FileDesc fd = files[td.file];
-    const size_t bufBytes = half_buf_bytes(hg.XU, hg.LAd);
+    const size_t bufBytes = half_buf_bytes(hg.XU, hg.LAd, NB);
     const long long rowLen = fd.M * kR;
     const _Float16 *fplanar = planarH + fd.planar_off + td.o0;
 
@@ -163,7 +174,7 @@ __global__ __launch_bounds__(kHThreads, 4) void corr_mfma_kernel(
 
     stage(channel_of(0), 0);
 
-    constexpr int kPerThread = kHTileW / kHThreads;
+    constexpr int kPerThread = (kHTileW + kHThreads - 1) / kHThreads;  // (the last one of an odd NB: half the threads)
     __syncthreads();
 
     f32x4 acc[NB];
@@ -207,6 +218,7 @@ __global__ __launch_bounds__(kHThreads, 4) void corr_mfma_kernel(
                     acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u & 1], h[(u + t) % NB], acc[t], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if constexpr (NB % 2 != 0) a[0] = a[1];  // the next block starts with slot 0 again
         }
 #pragma unroll
         for (int u = 0; u < NB - 1; u++) {
@@ -253,7 +265,7 @@ __global__ __launch_bounds__(kHThreads, 4) void corr_mfma_kernel(
 #pragma unroll
     for (int k = 0; k < kPerThread; k++) {
         const long long o = (long long)td.o0 + tid + k * kHThreads;
-        rec[k] = window_records(hp, o < fd.num_windows ? (unsigned)o : 0u, cp.L);
+        rec[k] = window_records(hp, (tid + k * kHThreads < kHTileW && o < fd.num_windows) ? (unsigned)o : 0u, cp.L);
     }
     reduce(redT4, acc);
     if (useTab) {  // behind the two slabs of the loudness sums
@@ -272,7 +284,7 @@ __global__ __launch_bounds__(kHThreads, 4) void corr_mfma_kernel(
     for (int k = 0; k < kPerThread; k++) {
         const int wdw = tid + k * kHThreads;
         const long long o = (long long)td.o0 + wdw;
-        if (o < fd.num_windows) {
+        if (wdw < kHTileW && o < fd.num_windows) {
             float sim, lo;
             float boost;
             const WindowCoeffs wc = window_coeffs(cph, hp, (unsigned)o, rec[k], (double)fd.cT, hg.relErrT, hg.relErrS, boost);
@@ -315,14 +327,18 @@ __global__ __launch_bounds__(kHThreads, 4) void corr_mfma_kernel(
 
 namespace sgz {
 
+// tile widths (column tiles per wave) a kernel exists for; the first is the default
+constexpr int kHalfWidths[] = {kHNB, 4, 5, 6, 7, 9, 10};
+
 // Geometry for a target of L frames; false when one staged channel does not fit
 // the kernel's registers / LDS (the caller then screens with the fp32 kernel).
-static bool half_geom(int L, HalfGeom &hg)
+static bool half_geom(int L, int NB, HalfGeom &hg)
 {
     const int S2 = (L + 15 + 31) / 32;
     const int Pmax = (S2 + 7) / 8;
     const int LAd = 128 * Pmax + 16;  // all 8 Pmax steps of 16 dwords + the shift room; = 16 mod 32
-    const int XU = 32 * (Pmax + kHNB);
+    const int XU = 32 * (Pmax + NB);
+    hg.NB = NB;
     hg.S2 = S2;
     hg.LAd = LAd;
     hg.XU = XU;
@@ -335,7 +351,51 @@ bool half_screen_fits(const sgz_context *ctx)
 {
     HalfGeom hg{};
     // Half precision needs a bounded value range: only normalised features qualify.
-    return ctx->have_target && ctx->norm.enabled && half_geom(ctx->cp.L, hg);
+    return ctx->have_target && ctx->norm.enabled && half_geom(ctx->cp.L, kHalfWidths[0], hg);
+}
+
+// The tile width for the files and the target of the context's layout: the variant with the smallest estimate of
+// the kernel's time.  A file of C column tiles costs ceil(C / NB) tiles, whatever part of the last one's columns
+// is empty, and a tile NB + 1.2 column times (start, reductions and epilogue are worth 1.2 columns).  The chip
+// holds CUs * k tiles at once (k workgroups per CU: 3 up to NB = 5 if their LDS fits, else 2) and works them off
+// in rounds; the workgroups of a CU share its matrix pipe, so a round of k per CU takes t(k) = 0.55, 1, 1.5 tile
+// times for k = 1, 2, 3, and the last round only as long as its fullest CU needs:
+//     (full rounds * t(k) + t(ceil(tiles left / CUs))) * (NB + 1.2).
+// Within 2 % of the measured order of the variants for 120 files of 91 columns (30 s target) and 1500 files of
+// 81 columns (60 s target): 8 resp. 9 win there, 9 by 8 % over 8.  SGZ_HALF_NB=<n> overrides the choice.
+int half_screen_pick_tile(sgz_context *ctx, const long long *numWindows, int numFiles)
+{
+    if (ctx->hg.S2 <= 0) return SGZ_OK;
+    int numCUs = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0)
+        numCUs = prop.multiProcessorCount;
+    int forced = 0;
+    if (const char *e = std::getenv("SGZ_HALF_NB")) forced = std::atoi(e);
+    double bestCost = 0.0;
+    HalfGeom best{};
+    bool have = false;
+    for (int nb : kHalfWidths) {
+        HalfGeom hg = ctx->hg;
+        if (!half_geom(ctx->cp.L, nb, hg)) continue;
+        hg.relErrT = ctx->hg.relErrT;
+        hg.relErrS = ctx->hg.relErrS;
+        const int wgs = (int)std::min<size_t>((size_t)half_wgs_per_cu(nb), (160 * 1024) / half_lds_bytes(hg));
+        if (wgs < 1) continue;
+        long long tiles = 0;
+        for (int f = 0; f < numFiles; f++) tiles += (numWindows[f] + 256ll * nb - 1) / (256ll * nb);
+        const long long slots = (long long)numCUs * wgs;
+        const long long left = tiles % slots;
+        auto roundTime = [](long long perCU) { return perCU <= 0 ? 0.0 : perCU == 1 ? 0.55 : 0.5 * (double)perCU; };
+        const double cost = ((double)(tiles / slots) * roundTime(wgs) + roundTime((left + numCUs - 1) / numCUs)) * (nb + 1.2);
+        if (forced ? nb == forced : (!have || cost < bestCost * 0.995)) {  // (near ties: the earlier, wider default)
+            best = hg;
+            bestCost = cost;
+            have = true;
+        }
+    }
+    if (have) ctx->hg = best;
+    return SGZ_OK;
 }
 
 // Builds the two shifted half-precision copies of every target channel.
@@ -344,7 +404,10 @@ int half_screen_set_target(sgz_context *ctx, const std::vector<double> &aprime, 
 {
     HalfGeom hg{};
     const int L = ctx->cp.L, numCh = ctx->cp.numCh;
-    if (!half_geom(L, hg)) {
+    // the width in use stays (the layout is built for it; a new target length rebuilds the layout and picks again)
+    bool fits = ctx->hg.S2 > 0 && half_geom(L, ctx->hg.NB, hg);
+    for (size_t k = 0; !fits && k < sizeof kHalfWidths / sizeof kHalfWidths[0]; k++) fits = half_geom(L, kHalfWidths[k], hg);
+    if (!fits) {
         ctx->hg = HalfGeom{};
         return SGZ_OK;
     }
@@ -394,16 +457,27 @@ int half_screen_launch(sgz_context *ctx, int tile_begin, int tile_end, hipStream
     ctx->lokey_clean[1 - par] = whole || ctx->lokey_clean[1 - par];
     ctx->lokey_cur = lokey;
     ctx->lokey_parity = 1 - par;
-    auto kern = corr_mfma_kernel;
-    if (ldsBytes > 64 * 1024)
-        SGZ_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
-    hipExtLaunchKernelGGL(kern, dim3(tile_end - tile_begin), dim3(kHThreads), ldsBytes, stream, start, stop, 0,
-                          ctx->d_files, ctx->d_tiles_h + tile_begin, planarH,
-                          reinterpret_cast<const float4 *>(ctx->d_prefix_h), ctx->d_tbase_h, aimg, ctx->cp, hg, ctx->d_sim,
-                          ctx->d_boost, ctx->d_lo, lokey, lokeyNext, ctx->d_hflags);
-    SGZ_HIP(ctx, hipGetLastError());
-    return SGZ_OK;
+    auto launch = [&](auto kern) -> int {
+        if (ldsBytes > 64 * 1024)
+            SGZ_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
+        hipExtLaunchKernelGGL(kern, dim3(tile_end - tile_begin), dim3(kHThreads), ldsBytes, stream, start, stop, 0,
+                              ctx->d_files, ctx->d_tiles_h + tile_begin, planarH,
+                              reinterpret_cast<const float4 *>(ctx->d_prefix_h), ctx->d_tbase_h, aimg, ctx->cp, hg,
+                              ctx->d_sim, ctx->d_boost, ctx->d_lo, lokey, lokeyNext, ctx->d_hflags);
+        SGZ_HIP(ctx, hipGetLastError());
+        return SGZ_OK;
+    };
+    switch (hg.NB) {
+    case 4: return launch(corr_mfma_kernel<4>);
+    case 5: return launch(corr_mfma_kernel<5>);
+    case 6: return launch(corr_mfma_kernel<6>);
+    case 7: return launch(corr_mfma_kernel<7>);
+    case 8: return launch(corr_mfma_kernel<8>);
+    case 9: return launch(corr_mfma_kernel<9>);
+    case 10: return launch(corr_mfma_kernel<10>);
+    default: return ctx->fail(SGZ_E_STATE, "no matrix-core kernel of that tile width");
+    }
 }
 
 }  // namespace sgz

@@ -68,11 +68,11 @@ struct CorrParams {
 };
 
 // ---- geometry of the half-precision matrix-core screening kernel ----------------
-constexpr int kHNB = 8;                 // 16x16 output tiles per wave (columns of 16 chunks each)
-constexpr int kHTileW = kHNB * 256;     // windows per workgroup tile
+constexpr int kHNB = 8;                 // 16x16 output tiles per wave (columns of 16 chunks each): the default
 constexpr int kHWaves = 8;              // waves per workgroup; wave q takes the 32-lag steps s = q, q + 8, ...
 
 struct HalfGeom {
+    int NB;    // column tiles per wave of the variant in use: a workgroup tile is 256 * NB windows
     int S2;    // 32-lag steps: 32 * S2 >= L + 15
     int LAd;   // dwords per shifted copy of one target channel (LAd % 32 == 16)
     int XU;    // 16-byte units of one staged channel block of database frames
@@ -237,6 +237,7 @@ struct sgz_context {
 namespace sgz {
 // sgz_corr_mfma.hip
 bool half_screen_fits(const sgz_context *ctx);
+int half_screen_pick_tile(sgz_context *ctx, const long long *numWindows, int numFiles);
 int half_screen_set_target(sgz_context *ctx, const std::vector<double> &aprime, size_t Lpad);
 int half_screen_launch(sgz_context *ctx, int tile_begin, int tile_end, hipStream_t stream, hipEvent_t start,
                        hipEvent_t stop);

@@ -175,6 +175,36 @@ def test_screening_f16_is_an_upper_bound(ctx, L, frames):
         assert abs(float(c["sim"]) - float(sims[c["file"]][c["offset"]])) <= 1.2e-7
 
 
+@pytest.mark.parametrize("nb", [4, 5, 6, 7, 9, 10])
+def test_screening_f16_tile_widths(ctx, monkeypatch, nb):
+    """The matrix-core kernel exists in several tile widths (256 * nb windows per workgroup; the library picks one
+    per database and target, SGZ_HALF_NB forces one): same bounds, same search result for each.  Files of one
+    window, of exactly one tile of the default width, one window more, and of several tiles."""
+    L, ts = 431, 20
+    frames = [L + 2 * 256 * nb + 77, L, L + 2047, L + 2048, 9000]
+    nf = len(frames)
+    db = [O.synth_file(SEED, g, frames[g], NUM_CH) for g in range(nf)]
+    tgt = synth_target(ts, L)
+    db[0][300:300 + L] = tgt[ts:ts + L] * np.float32(0.999) + db[0][300:300 + L] * np.float32(0.001)
+    db[4][8000:8000 + L] = tgt[ts:ts + L]
+    norms = norms_default()
+    want, sims, boosts = O.correlation_run(corr_config(ts, L, num_matches=4), tgt, norms, db)
+    monkeypatch.setenv("SGZ_HALF_NB", str(nb))
+    _load(ctx, db, norms)
+    ctx.corr_set_target(tgt[ts:ts + L], 0.5, 8.0)
+    ctx.corr_run_screen_f16(0, nf)
+    for f in range(nf):
+        gs, gb = ctx.corr_read_dense(f)
+        open_ = boosts[f] <= 8.0 * (1 - 1e-4)
+        d = gs.astype(np.float64) - sims[f]
+        assert gs.shape == sims[f].shape and np.all(d[open_] >= 0.0) and np.all(d[open_] <= 2e-2)
+    import strugatzki_amd as S
+    got = S.search(ctx, S.SearchParams(4, 1, 0, STEP))
+    assert [(g.sim, g.file, g.start, g.stop) for g in got] == [(w.sim, w.file, w.start, w.stop) for w in want]
+    monkeypatch.delenv("SGZ_HALF_NB")
+    _load(ctx, db[:1], norms)  # (the next test's layout picks its own width again)
+
+
 @pytest.mark.parametrize("L,frames", [(8000, 9300), (12498, 13400)])
 def test_screening_f16_bound_at_long_targets(ctx, L, frames):
     """The fp32 summation part of the bound grows with the target length (an output element passes through
