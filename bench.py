@@ -274,11 +274,15 @@ def main() -> int:
 
     # Cold step: the half-precision image, prefix records and centring constants of the database are built by the
     # first search after the database, the norms or the target length change and kept afterwards (the timed steps
-    # above are warm: a service answering queries against a resident database).  Here the norms are set again
-    # before each step, which discards that preparation (and the layout tables).
+    # above are warm: a service answering queries against a resident database).  Here other norms and then the
+    # right ones again are set before each step, which discards that preparation (and the layout tables; setting
+    # the norms already in force changes nothing).
     cold_ms = []
     if not sharded:
+        other = norms_default().copy()
+        other[:, 1] += 1.0
         for _ in range(5):
+            ctx.set_norms(other)
             ctx.set_norms(norms_default())
             ctx.corr_set_target(target, 0.5, 8.0)
             ctx.synchronize()

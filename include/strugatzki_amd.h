@@ -275,6 +275,19 @@ SGZ_API int sgz_corr_compact_bounded_device(sgz_context *ctx, int file_begin, in
                                             unsigned long long *device_count);
 SGZ_API int sgz_corr_compact_bounded(sgz_context *ctx, int file_begin, int file_end, int head_end,
                                      sgz_candidate *out, int64_t capacity, int64_t *count);
+/* sgz_corr_compact_bounded with every file of the context a head file, and one more filter: T = the
+ * num_top-th largest of the files' lower bounds (-inf when the context holds fewer than num_top files).  With
+ * numPerFile = 1 and num_top = numMatches the match set (impl/FeatureCorrelationImpl.scala:113-150: a sorted set
+ * of numMatches similarities, the worst one dropped when a better one arrives) ends with num_top entries >= T
+ * whenever num_top files reach T with distinct similarities; a file whose upper bounds all lie below T then
+ * cannot be in it, and none of its windows is collected or re-scored.  *threshold_out = T; the caller feeds the
+ * result through sgz_sel_feed_top, which checks that condition on the finished set.  The device variant writes
+ * the count to the first 8 bytes of `device_header` (16 bytes) and T, as a float, to its bytes 8..11. */
+SGZ_API int sgz_corr_compact_top_device(sgz_context *ctx, int file_begin, int file_end, int num_top,
+                                        sgz_candidate *device_out, int64_t capacity,
+                                        unsigned long long *device_header);
+SGZ_API int sgz_corr_compact_top(sgz_context *ctx, int file_begin, int file_end, int num_top, sgz_candidate *out,
+                                 int64_t capacity, int64_t *count, float *threshold_out);
 
 /* Milliseconds the GPU spent in the last sgz_corr_run's correlation kernel
  * (HIP events on the context's stream); < 0 if none has completed. */
@@ -381,6 +394,19 @@ SGZ_API int sgz_corr_search_multi(sgz_context *const *ctxs, int num_ctx, const i
  * the caller takes the exact path. */
 SGZ_API int sgz_sel_feed_screened(sgz_selector *sel, const sgz_candidate *cands, int64_t n, int head_files,
                                   int num_files);
+/* Feeds the exactly re-scored candidates of sgz_corr_compact_top (sorted by (file, offset)): per file that
+ * occurs its largest similarity, first occurrence, in file order.  Files without candidates were left out
+ * because everything of theirs lies below `threshold`; that is only sound when the finished set is full and
+ * its worst entry is not below `threshold` (equal similarities among the best files collapse into one entry
+ * and can leave room for a lesser file), which this call checks: SGZ_E_STATE otherwise, and for a NaN
+ * similarity; the selector must then be discarded and the caller takes sgz_corr_compact_bounded.
+ * threshold = -inf: no file was left out, nothing to check. */
+SGZ_API int sgz_sel_feed_top(sgz_selector *sel, const sgz_candidate *cands, int64_t n, float threshold);
+/* sgz_sel_feed_top over the blocks of a candidate exchange (layout as for sgz_sel_feed_gathered; bytes 8..11
+ * of a block's header row hold that rank's threshold, as sgz_corr_compact_top_device leaves it: a rank leaves
+ * out files below the num_top-th best of its own files, and the check uses the largest of the thresholds). */
+SGZ_API int sgz_sel_feed_gathered_top(sgz_selector *sel, const sgz_candidate *blocks, int world, int64_t rows,
+                                      const int32_t *maps, const int64_t *map_offsets);
 /* 1 once allPrio holds num_matches entries: from then on only windows with
  * sim > sgz_sel_threshold() can still be offered. */
 SGZ_API int sgz_sel_is_full(const sgz_selector *sel);

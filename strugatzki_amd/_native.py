@@ -111,6 +111,11 @@ SIGNATURES = {
     "sgz_corr_compact_rescored": (C.c_int, [_vp, C.c_int, C.c_int, C.c_float, _vp, C.c_int64, C.POINTER(C.c_int64)]),
     "sgz_corr_compact_bounded": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int64, C.POINTER(C.c_int64)]),
     "sgz_corr_compact_bounded_device": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int64, _vp]),
+    "sgz_corr_compact_top": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int64, C.POINTER(C.c_int64),
+                                       C.POINTER(C.c_float)]),
+    "sgz_corr_compact_top_device": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int64, _vp]),
+    "sgz_sel_feed_top": (C.c_int, [_vp, _vp, C.c_int64, C.c_float]),
+    "sgz_sel_feed_gathered_top": (C.c_int, [_vp, _vp, C.c_int, C.c_int64, _vp, _vp]),
     "sgz_corr_last_kernel_ms": (C.c_float, [_vp]),
     "sgz_last_kernel_ms": (C.c_float, [_vp]),
     "sgz_kernel_ms_history": (C.c_int, [_vp, _vp, C.c_int]),

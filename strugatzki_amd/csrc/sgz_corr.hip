@@ -894,8 +894,51 @@ __global__ __launch_bounds__(64) void bound_min_kernel(const int *__restrict__ l
     if (threadIdx.x == 0) out[0] = v;
 }
 
-// Windows of head files (file < headEnd) whose upper bound reaches the file's own bound, windows of the
-// other files whose upper bound exceeds the minimum of the head bounds (thr[headEnd]).
+// The k-th largest of the per-file bounds (lokey[0 .. n)), -inf when there are fewer than k files: with
+// numPerFile = 1 and k = numMatches, a file whose similarities all lie below it cannot be in the result when at
+// least k files reach it with distinct values (the caller checks that on the finished selection).  One
+// workgroup; radix selection over the order-preserving keys, a byte per round.
+__global__ __launch_bounds__(256) void bound_kth_kernel(const int *__restrict__ lokey, int n, int k, float *__restrict__ out)
+{
+    __shared__ int hist[256];
+    __shared__ unsigned int chosenPrefix;
+    __shared__ int chosenLeft;
+    const int tid = threadIdx.x;
+    if (n < k || k < 1) {
+        if (tid == 0) out[0] = -INFINITY;
+        return;
+    }
+    unsigned int prefix = 0, mask = 0;
+    int left = k;  // the wanted key is the left-th largest of those that match the prefix
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        hist[tid] = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += 256) {
+            const unsigned int u = (unsigned int)lokey[i] ^ 0x80000000u;
+            if ((u & mask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int above = 0, b = 255;
+            for (; b > 0; b--) {
+                if (above + hist[b] >= left) break;
+                above += hist[b];
+            }
+            chosenPrefix = prefix | ((unsigned int)b << shift);
+            chosenLeft = left - above;
+        }
+        __syncthreads();
+        prefix = chosenPrefix;
+        left = chosenLeft;
+        mask |= 255u << shift;
+        __syncthreads();
+    }
+    if (tid == 0) out[0] = bound_from_key((int)(prefix ^ 0x80000000u));
+}
+
+// Windows of head files (file < headEnd) whose upper bound reaches the file's own bound (and topThr[0], the
+// bound of bound_kth_kernel, when given), windows of the other files whose upper bound exceeds the minimum of
+// the head bounds (thr[headEnd]).
 __global__ __launch_bounds__(256) void compact_bounded_kernel(const FileDesc *__restrict__ files,
                                                               const TileDesc *__restrict__ tiles,
                                                               const float *__restrict__ up,
@@ -905,7 +948,8 @@ __global__ __launch_bounds__(256) void compact_bounded_kernel(const FileDesc *__
                                                               sgz_candidate *__restrict__ out, long long capacity,
                                                               unsigned long long *__restrict__ count,
                                                               const int *__restrict__ hflags,
-                                                              unsigned long long *__restrict__ zeroOther)
+                                                              unsigned long long *__restrict__ zeroOther,
+                                                              const float *__restrict__ topThr)
 {
     const TileDesc td = tiles[blockIdx.x];
     const FileDesc fd = files[td.file];
@@ -913,7 +957,8 @@ __global__ __launch_bounds__(256) void compact_bounded_kernel(const FileDesc *__
     // (every file this kernel sees holds bounds of a half-precision run: the host checks)
     if (hflags[td.file] && td.o0 == 0 && threadIdx.x == 0) atomicAdd(count, (unsigned long long)capacity + 1ull);
     const bool headFile = td.file < headEnd;
-    const float t = headFile ? bound_from_key(lokey[td.file]) : tailThr[0];
+    float t = headFile ? bound_from_key(lokey[td.file]) : tailThr[0];
+    if (topThr && headFile) t = fmaxf(t, topThr[0]);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const long long o = (long long)td.o0 + k * 256 + threadIdx.x;
@@ -1929,10 +1974,12 @@ int sgz_corr_compact_device(sgz_context *ctx, int file_begin, int file_end, floa
                                nullptr, nullptr);
 }
 
+// top_k > 0: the header that starts with the count also takes, as a float in its bytes 8..11, the top_k-th
+// largest bound of the files [0, head_end), and head files are filtered by it as well.
 static int compact_bounded_device_impl(sgz_context *ctx, int file_begin, int file_end, int head_end,
                                        sgz_candidate *device_out, int64_t capacity,
                                        unsigned long long *device_count, bool count_is_zero,
-                                       unsigned long long *zero_other, bool *launched)
+                                       unsigned long long *zero_other, bool *launched, int top_k = 0)
 {
     if (!ctx) return SGZ_E_ARG;
     if (ctx->layout_dirty || !ctx->have_target) return ctx->fail(SGZ_E_STATE, "no correlation results");
@@ -1954,12 +2001,18 @@ static int compact_bounded_device_impl(sgz_context *ctx, int file_begin, int fil
         hipLaunchKernelGGL(bound_min_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->lokey_cur, head_end, ctx->d_thr);
         SGZ_HIP(ctx, hipGetLastError());
     }
+    float *topThr = nullptr;
+    if (top_k > 0) {
+        topThr = reinterpret_cast<float *>(device_count) + 2;
+        hipLaunchKernelGGL(bound_kth_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->lokey_cur, head_end, top_k, topThr);
+        SGZ_HIP(ctx, hipGetLastError());
+    }
     const int t0 = ctx->tile_begin[file_begin], t1 = ctx->tile_begin[file_end];
     if (launched) *launched = t1 > t0;
     if (t1 > t0) {
         hipLaunchKernelGGL(compact_bounded_kernel, dim3(t1 - t0), dim3(256), 0, ctx->stream, ctx->d_files,
                            ctx->d_tiles + t0, ctx->d_sim, ctx->d_boost, ctx->lokey_cur, ctx->d_thr, head_end, device_out,
-                           (long long)capacity, device_count, ctx->d_hflags, zero_other);
+                           (long long)capacity, device_count, ctx->d_hflags, zero_other, (const float *)topThr);
         SGZ_HIP(ctx, hipGetLastError());
     }
     return SGZ_OK;
@@ -2027,6 +2080,15 @@ static int rescore_device_impl(sgz_context *ctx, sgz_candidate *device_cands, in
     return SGZ_OK;
 }
 
+int sgz_corr_compact_top_device(sgz_context *ctx, int file_begin, int file_end, int num_top,
+                                sgz_candidate *device_out, int64_t capacity, unsigned long long *device_header)
+{
+    if (!ctx) return SGZ_E_ARG;
+    if (num_top < 1) return ctx->fail(SGZ_E_ARG, "bad num_top");
+    return compact_bounded_device_impl(ctx, file_begin, file_end, (int)ctx->files.size(), device_out, capacity,
+                                       device_header, false, nullptr, nullptr, num_top);
+}
+
 int sgz_corr_rescore_device(sgz_context *ctx, sgz_candidate *device_cands, int64_t capacity,
                             const unsigned long long *device_count)
 {
@@ -2045,7 +2107,18 @@ int sgz_corr_rescore_device_noalloc(sgz_context *ctx, sgz_candidate *device_cand
 }
 
 static int compact_host(sgz_context *ctx, int file_begin, int file_end, float threshold, bool rescore,
-                        sgz_candidate *out, int64_t capacity, int64_t *count, int head_end = 0);
+                        sgz_candidate *out, int64_t capacity, int64_t *count, int head_end = 0, int top_k = 0,
+                        float *top_out = nullptr);
+
+int sgz_corr_compact_top(sgz_context *ctx, int file_begin, int file_end, int num_top, sgz_candidate *out,
+                         int64_t capacity, int64_t *count, float *threshold_out)
+{
+    if (!ctx) return SGZ_E_ARG;
+    if (num_top < 1 || !threshold_out) return ctx->fail(SGZ_E_ARG, "bad num_top / threshold_out");
+    if (ctx->files.empty()) return ctx->fail(SGZ_E_STATE, "no database");
+    return compact_host(ctx, file_begin, file_end, 0.0f, true, out, capacity, count, (int)ctx->files.size(), num_top,
+                        threshold_out);
+}
 
 int sgz_corr_compact_bounded(sgz_context *ctx, int file_begin, int file_end, int head_end, sgz_candidate *out,
                              int64_t capacity, int64_t *count)
@@ -2068,7 +2141,7 @@ int sgz_corr_compact(sgz_context *ctx, int file_begin, int file_end, float thres
 }
 
 static int compact_host(sgz_context *ctx, int file_begin, int file_end, float threshold, bool rescore,
-                        sgz_candidate *out, int64_t capacity, int64_t *count, int head_end)
+                        sgz_candidate *out, int64_t capacity, int64_t *count, int head_end, int top_k, float *top_out)
 {
     if (!ctx) return SGZ_E_ARG;
     if (!count || capacity < 0 || (capacity > 0 && !out)) return ctx->fail(SGZ_E_ARG, "bad output buffers");
@@ -2091,7 +2164,7 @@ static int compact_host(sgz_context *ctx, int file_begin, int file_end, float th
     bool launched = false;
     if (head_end > 0)
         rc = compact_bounded_device_impl(ctx, file_begin, file_end, head_end, d_rec, capacity, d_count, clean, d_other,
-                                         &launched);
+                                         &launched, top_k);
     else
         rc = compact_device_impl(ctx, file_begin, file_end, threshold, d_rec, capacity, d_count, clean, d_other,
                                  &launched);
@@ -2159,6 +2232,7 @@ static int compact_host(sgz_context *ctx, int file_begin, int file_end, float th
     unsigned long long n = 0;
     std::memcpy(&n, ctx->h_pinned + parity, sizeof n);
     *count = (int64_t)n;
+    if (top_out) std::memcpy(top_out, reinterpret_cast<const char *>(ctx->h_pinned + parity) + 8, sizeof(float));
     const size_t got = (size_t)std::min<unsigned long long>(n, (unsigned long long)capacity);
     const size_t inFirst = std::min(got, first);
     if (inFirst) std::memcpy(out, ctx->h_pinned + 2, sizeof(sgz_candidate) * inFirst);

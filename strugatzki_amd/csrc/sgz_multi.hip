@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <thread>
 #include <vector>
 
@@ -122,17 +123,24 @@ extern "C" int sgz_corr_search_multi(sgz_context *const *ctxs, int num_ctx, cons
     // maxima of its own files through the bounds of the matrix-core kernel.
     bool f16 = num_per_file == 1 && num_matches >= 1 && num_files_total > 0;
     for (int c = 0; c < num_ctx && f16; c++) f16 = sgz_corr_screen_f16_available(ctxs[c]) == 1;
-    if (f16) {
+    // First with every context leaving out the files that cannot reach the numMatches-th best of its own files'
+    // bounds (sgz_corr_compact_top), then, where the finished set shows that this filter does not apply, with
+    // every file.
+    for (int pass = 0; pass < 2 && f16; pass++) {
         std::vector<int> over((size_t)num_ctx, 0);
+        std::vector<float> tops((size_t)num_ctx, -INFINITY);
         const int rc = for_each_context(num_ctx, [&](int c) -> int {
             sgz_context *ctx = ctxs[c];
             const int nloc = (int)ctx->files.size();
             counts[(size_t)c] = 0;
             if (nloc == 0) return SGZ_OK;
             cands[(size_t)c].resize((size_t)capacity);
-            int r = sgz_corr_run_screen_f16(ctx, 0, nloc);
+            int r = pass == 0 ? sgz_corr_run_screen_f16(ctx, 0, nloc) : SGZ_OK;
             if (r) return r;
-            r = sgz_corr_compact_bounded(ctx, 0, nloc, nloc, cands[(size_t)c].data(), capacity, &counts[(size_t)c]);
+            r = pass == 0 ? sgz_corr_compact_top(ctx, 0, nloc, num_matches, cands[(size_t)c].data(), capacity,
+                                                 &counts[(size_t)c], &tops[(size_t)c])
+                          : sgz_corr_compact_bounded(ctx, 0, nloc, nloc, cands[(size_t)c].data(), capacity,
+                                                     &counts[(size_t)c]);
             if (r == SGZ_E_OVERFLOW) {
                 over[(size_t)c] = 1;
                 return SGZ_OK;
@@ -140,17 +148,19 @@ extern "C" int sgz_corr_search_multi(sgz_context *const *ctxs, int num_ctx, cons
             return r;
         });
         if (rc) return rc;
-        if (std::none_of(over.begin(), over.end(), [](int o) { return o != 0; })) {
-            merged(all);
-            SelGuard q{sgz_sel_create(num_matches, num_per_file, min_spacing, step_size, target_frames)};
-            if (!q.s) return SGZ_E_ARG;
-            const int r = sgz_sel_feed_screened(q.s, all.data(), (int64_t)all.size(), num_files_total, num_files_total);
-            if (r == SGZ_OK) {
-                *count_out = sgz_sel_result(q.s, matches_out, std::min(out_capacity, num_matches));
-                return *count_out < 0 ? *count_out : SGZ_OK;
-            }
-            if (r != SGZ_E_STATE) return r;  // SGZ_E_STATE: the shortcut does not apply
+        if (std::any_of(over.begin(), over.end(), [](int o) { return o != 0; })) break;
+        merged(all);
+        SelGuard q{sgz_sel_create(num_matches, num_per_file, min_spacing, step_size, target_frames)};
+        if (!q.s) return SGZ_E_ARG;
+        const int r = pass == 0 ? sgz_sel_feed_top(q.s, all.data(), (int64_t)all.size(),
+                                                   *std::max_element(tops.begin(), tops.end()))
+                                : sgz_sel_feed_screened(q.s, all.data(), (int64_t)all.size(), num_files_total,
+                                                        num_files_total);
+        if (r == SGZ_OK) {
+            *count_out = sgz_sel_result(q.s, matches_out, std::min(out_capacity, num_matches));
+            return *count_out < 0 ? *count_out : SGZ_OK;
         }
+        if (r != SGZ_E_STATE) return r;  // SGZ_E_STATE: the shortcut does not apply
     }
 
     // General case: the exact kernel over every file; the first numMatches files of the global order are replayed

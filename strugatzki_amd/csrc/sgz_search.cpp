@@ -40,7 +40,21 @@ extern "C" int sgz_corr_search(sgz_context *ctx, int target_frames, int num_matc
         if (cands.size() < (size_t)capacity) cands.resize((size_t)capacity);
         int64_t n = 0;
         if ((rc = sgz_corr_run_screen_f16(ctx, 0, nf))) return rc;
-        rc = sgz_corr_compact_bounded(ctx, 0, nf, nf, cands.data(), capacity, &n);
+        // first with the files left out that cannot reach the numMatches-th best of the per-file bounds
+        float top = 0.0f;
+        rc = sgz_corr_compact_top(ctx, 0, nf, num_matches, cands.data(), capacity, &n, &top);
+        if (rc != SGZ_OK && rc != SGZ_E_OVERFLOW) return rc;
+        if (rc == SGZ_OK) {
+            SelGuard q{sgz_sel_create(num_matches, num_per_file, min_spacing, step_size, target_frames)};
+            if (!q.s) return SGZ_E_ARG;
+            rc = sgz_sel_feed_top(q.s, cands.data(), n, top);
+            if (rc == SGZ_OK) {
+                *count_out = sgz_sel_result(q.s, matches_out, std::min(out_capacity, num_matches));
+                return *count_out < 0 ? *count_out : SGZ_OK;
+            }
+            if (rc != SGZ_E_STATE) return rc;  // SGZ_E_STATE: that filter does not apply; every file, then
+            rc = sgz_corr_compact_bounded(ctx, 0, nf, nf, cands.data(), capacity, &n);
+        }  // (an overflow with the filter is one without it, too)
         if (rc != SGZ_OK && rc != SGZ_E_OVERFLOW) return rc;
         if (rc == SGZ_OK) {
             SelGuard q{sgz_sel_create(num_matches, num_per_file, min_spacing, step_size, target_frames)};

@@ -293,17 +293,47 @@ int sgz_sel_feed_screened(sgz_selector *sel, const sgz_candidate *cands, int64_t
     return sgz_sel_feed_candidates(sel, cands + i, n - i);
 }
 
-int sgz_sel_feed_gathered(sgz_selector *sel, const sgz_candidate *blocks, int world, int64_t rows,
-                          const int32_t *maps, const int64_t *map_offsets, int head_files, int num_files)
+int sgz_sel_feed_top(sgz_selector *sel, const sgz_candidate *cands, int64_t n, float threshold)
 {
-    if (!sel || !blocks || world < 1 || rows < 1 || !maps || !map_offsets) return SGZ_E_ARG;
-    static thread_local std::vector<sgz_candidate> all;
+    if (!sel || n < 0 || (n > 0 && !cands) || threshold != threshold) return SGZ_E_ARG;
+    if (sel->num_per_file != 1) return SGZ_E_STATE;
+    for (int64_t i = 0; i < n;) {
+        const int f = cands[i].file;
+        int64_t best = i, j = i;
+        for (; j < n && cands[j].file == f; j++) {
+            if (j > i && cands[j].offset <= cands[j - 1].offset) return SGZ_E_ARG;  // must be sorted
+            if (cands[j].sim != cands[j].sim) return SGZ_E_STATE;                   // NaN: order matters
+            if (cands[j].sim > cands[best].sim) best = j;                            // strict: first occurrence
+        }
+        if (j < n && cands[j].file < f) return SGZ_E_ARG;
+        const int rc = sgz_sel_feed_file(sel, f, 1, &cands[best].offset, &cands[best].sim, &cands[best].boost);
+        if (rc != SGZ_OK) return rc;
+        i = j;
+    }
+    // No file was left out (fewer files than matches): the replay above is the whole loop.  Otherwise the files
+    // left out lie below `threshold`, and they would matter only if the set had room for such a value.
+    if (threshold == -INFINITY) return SGZ_OK;
+    return sgz_sel_is_full(sel) && sgz_sel_threshold(sel) >= threshold ? SGZ_OK : SGZ_E_STATE;
+}
+
+// Blocks of a candidate exchange -> one list in global file order (ids through the ranks' tables, sorted, one
+// record per window); also the largest of the thresholds in the headers' bytes 8..11.
+static int merge_gathered(std::vector<sgz_candidate> &all, const sgz_candidate *blocks, int world, int64_t rows,
+                          const int32_t *maps, const int64_t *map_offsets, float *top)
+{
     all.clear();
+    if (top) *top = -INFINITY;
     for (int r = 0; r < world; r++) {
         const sgz_candidate *blk = blocks + (size_t)r * (size_t)rows;
         unsigned long long cnt = 0;
         std::memcpy(&cnt, blk, sizeof cnt);  // the header row holds the count
         if (cnt > (unsigned long long)(rows - 1)) return SGZ_E_OVERFLOW;
+        if (top) {
+            float t;
+            std::memcpy(&t, reinterpret_cast<const char *>(blk) + 8, sizeof t);
+            if (t != t) return SGZ_E_ARG;
+            *top = std::max(*top, t);
+        }
         const int64_t nmap = map_offsets[r + 1] - map_offsets[r];
         for (unsigned long long i = 0; i < cnt; i++) {
             sgz_candidate c = blk[1 + i];
@@ -321,6 +351,27 @@ int sgz_sel_feed_gathered(sgz_selector *sel, const sgz_candidate *blocks, int wo
                               return a.file == b.file && a.offset == b.offset;
                           }),
               all.end());
+    return SGZ_OK;
+}
+
+int sgz_sel_feed_gathered_top(sgz_selector *sel, const sgz_candidate *blocks, int world, int64_t rows,
+                              const int32_t *maps, const int64_t *map_offsets)
+{
+    if (!sel || !blocks || world < 1 || rows < 1 || !maps || !map_offsets) return SGZ_E_ARG;
+    static thread_local std::vector<sgz_candidate> all;
+    float top;
+    const int rc = merge_gathered(all, blocks, world, rows, maps, map_offsets, &top);
+    if (rc) return rc;
+    return sgz_sel_feed_top(sel, all.data(), (int64_t)all.size(), top);
+}
+
+int sgz_sel_feed_gathered(sgz_selector *sel, const sgz_candidate *blocks, int world, int64_t rows,
+                          const int32_t *maps, const int64_t *map_offsets, int head_files, int num_files)
+{
+    if (!sel || !blocks || world < 1 || rows < 1 || !maps || !map_offsets) return SGZ_E_ARG;
+    static thread_local std::vector<sgz_candidate> all;
+    const int rcm = merge_gathered(all, blocks, world, rows, maps, map_offsets, nullptr);
+    if (rcm) return rcm;
     return sgz_sel_feed_screened(sel, all.data(), (int64_t)all.size(), head_files, num_files);
 }
 

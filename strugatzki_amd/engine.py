@@ -207,6 +207,21 @@ class Context:
                                                  C.byref(cnt)))
         return out[: cnt.value]
 
+    def corr_compact_top(self, file_begin: int, file_end: int, num_top: int, capacity: int) -> tuple[np.ndarray, float]:
+        """corr_compact_bounded over all files as head files, without the files that cannot reach the num_top-th
+        largest of the files' lower bounds; returns the candidates and that bound (sgz_corr_compact_top)."""
+        out = np.empty(max(capacity, 1), dtype=N.CANDIDATE_DTYPE)
+        cnt = C.c_int64(0)
+        thr = C.c_float(0.0)
+        self._check(lib.sgz_corr_compact_top(self._h, file_begin, file_end, num_top, N.ptr(out), capacity,
+                                             C.byref(cnt), C.byref(thr)))
+        return out[: cnt.value], float(thr.value)
+
+    def corr_compact_top_device(self, file_begin: int, file_end: int, num_top: int, out_ptr: int, capacity: int,
+                                header_ptr: int) -> None:
+        self._check(lib.sgz_corr_compact_top_device(self._h, file_begin, file_end, num_top, C.c_void_p(out_ptr),
+                                                    capacity, C.c_void_p(header_ptr)))
+
     def corr_search(self, num_matches: int, num_per_file: int, min_spacing: int, step_size: int,
                     screen_mode: int = N.SGZ_SCREEN_AUTO, over_bounds: bool = True, capacity: int = 1 << 16,
                     margin: float = -1.0) -> list[N.Match]:
@@ -385,6 +400,30 @@ class Selector:
             return False
         if rc != N.SGZ_OK:
             raise N.NativeError(rc, "sgz_sel_feed_screened")
+        return True
+
+    def feed_top(self, cands: np.ndarray, threshold: float) -> bool:
+        """Feeds the re-scored candidates of Context.corr_compact_top.  False: leaving out the files below the
+        threshold was not sound for this data (or a NaN): discard this selector, take corr_compact_bounded."""
+        c = np.ascontiguousarray(cands, dtype=N.CANDIDATE_DTYPE)
+        rc = lib.sgz_sel_feed_top(self._h, N.ptr(c), c.shape[0], threshold)
+        if rc == N.SGZ_E_STATE:
+            return False
+        if rc != N.SGZ_OK:
+            raise N.NativeError(rc, "sgz_sel_feed_top")
+        return True
+
+    def feed_gathered_top(self, blocks: np.ndarray, world: int, rows: int, maps: np.ndarray,
+                          map_offsets: np.ndarray) -> bool | None:
+        """feed_top over the blocks of a candidate exchange (sgz_sel_feed_gathered_top).  None: some rank has
+        more records than a block holds; False: the filter does not apply."""
+        rc = lib.sgz_sel_feed_gathered_top(self._h, N.ptr(blocks), world, rows, N.ptr(maps), N.ptr(map_offsets))
+        if rc == N.SGZ_E_OVERFLOW:
+            return None
+        if rc == N.SGZ_E_STATE:
+            return False
+        if rc != N.SGZ_OK:
+            raise N.NativeError(rc, "sgz_sel_feed_gathered_top")
         return True
 
     @property

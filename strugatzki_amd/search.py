@@ -334,61 +334,78 @@ def _sharded_over_bounds(ctx: Context, p: SearchParams, local_to_global: Sequenc
     maps = _rank_maps(ctx, local_to_global, group)
     b = _exchange_buffers(ctx, cap, world, on_gpu)
     rec, rows = b["rec"], b["rows"]
-    if nloc:
-        ctx.corr_run_screen_f16(0, nloc)
-        # row 0 = header (the count, written by the library), rows 1.. = records
-        ctx.corr_compact_bounded_device(0, nloc, nloc, b["rec_ptr"], cap, b["count_ptr"])
-        ctx.corr_rescore_device(b["rec_ptr"], cap, b["count_ptr"])
-    else:
-        # fewer files than ranks: this rank has none, but takes part in the exchange with a count of zero
-        rec[0].zero_()
-        torch.cuda.current_stream().synchronize()
     ts = ctx.torch_stream
-    if on_gpu and ts is not None:
-        # the context runs on a stream torch owns (Context.on_torch_stream): collective and copy are queued
-        # behind the kernels on the device, one host-side wait at the end
-        with torch.cuda.stream(ts):
+    # First with every rank leaving out the files that cannot reach the numMatches-th best of its own files'
+    # bounds (corr_compact_top_device; the bound travels in the header row); where the finished selection shows
+    # that this was not sound (every rank sees the same gathered data and decides the same), with every file.
+    for top in (True, False):
+        if nloc:
+            if top:
+                ctx.corr_run_screen_f16(0, nloc)
+                # row 0 = header (count and bound, written by the library), rows 1.. = records
+                ctx.corr_compact_top_device(0, nloc, p.num_matches, b["rec_ptr"], cap, b["count_ptr"])
+            else:
+                ctx.corr_compact_bounded_device(0, nloc, nloc, b["rec_ptr"], cap, b["count_ptr"])
+            ctx.corr_rescore_device(b["rec_ptr"], cap, b["count_ptr"])
+        else:
+            # fewer files than ranks: this rank has none, but takes part in the exchange with a count of zero
+            # (and a bound of -inf: it leaves nothing out)
+            rec[0].zero_()
+            rec[0, 2] = -8388608  # the bits of float -inf
+            torch.cuda.current_stream().synchronize()
+        if on_gpu and ts is not None:
+            # the context runs on a stream torch owns (Context.on_torch_stream): collective and copy are queued
+            # behind the kernels on the device, one host-side wait at the end
+            with torch.cuda.stream(ts):
+                dist.all_gather_into_tensor(b["gathered"], b["send"], group=group)
+                b["host"].copy_(b["gathered"], non_blocking=True)
+                b["event"].record(ts)
+            while not b["event"].query():  # polling: a blocking wait costs its wake-up on top of a 0.3 ms search
+                pass
+        elif on_gpu:
+            # the context owns its stream: a host-side wait, then the collective on torch's stream.  (Wrapping the
+            # library's stream in torch.cuda.ExternalStream leaves torch and RCCL holding a stream the context
+            # destroys: the process then crashes on exit.)
+            ctx.synchronize()
             dist.all_gather_into_tensor(b["gathered"], b["send"], group=group)
             b["host"].copy_(b["gathered"], non_blocking=True)
-            b["event"].record(ts)
-        while not b["event"].query():  # polling: a blocking wait costs its wake-up on top of a 0.3 ms search
-            pass
-    elif on_gpu:
-        # the context owns its stream: a host-side wait, then the collective on torch's stream.  (Wrapping the
-        # library's stream in torch.cuda.ExternalStream leaves torch and RCCL holding a stream the context
-        # destroys: the process then crashes on exit.)
-        ctx.synchronize()
-        dist.all_gather_into_tensor(b["gathered"], b["send"], group=group)
-        b["host"].copy_(b["gathered"], non_blocking=True)
-        torch.cuda.current_stream().synchronize()
-    else:
-        ctx.synchronize()
-        dist.all_gather_into_tensor(b["gathered"], b["send"].cpu(), group=group)
-    h = b["view"]
-    sel = Selector(p.num_matches, p.num_per_file, p.min_spacing, p.step_size, ctx.target_frames)
-    try:
-        # translation to global file ids, merge, sort and replay in one native call
-        ok = sel.feed_gathered(h, world, rows, maps["flat"], maps["offsets"], num_files_total, num_files_total)
-        if ok is None:  # rare: some rank has more records than the first exchange carries
-            counts = h[:, 0, :2].copy().view(np.int64).reshape(world)
-            if (counts > cap).any():
-                return None  # every rank sees the overflow
-            full = [torch.empty_like(rec) for _ in range(world)] if on_gpu else [
-                torch.empty((cap + 1, 4), dtype=torch.int32) for _ in range(world)]
-            if ts is not None:
-                ts.synchronize()
-            dist.all_gather(full, rec if on_gpu else rec.cpu(), group=group)
-            out = []
-            for r in range(world):
-                part = full[r][1: 1 + int(counts[r])].cpu().numpy()
-                c = np.ascontiguousarray(part, dtype=np.int32).view(N.CANDIDATE_DTYPE).reshape(-1).copy()
-                c["file"] = maps["per_rank"][r][c["file"]]
-                out.append(c)
-            cands = _sort_candidates(np.concatenate(out) if out else np.zeros(0, N.CANDIDATE_DTYPE))
-            ok = sel.feed_screened(cands, num_files_total, num_files_total)
-        return sel.result() if ok else None
-    finally:
-        sel.close()
+            torch.cuda.current_stream().synchronize()
+        else:
+            ctx.synchronize()
+            dist.all_gather_into_tensor(b["gathered"], b["send"].cpu(), group=group)
+        h = b["view"]
+        sel = Selector(p.num_matches, p.num_per_file, p.min_spacing, p.step_size, ctx.target_frames)
+        try:
+            # translation to global file ids, merge, sort and replay in one native call
+            if top:
+                ok = sel.feed_gathered_top(h, world, rows, maps["flat"], maps["offsets"])
+            else:
+                ok = sel.feed_gathered(h, world, rows, maps["flat"], maps["offsets"], num_files_total, num_files_total)
+            if ok is None:  # rare: some rank has more records than the first exchange carries
+                counts = h[:, 0, :2].copy().view(np.int64).reshape(world)
+                if (counts > cap).any():
+                    return None  # every rank sees the overflow
+                full = [torch.empty_like(rec) for _ in range(world)] if on_gpu else [
+                    torch.empty((cap + 1, 4), dtype=torch.int32) for _ in range(world)]
+                if ts is not None:
+                    ts.synchronize()
+                dist.all_gather(full, rec if on_gpu else rec.cpu(), group=group)
+                out = []
+                for r in range(world):
+                    part = full[r][1: 1 + int(counts[r])].cpu().numpy()
+                    c = np.ascontiguousarray(part, dtype=np.int32).view(N.CANDIDATE_DTYPE).reshape(-1).copy()
+                    c["file"] = maps["per_rank"][r][c["file"]]
+                    out.append(c)
+                cands = _sort_candidates(np.concatenate(out) if out else np.zeros(0, N.CANDIDATE_DTYPE))
+                if top:
+                    ok = sel.feed_top(cands, float(h[:, 0, 2].copy().view(np.float32).max()))
+                else:
+                    ok = sel.feed_screened(cands, num_files_total, num_files_total)
+            if ok:
+                return sel.result()
+        finally:
+            sel.close()
+    return None
 
 
 def _sharded_exact_maxima(ctx: Context, p: SearchParams, local_to_global: Sequence[int], num_files_total: int,

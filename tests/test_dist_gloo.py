@@ -217,6 +217,103 @@ def test_feed_gathered_equals_feed_screened_on_the_merged_list():
     sel.close()
 
 
+def _top_pruned_candidates(sims, boosts, files, num_top, err):
+    """What sgz_corr_compact_top leaves of `files` (global ids): bounds = exact +- err; T = num_top-th largest lower
+    bound of these files; windows with upper bound >= max(file's largest lower bound, T)."""
+    from strugatzki_amd import _native as N
+    lows = sorted((np.float32(sims[g].max() - err) for g in files), reverse=True)
+    T = np.float32(lows[num_top - 1]) if len(lows) >= num_top else np.float32(-np.inf)
+    rows = []
+    for loc, g in enumerate(files):
+        gate = max(np.float32(sims[g].max() - err), T)
+        for o in np.flatnonzero(sims[g] + np.float32(err) >= gate):
+            rows.append((loc, o, sims[g][o], boosts[g][o]))
+    return np.array(rows, dtype=N.CANDIDATE_DTYPE), float(T)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_feed_top_equals_the_sequential_loop_or_declines(seed):
+    """Leaving out the files that cannot reach the numMatches-th best per-file bound (sgz_corr_compact_top /
+    sgz_sel_feed_top): the same matches as the reference loop over every window, also with fewer files than
+    matches; with duplicated files (equal similarities collapse into one set entry and leave room for a lesser
+    file) the call must decline instead of returning a shorter or different list."""
+    from strugatzki_amd.engine import Selector, match_tuple
+    rng = np.random.default_rng(100 + seed)
+    L, ts, frames = 48, 5, 300
+    nf = int(rng.integers(3, 14))
+    num_matches = int(rng.integers(1, 8))
+    db = synth_db(nf, frames, make_plants(min(3, nf), L, nf, frames, ts))
+    dup = seed % 3 == 2 and nf >= 3
+    if dup:  # the two best files become identical (the plants sit in the first files)
+        db[1] = db[0].copy()
+    tgt = synth_target(ts, L)
+    cfg = corr_config(ts, L, num_matches=num_matches, num_per_file=1)
+    want, sims, boosts = O.correlation_run(cfg, tgt, norms_default(), db)
+    cands, T = _top_pruned_candidates(sims, boosts, list(range(nf)), num_matches, 1e-3)
+    sel = Selector(num_matches, 1, 0, STEP, L)
+    ok = sel.feed_top(cands, T)
+    if ok:
+        assert [match_tuple(m) for m in sel.result()] == [O.match_tuple(w) for w in want]
+    else:
+        assert dup and num_matches >= 2 and nf > num_matches
+    if not dup or num_matches < 2:
+        assert ok
+    sel.close()
+
+
+def test_feed_top_declines_when_equal_similarities_leave_room():
+    """Two identical best files, numMatches = 2: the reference's set keeps one entry for both (keyed on the
+    similarity) and fills the second place with a lesser file, which the filter left out."""
+    from strugatzki_amd.engine import Selector, match_tuple
+    L, ts, nf, frames = 48, 5, 6, 300
+    db = synth_db(nf, frames, make_plants(1, L, nf, frames, ts))
+    db[1] = db[0].copy()
+    tgt = synth_target(ts, L)
+    want, sims, boosts = O.correlation_run(corr_config(ts, L, num_matches=2, num_per_file=1), tgt, norms_default(), db)
+    assert sorted(w.file for w in want)[0] == 0 and sorted(w.file for w in want)[1] > 1
+    cands, T = _top_pruned_candidates(sims, boosts, list(range(nf)), 2, 1e-3)
+    assert set(cands["file"]) == {0, 1}
+    sel = Selector(2, 1, 0, STEP, L)
+    assert sel.feed_top(cands, T) is False
+    sel.close()
+    cands, _ = _top_pruned_candidates(sims, boosts, list(range(nf)), nf + 1, 1e-3)  # nothing left out
+    sel = Selector(2, 1, 0, STEP, L)
+    assert sel.feed_top(cands, float("-inf")) is True
+    assert [match_tuple(m) for m in sel.result()] == [O.match_tuple(w) for w in want]
+    sel.close()
+
+
+def test_feed_gathered_top_uses_the_largest_threshold():
+    """Three ranks each leave out files below their own threshold (header bytes 8..11); the merged replay equals
+    the reference loop, and declines when a threshold above the finished set's worst entry says that a file may
+    be missing."""
+    from strugatzki_amd.engine import Selector, match_tuple
+    L, ts, nf, frames, world, num_matches = 48, 5, 13, 300, 3, 3
+    db = synth_db(nf, frames, make_plants(3, L, nf, frames, ts))
+    tgt = synth_target(ts, L)
+    want, sims, boosts = O.correlation_run(corr_config(ts, L, num_matches=num_matches, num_per_file=1), tgt,
+                                           norms_default(), db)
+    rows = 64
+    blocks = np.zeros((world, rows, 4), dtype=np.int32)
+    per_rank = [[g for g in range(nf) if g % world == r] for r in range(world)]
+    for r in range(world):
+        rec, T = _top_pruned_candidates(sims, boosts, per_rank[r], num_matches, 1e-3)
+        assert len(rec) < rows and np.isfinite(T) and len(set(rec["file"])) < len(per_rank[r])
+        blocks[r, 0, :2] = np.array([len(rec)], dtype=np.int64).view(np.int32)
+        blocks[r, 0, 2] = np.array([T], dtype=np.float32).view(np.int32)[0]
+        blocks[r, 1:1 + len(rec)] = rec.view(np.int32).reshape(-1, 4)
+    flat = np.array(sum(per_rank, []), dtype=np.int32)
+    offsets = np.concatenate([[0], np.cumsum([len(x) for x in per_rank])]).astype(np.int64)
+    sel = Selector(num_matches, 1, 0, STEP, L)
+    assert sel.feed_gathered_top(blocks, world, rows, flat, offsets) is True
+    assert [match_tuple(m) for m in sel.result()] == [O.match_tuple(w) for w in want]
+    sel.close()
+    blocks[2, 0, 2] = np.array([2.0], dtype=np.float32).view(np.int32)[0]
+    sel = Selector(num_matches, 1, 0, STEP, L)
+    assert sel.feed_gathered_top(blocks, world, rows, flat, offsets) is False
+    sel.close()
+
+
 def test_shard_files_partitions_the_tail():
     from strugatzki_amd.search import shard_files
     parts = [shard_files(37, 5, r, 4) for r in range(4)]

@@ -396,6 +396,37 @@ def test_bounds_hold_on_awkward_data(ctx, case):
     assert [(g.file, g.start, g.stop) for g in got] == [(w.file, w.start, w.stop) for w in want]
 
 
+def test_compact_top_leaves_out_files_below_the_kth_bound(ctx):
+    """sgz_corr_compact_top: T = the num_top-th largest per-file lower bound; only files that can reach it are
+    collected (a subset of sgz_corr_compact_bounded's records, exactly re-scored), and the replay over them
+    (sgz_sel_feed_top) gives the reference's matches.  More num_top than files: nothing is left out."""
+    from strugatzki_amd.engine import Selector, match_tuple
+    L, ts, nf, frames, k = 431, 20, 12, 2583, 3
+    db = synth_db(nf, frames, make_plants(3, L, nf, frames, ts))
+    tgt = synth_target(ts, L)
+    norms = norms_default()
+    want, sims, boosts = O.correlation_run(corr_config(ts, L, num_matches=k, num_per_file=1), tgt, norms, db)
+    _load(ctx, db, norms)
+    ctx.corr_set_target(tgt[ts:ts + L], 0.5, 8.0)
+    ctx.corr_run_screen_f16(0, nf)
+    every = ctx.corr_compact_bounded(0, nf, nf, 1 << 16)
+    top, T = ctx.corr_compact_top(0, nf, k, 1 << 16)
+    assert {(int(c["file"]), int(c["offset"])) for c in top} <= {(int(c["file"]), int(c["offset"])) for c in every}
+    files = {int(f) for f in top["file"]}
+    exact_max = sorted((float(sims[f].max()) for f in range(nf)), reverse=True)
+    assert k <= len(files) < nf
+    assert exact_max[k - 1] - 3e-3 <= T <= exact_max[k - 1]
+    assert all(f in files for f in range(nf) if sims[f].max() >= T)
+    for c in top:
+        assert abs(float(c["sim"]) - float(sims[c["file"]][c["offset"]])) <= 1.2e-7
+    sel = Selector(k, 1, 0, STEP, L)
+    assert sel.feed_top(top, T)
+    assert [match_tuple(m) for m in sel.result()] == [O.match_tuple(w) for w in want]
+    sel.close()
+    top2, T2 = ctx.corr_compact_top(0, nf, nf + 1, 1 << 16)
+    assert T2 == float("-inf") and {int(f) for f in top2["file"]} == set(range(nf))
+
+
 @pytest.mark.parametrize("case", ["duplicate_head_files", "short_head_file", "single_file", "fewer_files_than_matches"])
 def test_search_over_bounds_and_its_fallbacks(ctx, case):
     """numPerFile = 1 with f16 screening searches over bounds; cases it cannot decide go to the exact path."""
