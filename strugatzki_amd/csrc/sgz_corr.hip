@@ -492,36 +492,55 @@ __global__ __launch_bounds__(256) void prep_half_kernel(const FileDesc *__restri
 }
 
 // ---------------------------------------------------------------------------
-// file_const_kernel: the centring constants of a file's half-precision image -- the mean of the normalised
-// loudness channel and the mean of all other normalised channels over the whole file -- written into the file
-// table on the device.  Any constant gives correct bounds (the target image is centred on its own mean, so the
-// constant drops out of the cross term); the file's own mean keeps the half-precision values, and with them
-// the error bound, small.  One workgroup per file; thread t owns channel t % numCh (fixed order of summation).
-// A file whose mean is not finite gets 0: its bounds are NaN then and the exact path takes over.
+// file_const_kernel: the centring constants of a file's half-precision image -- the mean level of the
+// normalised loudness channel and of all other normalised channels -- written into the file table on the
+// device.  Any constant gives correct bounds (the target image is centred on its own mean, so the constant
+// drops out of the cross term); one near the file's mean keeps the half-precision values, and with them the
+// error bound, small.  So a sample is enough: the first `rows` (up to 64) frames of every block of 256, read as
+// one contiguous run by a workgroup per file, thread t on channel t % numCh, eight loads in flight; sums in a
+// fixed order.  A file whose mean is not finite gets 0: its bounds are NaN then and the exact path takes over.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void file_const_kernel(FileDesc *__restrict__ files, int fileBegin, NormParams nrm,
                                                           int numCh)
 {
     __shared__ double part[1024];
+    __shared__ double chan[SGZ_MAX_CHANNELS];
     FileDesc &fd = files[fileBegin + blockIdx.x];
     const int tid = threadIdx.x;
-    const int rows = 1024 / numCh, stride = rows * numCh;
-    const long long total = fd.frames * numCh;
+    const int rows = min(64, 1024 / numCh), used = rows * numCh;
+    const long long frames = fd.frames, blockVals = 256ll * numCh;
+    const long long nblocks = (frames + 255) / 256;
     double s = 0.0;
-    if (tid < stride) {
-        const int c = tid % numCh;
-        const float mn = nrm.enabled ? nrm.mn[c] : 0.0f, d = nrm.enabled ? nrm.d[c] : 1.0f;
-        for (long long e = tid; e < total; e += stride) s += (double)((fd.raw[e] - mn) / d);
+    if (tid < used) {
+        const int c = tid % numCh, r = tid / numCh;
+        const float mn = nrm.enabled ? nrm.mn[c] : 0.0f, rcp = nrm.enabled ? 1.0f / nrm.d[c] : 1.0f;
+        const float *src = fd.raw + tid;
+        for (long long b0 = 0; b0 < nblocks; b0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const long long b = b0 + u;
+                v[u] = (b < nblocks && b * 256 + r < frames) ? src[b * blockVals] : mn;  // (mn adds 0)
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) s += (double)((v[u] - mn) * rcp);
+        }
     }
     part[tid] = s;
     __syncthreads();
+    if (tid < numCh) {
+        double t = 0.0;
+        for (int k = tid; k < used; k += numCh) t += part[k];
+        chan[tid] = t;
+    }
+    __syncthreads();
     if (tid == 0) {
-        double t = 0.0, sp = 0.0;
-        for (int k = 0; k < stride; k++) {
-            if (k % numCh == 0) t += part[k]; else sp += part[k];
-        }
-        const double n = (double)fd.frames;
-        float cT = n > 0 ? (float)(t / n) : 0.0f, cS = n > 0 ? (float)(sp / (n * (numCh - 1))) : 0.0f;
+        double sp = 0.0;
+        for (int c = 1; c < numCh; c++) sp += chan[c];
+        // frames in the sample: `rows` of every whole block, and what the last block holds of its first `rows`
+        const long long whole = frames / 256, rest = frames - whole * 256;
+        const double n = (double)(whole * rows + min((long long)rows, rest));
+        float cT = n > 0 ? (float)(chan[0] / n) : 0.0f, cS = n > 0 ? (float)(sp / (n * (numCh - 1))) : 0.0f;
         if (!(fabsf(cT) < 3.0e38f)) cT = 0.0f;
         if (!(fabsf(cS) < 3.0e38f)) cS = 0.0f;
         fd.cT = cT;
@@ -901,37 +920,51 @@ __global__ __launch_bounds__(64) void bound_min_kernel(const int *__restrict__ l
 __global__ __launch_bounds__(256) void bound_kth_kernel(const int *__restrict__ lokey, int n, int k, float *__restrict__ out)
 {
     __shared__ int hist[256];
+    __shared__ int waveTotal[4];
     __shared__ unsigned int chosenPrefix;
     __shared__ int chosenLeft;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (n < k || k < 1) {
         if (tid == 0) out[0] = -INFINITY;
         return;
     }
+    // (the keys of up to four files per thread stay in registers; more are read again every round)
+    unsigned int mine[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) mine[j] = tid + 256 * j < n ? (unsigned int)lokey[tid + 256 * j] ^ 0x80000000u : 0u;
     unsigned int prefix = 0, mask = 0;
     int left = k;  // the wanted key is the left-th largest of those that match the prefix
     for (int shift = 24; shift >= 0; shift -= 8) {
         hist[tid] = 0;
         __syncthreads();
-        for (int i = tid; i < n; i += 256) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (tid + 256 * j < n && (mine[j] & mask) == prefix) atomicAdd(&hist[(mine[j] >> shift) & 255u], 1);
+        for (int i = tid + 1024; i < n; i += 256) {
             const unsigned int u = (unsigned int)lokey[i] ^ 0x80000000u;
             if ((u & mask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1);
         }
         __syncthreads();
-        if (tid == 0) {
-            int above = 0, b = 255;
-            for (; b > 0; b--) {
-                if (above + hist[b] >= left) break;
-                above += hist[b];
-            }
-            chosenPrefix = prefix | ((unsigned int)b << shift);
-            chosenLeft = left - above;
+        // thread b: how many matching keys have a byte >= b (suffix sums: within the wave by shuffles, then the
+        // totals of the waves above); the wanted byte is the one where that count first reaches `left`
+        const int h = hist[tid];
+        int atLeast = h;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_down(atLeast, off, 64);
+            if (lane + off < 64) atLeast += t;
+        }
+        if (lane == 0) waveTotal[wave] = atLeast;
+        __syncthreads();
+        for (int w = wave + 1; w < 4; w++) atLeast += waveTotal[w];
+        if (atLeast >= left && atLeast - h < left) {  // exactly one thread
+            chosenPrefix = prefix | ((unsigned int)tid << shift);
+            chosenLeft = left - (atLeast - h);
         }
         __syncthreads();
         prefix = chosenPrefix;
         left = chosenLeft;
         mask |= 255u << shift;
-        __syncthreads();
     }
     if (tid == 0) out[0] = bound_from_key((int)(prefix ^ 0x80000000u));
 }

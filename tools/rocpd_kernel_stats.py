@@ -2,12 +2,17 @@
 (rocpd sqlite, the default output of `rocprofv3 --kernel-trace --stats`), written as CSV.
 usage: rocpd_kernel_stats.py RESULTS.db [OUT.csv]"""
 import csv
+import re
 import sqlite3
 import sys
 
 
 def short(name: str) -> str:
     """Kernel name without the anonymous namespace, the return type and the argument list."""
+    if name.startswith("_Z"):  # a mangled name (template kernels arrive that way): kernel<first integer argument>
+        m = re.search(r"\d+([a-z][a-z0-9_]*_kernel)(?:ILi(\d+)E)?", name)
+        if m:
+            return m.group(1) + (f"<{m.group(2)}>" if m.group(2) else "")
     name = name.replace("(anonymous namespace)::", "")
     if name.startswith("void "):
         name = name[5:]
