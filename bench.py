@@ -44,6 +44,7 @@ PEAK_F64_TFLOPS = 78.6
 PEAK_F32_TFLOPS = 157.3
 PEAK_F16_TFLOPS = 2516.6  # dense f16/bf16 MFMA: 256 CU x 4 SIMD x 1024 flop/clk x 2.4 GHz
 PEAK_HBM_GBS = 8000.0
+SUSTAINED_F16_RANDOM_TFLOPS = 1965.0  # measured, tools/mfma_peak.hip (register operands, random data, 20-40 ms runs)
 
 
 def plant_list(num: int, L: int, files: list[int], frames_per_file: int):
@@ -98,9 +99,9 @@ def cpu_baseline(L: int, frames_per_file: int, budget_s: float) -> dict:
 
 def pmc_traffic_bytes(kernel: str):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of the default N=1 command
-    (profiles/r01_pmc_summary.csv): 2 x FETCH_SIZE (gfx950 tallies 128-byte read requests at 64 bytes) +
+    (profiles/r02_pmc_summary.csv): 2 x FETCH_SIZE (gfx950 tallies 128-byte read requests at 64 bytes) +
     WRITE_SIZE, both in KiB.  None when the summary does not hold the kernel."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_summary.csv")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_summary.csv")
     try:
         import csv
         vals = {}
@@ -395,6 +396,11 @@ def main() -> int:
                 "windows_per_launch": tail_windows,
                 "flop_per_window": 2.0 * NUM_CH * L,
                 "hbm_frac_algorithmic": (alg_bytes / (k_ms * 1e-3) / 1e9) / PEAK_HBM_GBS if k_ms > 0 else 0.0,
+                # what tools/mfma_peak.hip sustains with this instruction shape, register operands only, on
+                # pseudo-random half-precision data (the chip's clock under matrix load depends on operand bit
+                # activity: 2480 TFLOP/s on zeros, 2320 on smooth small numbers, 1965 on random data)
+                "sustained_peak_random_operands": SUSTAINED_F16_RANDOM_TFLOPS if mode == "f16" else None,
+                "frac_of_sustained": achieved / SUSTAINED_F16_RANDOM_TFLOPS if mode == "f16" else None,
                 "note": note,
             },
             "verified": verified,
