@@ -13,7 +13,9 @@
  * What pins this file are the invariants the reference states itself:
  * correlate(a, a) == 1.0 (impl/MathUtil.scala:98,195), the boost law of
  * notes/BoostFactor.txt:34-39, and the result orderings
- * (FeatureCorrelation.scala:30-33, FeatureSegmentation.scala:32-35).
+ * (FeatureCorrelation.scala:30-33, FeatureSegmentation.scala:32-35), and a
+ * second restatement of the same Scala sources, written independently in numpy
+ * (oracle/twin.py), which the tests hold against this one.
  *
  * Every function cites the reference lines it follows; paths are relative to
  * src/main/scala/de/sciss/strugatzki/ of the reference.  Loop order, operand
