@@ -10,9 +10,9 @@ windows per second, whole job.
     python bench.py --gpus N --steps K --warmup W          (N=1)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-Workload at N=1: BASELINE.json configs[2] -- 30 s target (2584 feature frames)
+Workload at N=1: the configuration the headline metric is quoted on -- 30 s target (2584 feature frames)
 against a 10 h database (120 files x 300 s), 13 MFCC + loudness,
-temporalWeight 0.5, top-10.  For N>1 the default is BASELINE.json configs[4]:
+temporalWeight 0.5, top-10.  For N>1 the default is the large-database configuration:
 60 s target (5168 frames) against 1500 files x 300 s per GPU (125 h per GPU,
 1000 h on 8 GPUs), sharded by file; --target-seconds / --files-per-gpu override
 either.  The same run also times the reference-precision dense path (fp64

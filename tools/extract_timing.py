@@ -1,4 +1,4 @@
-"""Times sgz_extract on BASELINE config 2: 1 h mono 44.1 kHz, fftSize 1024, hop 512, 13 MFCC + loudness."""
+"""Times sgz_extract on the extraction configuration of the benchmark set: 1 h mono 44.1 kHz, fftSize 1024, hop 512, 13 MFCC + loudness."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
