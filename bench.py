@@ -135,8 +135,11 @@ def main() -> int:
     ap.add_argument("--settle-ms", type=float, default=100.0,
                     help="untimed steps for about this long (counted as 0.3 ms each) before the warm-up steps, so that the "
                          "clocks have settled")
-    ap.add_argument("--timing-every", type=int, default=1,
-                    help="HIP events with one launch in n of the dominant kernel (matrix-core path)")
+    ap.add_argument("--timing-every", type=int, default=8,
+                    help="HIP events with one launch in n of the dominant kernel (matrix-core path).  A launch that "
+                         "carries events costs the host about 20 us more than one that does not (measured: "
+                         "tools/search_loop.cpp), a tenth of a step at the default workload, so the kernel's average "
+                         "duration over the timed region comes from a sample of its launches")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget; 0 disables")
     ap.add_argument("--exact-only", action="store_true",
                     help="fp64 kernel for every file (no screening + re-scoring)")
@@ -237,7 +240,7 @@ def main() -> int:
     gc.collect()
     gc.freeze()
 
-    # HIP events travel with every launch of the dominant kernel by default (--timing-every n: one in n)
+    # HIP events travel with one launch in --timing-every of the dominant kernel
     timing_every = max(1, args.timing_every) if mode == "f16" else 1
     ctx.set_kernel_timing(timing_every)
     # Clock settling, untimed and reported as such: after an idle period the chip needs some tens of
