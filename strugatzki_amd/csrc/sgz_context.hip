@@ -68,6 +68,8 @@ void sgz_destroy(sgz_context *ctx)
         if (b) (void)hipFree(b);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     for (auto &slot : ctx->pin_pool) {
+        (void)hipEventDestroy(slot.done[0]);
+        (void)hipEventDestroy(slot.done[1]);
         (void)hipStreamDestroy(slot.stream);
         (void)hipHostFree(slot.pin);
     }
@@ -136,14 +138,15 @@ int sgz_synchronize(sgz_context *ctx)
 
 // Large transfers between pageable host memory and the device go through several pinned staging buffers, one
 // thread and stream each: a single pageable copy is bound by one core's page faults and memcpy (about 9 GB/s to
-// the host, 27 GB/s from it), well below the link.  The buffers and streams are made on first use and kept with
-// the context (allocating 256 MB of pinned memory costs more than the copy it serves).  Synchronous; work queued
-// on ctx->stream is waited for first.
+// the host, 27 GB/s from it), well below the link.  Every thread has two half buffers, so that its own memcpy
+// and its own transfer overlap as well.  The buffers and streams are made on first use and kept with the
+// context (allocating 256 MB of pinned memory costs more than the copy it serves).  Synchronous; work queued on
+// ctx->stream is waited for first.
 int sgz::copy_large(sgz_context *ctx, void *dst, const void *src, size_t bytes, bool to_host)
 {
-    constexpr size_t kChunk = (size_t)32 << 20;
+    constexpr size_t kChunk = (size_t)16 << 20;  // half a staging buffer
     constexpr int kThreads = 8;
-    if (bytes < 8 * kChunk) {
+    if (bytes < 16 * kChunk) {
         SGZ_HIP(ctx, hipMemcpyAsync(dst, src, bytes, to_host ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice, ctx->stream));
         SGZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
         return SGZ_OK;
@@ -152,8 +155,13 @@ int sgz::copy_large(sgz_context *ctx, void *dst, const void *src, size_t bytes, 
     if (ctx->pin_pool.empty()) {
         for (int t = 0; t < kThreads; t++) {
             sgz_context::PinSlot slot;
-            if (hipHostMalloc(&slot.pin, kChunk, hipHostMallocDefault) != hipSuccess ||
-                hipStreamCreateWithFlags(&slot.stream, hipStreamNonBlocking) != hipSuccess) {
+            if (hipHostMalloc(&slot.pin, 2 * kChunk, hipHostMallocDefault) != hipSuccess ||
+                hipStreamCreateWithFlags(&slot.stream, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&slot.done[0], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&slot.done[1], hipEventDisableTiming) != hipSuccess) {
+                if (slot.done[0]) (void)hipEventDestroy(slot.done[0]);
+                if (slot.done[1]) (void)hipEventDestroy(slot.done[1]);
+                if (slot.stream) (void)hipStreamDestroy(slot.stream);
                 if (slot.pin) (void)hipHostFree(slot.pin);
                 break;
             }
@@ -169,17 +177,35 @@ int sgz::copy_large(sgz_context *ctx, void *dst, const void *src, size_t bytes, 
             failed = 1;
             return;
         }
-        for (size_t c = next++; c < chunks && !failed; c = next++) {
-            const size_t off = c * kChunk, len = std::min(kChunk, bytes - off);
-            if (!to_host) std::memcpy(slot.pin, (const char *)src + off, len);
-            const hipError_t e = to_host ? hipMemcpyAsync(slot.pin, (const char *)src + off, len, hipMemcpyDeviceToHost, slot.stream)
-                                         : hipMemcpyAsync((char *)dst + off, slot.pin, len, hipMemcpyHostToDevice, slot.stream);
-            if (e != hipSuccess || hipStreamSynchronize(slot.stream) != hipSuccess) {
+        char *half[2] = {(char *)slot.pin, (char *)slot.pin + kChunk};
+        // what each half holds: chunk offset and length of a transfer in flight (len 0: nothing)
+        size_t off[2] = {0, 0}, len[2] = {0, 0};
+        auto retire = [&](int h) {  // waits for the transfer of half h; to the host: hands its data on
+            if (len[h] == 0) return true;
+            if (hipEventSynchronize(slot.done[h]) != hipSuccess) return false;
+            if (to_host) std::memcpy((char *)dst + off[h], half[h], len[h]);
+            len[h] = 0;
+            return true;
+        };
+        int h = 0;
+        for (size_t c = next++; c < chunks && !failed; c = next++, h ^= 1) {
+            if (!retire(h)) {
                 failed = 1;
                 break;
             }
-            if (to_host) std::memcpy((char *)dst + off, slot.pin, len);
+            off[h] = c * kChunk;
+            len[h] = std::min(kChunk, bytes - off[h]);
+            if (!to_host) std::memcpy(half[h], (const char *)src + off[h], len[h]);
+            const hipError_t e =
+                to_host ? hipMemcpyAsync(half[h], (const char *)src + off[h], len[h], hipMemcpyDeviceToHost, slot.stream)
+                        : hipMemcpyAsync((char *)dst + off[h], half[h], len[h], hipMemcpyHostToDevice, slot.stream);
+            if (e != hipSuccess || hipEventRecord(slot.done[h], slot.stream) != hipSuccess) {
+                failed = 1;
+                break;
+            }
         }
+        if (!retire(0) || !retire(1)) failed = 1;
+        if (failed) (void)hipStreamSynchronize(slot.stream);  // nothing of this call stays in flight
     };
     std::vector<std::thread> pool;
     for (const auto &slot : ctx->pin_pool) pool.emplace_back(worker, slot);

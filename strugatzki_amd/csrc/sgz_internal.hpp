@@ -202,8 +202,9 @@ struct sgz_context {
     std::vector<hipEvent_t> event_pool;
     hipStream_t copy_stream = nullptr;       // device-to-host result copies
     struct PinSlot {                         // staging of large copies from / to pageable memory (copy_large)
-        void *pin = nullptr;
-        hipStream_t stream = nullptr;
+        void *pin = nullptr;                 // two halves: one is filled or emptied by the host while the
+        hipStream_t stream = nullptr;        // other is in flight
+        hipEvent_t done[2] = {nullptr, nullptr};
     };
     std::vector<PinSlot> pin_pool;
     hipStream_t screen_stream = nullptr;     // screening runs (overlap with exact runs on `stream`)
