@@ -360,7 +360,8 @@ SGZ_API int sgz_sel_feed_gathered(sgz_selector *sel, const sgz_candidate *blocks
  * :399-411, without punch-out.  over_bounds != 0 lets numPerFile = 1 searches take the route of
  * sgz_corr_compact_bounded / sgz_sel_feed_screened (all files through the matrix-core kernel); everything
  * else, and every case that route cannot decide, goes: exact kernel + dense replay for the first
- * numMatches files, screening + threshold compaction + exact re-scoring for the rest, dense exact replay on
+ * numMatches files (and further ones while the set is not full), screening + threshold
+ * compaction + exact re-scoring for the rest, dense exact replay on
  * a candidate overflow.  matches_out receives at most min(out_capacity, num_matches) records in descending
  * similarity; file = index in the context.  `capacity` = candidate records fetched from the GPU at most.
  * `margin`: screened windows with sim > bound - margin are re-scored; negative = the default of the mode
@@ -377,7 +378,7 @@ SGZ_API int sgz_corr_search(sgz_context *ctx, int target_frames, int num_matches
  * loop would show them (sgz_corr_ring_runs, frames fetched from the contexts that hold them).  numPerFile = 1 with
  * half-precision screening available: every context finds the exact maxima of its files, the host merges and
  * replays; otherwise, and whenever that route cannot decide: exact kernel everywhere, dense replay of the first
- * numMatches files, threshold compaction of the rest.  matches_out: file = global index.  The result equals that
+ * numMatches files (more while the set is not full), threshold compaction of the rest.  matches_out: file = global index.  The result equals that
  * of one context holding all files in global order. */
 SGZ_API int sgz_corr_search_multi(sgz_context *const *ctxs, int num_ctx, const int32_t *const *global_ids,
                                   int num_files_total, int target_frames, int num_matches, int num_per_file,
