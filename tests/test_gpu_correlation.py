@@ -427,6 +427,30 @@ def test_compact_top_leaves_out_files_below_the_kth_bound(ctx):
     assert T2 == float("-inf") and {int(f) for f in top2["file"]} == set(range(nf))
 
 
+def test_compact_top_with_more_files_than_one_selection_round_holds(ctx):
+    """1100 small files: the k-th largest bound is selected over more keys than the selection kernel keeps in
+    registers (4 per thread of one workgroup); the threshold sits just below the k-th largest exact per-file
+    maximum and the replay over the files kept equals the reference loop."""
+    from strugatzki_amd.engine import Selector, match_tuple
+    L, ts, nf, frames, k = 64, 5, 1100, 80, 7
+    db = synth_db(nf, frames, make_plants(3, L, nf, frames, ts))
+    tgt = synth_target(ts, L)
+    norms = norms_default()
+    want, sims, boosts = O.correlation_run(corr_config(ts, L, num_matches=k, num_per_file=1), tgt, norms, db)
+    _load(ctx, db, norms)
+    ctx.corr_set_target(tgt[ts:ts + L], 0.5, 8.0)
+    ctx.corr_run_screen_f16(0, nf)
+    top, T = ctx.corr_compact_top(0, nf, k, 1 << 16)
+    exact_max = sorted((float(sims[f].max()) for f in range(nf)), reverse=True)
+    assert exact_max[k - 1] - 3e-3 <= T <= exact_max[k - 1]
+    files = {int(f) for f in top["file"]}
+    assert all(f in files for f in range(nf) if sims[f].max() >= T) and len(files) < nf // 4
+    sel = Selector(k, 1, 0, STEP, L)
+    assert sel.feed_top(top, T)
+    assert [match_tuple(m) for m in sel.result()] == [O.match_tuple(w) for w in want]
+    sel.close()
+
+
 @pytest.mark.parametrize("case", ["duplicate_head_files", "short_head_file", "single_file", "fewer_files_than_matches"])
 def test_search_over_bounds_and_its_fallbacks(ctx, case):
     """numPerFile = 1 with f16 screening searches over bounds; cases it cannot decide go to the exact path."""
