@@ -548,6 +548,34 @@ __global__ __launch_bounds__(1024) void file_const_kernel(FileDesc *__restrict__
     }
 }
 
+// window_static_kernel: for every window of the files of a half-precision preparation, the part of its bounds
+// that does not depend on the target's values (sgz::WindowStatic, 32 bytes), from the fp32 prefix records and the
+// fp64 tile bases.  Runs once per database / norms / target length, after tile_scan_kernel; the matrix-core
+// kernel then reads two 16-byte words per window instead of doing these statistics in its epilogue.
+__global__ __launch_bounds__(256) void window_static_kernel(const FileDesc *__restrict__ files,
+                                                            const TileDesc *__restrict__ tiles,
+                                                            const float4 *__restrict__ prefix,
+                                                            const double *__restrict__ tbase, int L, int numCh,
+                                                            int tileShift, float4 *__restrict__ wstat)
+{
+    const TileDesc td = tiles[blockIdx.x];
+    const FileDesc fd = files[td.file];
+    HalfPrefix hp;
+    hp.pre = prefix + fd.prefix_off / 4;  // (prefix_off counts four values per frame)
+    hp.tbase = tbase + fd.tbase_off;
+    hp.nptiles = fd.nptiles;
+    hp.tileShift = tileShift;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const long long o = (long long)td.o0 + k * 256 + threadIdx.x;
+        if (o < fd.num_windows) {
+            const WindowStatic ws = window_static(L, numCh, hp, (unsigned)o, window_records(hp, (unsigned)o, L), (double)fd.cT);
+            wstat[2 * (fd.win_off + o)] = make_float4(ws.rsdT, ws.dmT, ws.gT, ws.lnAvg);
+            wstat[2 * (fd.win_off + o) + 1] = make_float4(ws.rsdS, ws.dmS, ws.gS, __uint_as_float(ws.hTS));
+        }
+    }
+}
+
 // New target, same layout: the NaN marks the matrix-core kernel left (bit 2) belong to the previous target; the
 // range marks of the image (bit 1) stay.
 __global__ void clear_nan_flags_kernel(int *__restrict__ hflags, int n)
@@ -1357,7 +1385,17 @@ int build_layout(sgz_context *ctx)
         for (long long t = 0; t < ntiles; t++) ctx->h_tiles.push_back(TileDesc{f, (int)(t * kTileW)});
         ctx->tile_h_begin[f] = (int)ctx->h_tiles_h.size();
         if (halfOk)
-            for (long long t = 0; t < ntilesH; t++) ctx->h_tiles_h.push_back(TileDesc{f, (int)(t * kHTileW)});
+            for (long long t = 0; t < ntilesH; t++) {
+                HalfTile ht;
+                ht.file = f;
+                ht.o0 = (int)(t * kHTileW);
+                ht.valid = (int)std::min<long long>(kHTileW, fd.num_windows - t * kHTileW);
+                ht.pad = 0;
+                ht.planar = fd.planar_off + t * kHTileW;
+                ht.rowLen = fd.M * kR;
+                ht.win = fd.win_off + t * kHTileW;
+                ctx->h_tiles_h.push_back(ht);
+            }
         ctx->ptile_begin[f] = (int)ctx->h_ptiles.size();
         if (fd.num_windows > 0) {
             for (long long c0 = 0; c0 < M; c0 += ctx->prep_cb) ctx->h_ptiles.push_back(PrepTile{f, (int)c0});
@@ -1390,6 +1428,7 @@ int build_layout(sgz_context *ctx)
     if ((rc = ensure(ctx, ctx->d_sim, ctx->dense_cap, (size_t)wins))) return rc;
     if ((rc = ensure(ctx, ctx->d_boost, ctx->boost_cap, (size_t)wins))) return rc;
     if (halfOk && (rc = ensure(ctx, ctx->d_lo, ctx->lo_cap, (size_t)wins))) return rc;
+    if (halfOk && (rc = ensure(ctx, ctx->d_wstat_h, ctx->wstat_h_cap, (size_t)8 * (size_t)wins))) return rc;
     if (halfOk && (rc = ensure(ctx, ctx->d_lokey, ctx->lokey_cap, (size_t)2 * nf))) return rc;
     if (halfOk && nf)  // key of -inf in both arrays; files without windows keep it (no tile ever writes them)
         SGZ_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ctx->d_lokey), (int)0x807fffff, (size_t)2 * nf,
@@ -1405,7 +1444,7 @@ int build_layout(sgz_context *ctx)
         SGZ_HIP(ctx, hipMemcpyAsync(ctx->d_tiles, ctx->h_tiles.data(), sizeof(TileDesc) * ctx->h_tiles.size(),
                                     hipMemcpyHostToDevice, ctx->stream));
     if (!ctx->h_tiles_h.empty())
-        SGZ_HIP(ctx, hipMemcpyAsync(ctx->d_tiles_h, ctx->h_tiles_h.data(), sizeof(TileDesc) * ctx->h_tiles_h.size(),
+        SGZ_HIP(ctx, hipMemcpyAsync(ctx->d_tiles_h, ctx->h_tiles_h.data(), sizeof(HalfTile) * ctx->h_tiles_h.size(),
                                     hipMemcpyHostToDevice, ctx->stream));
     if (!ctx->h_ptiles.empty())
         SGZ_HIP(ctx, hipMemcpyAsync(ctx->d_ptiles, ctx->h_ptiles.data(), sizeof(PrepTile) * ctx->h_ptiles.size(),
@@ -1858,6 +1897,13 @@ static int corr_run_impl(sgz_context *ctx, int file_begin, int file_end, int mod
         SGZ_HIP(ctx, hipGetLastError());
     }
     if (half && !halfCached) {
+        const int s0 = ctx->tile_begin[file_begin], s1 = ctx->tile_begin[file_end];
+        if (s1 > s0) {
+            hipLaunchKernelGGL(window_static_kernel, dim3(s1 - s0), dim3(256), 0, stream, ctx->d_files, ctx->d_tiles + s0,
+                               reinterpret_cast<const float4 *>(ctx->d_prefix_h), ctx->d_tbase_h, ctx->cp.L, ctx->numCh,
+                               ctx->cp.prepTileShift, reinterpret_cast<float4 *>(ctx->d_wstat_h));
+            SGZ_HIP(ctx, hipGetLastError());
+        }
         ctx->hc_begin = file_begin;
         ctx->hc_end = file_end;
     }

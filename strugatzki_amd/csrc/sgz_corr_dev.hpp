@@ -92,8 +92,8 @@ __device__ __forceinline__ void window_result(const CorrParams &cp, const Epilog
 // hardware reciprocal, square root, log2, exp2), which the absolute slack of 1e-5 covers.
 // A window without spread gets (-inf, +inf); a boost within 1e-5 of the gate makes the bounds include 0, the
 // value of a gated window.
-// The part that does not depend on the cross terms is evaluated ahead of them (window_coeffs) and folded into
-// four numbers: sim ~ a * crossT + b * crossS - c, error bound |e|; e < 0 marks a boost next to the gate.
+// The part that does not depend on the cross terms is folded into four numbers (window_coeffs):
+// sim ~ a * crossT + b * crossS - c, error bound |e|; e < 0 marks a boost next to the gate.
 struct WindowCoeffs {
     float a, b, c, e;
 };
@@ -103,12 +103,7 @@ struct HalfPrefix {
     const double *tbase;  // 4 arrays of `nptiles` tile bases
     long long nptiles;
     int tileShift;
-    // optional: the tile bases a workgroup's windows can touch, staged in LDS by the caller --
-    // tab[(2 q + e) * kHalfTabTiles + j] = base of moment q of tile (e ? hi0 : lo0) + j
-    const double *tab;
-    unsigned lo0, hi0;
 };
-constexpr int kHalfTabTiles = 6;
 
 // The two prefix records of window o (no branch around the loads; fetched ahead of their use).
 struct WindowRecords {
@@ -119,38 +114,53 @@ __device__ __forceinline__ WindowRecords window_records(const HalfPrefix &hp, un
     return WindowRecords{hp.pre[o + (unsigned)L - 1], hp.pre[o > 0 ? o - 1 : 0]};
 }
 
-// cT: centring constant of the loudness channel of this file's image; relErrT / relErrS: relative error of the
-// cross terms of the two channel groups.  Half-precision values below 2^-14 round with an absolute error of up to
-// 2^-25 instead of a relative one: over a whole window that moves a normalised cross term by at most
-// 2^-25 (1 / sd_b + sqrt(1 + (dm / sd_b)^2) / sd_a), which is added.
-__device__ __forceinline__ WindowCoeffs window_coeffs(const CorrParams &cp, const HalfPrefix &hp, unsigned o,
-                                                      const WindowRecords &rec, double cT, float relErrT,
-                                                      float relErrS, float &boostOut)
+// What window_coeffs needs of a window that depends on the database, the norms and the target *length* only --
+// kept per window (32 bytes) from the first search on and reused by every later one, so that the epilogue of the
+// matrix-core kernel is a handful of fp32 operations on two 16-byte loads instead of fp64 statistics from
+// prefix records and tile bases:
+//   rsd = 1 / std-dev and dm = mean - centring constant of the two channel groups, lnAvg = ln(window's average
+//   loudness), g = dv / var (how far the fp32 prefix records can move 1 / sd; +inf where the window has no
+//   usable spread), h = rsd * E1 / n (what they can move the mean by, times rsd; the two h as half-precision
+//   numbers rounded up, in one word).
+struct WindowStatic {
+    float rsdT, dmT, gT, lnAvg;
+    float rsdS, dmS, gS;
+    unsigned int hTS;
+};
+
+__device__ __forceinline__ unsigned int half_bits_up(float x)  // a half-precision number >= x (x >= 0)
 {
-    constexpr float kSubAbs = 2.9802322e-8f;  // 2^-25
-    const double nTd = (double)cp.L, nSd = (double)cp.L * (double)(cp.numCh - 1);
-    const double rnT = 1.0 / nTd, rnS = 1.0 / nSd;  // wave-uniform: one division each, not one per window
-    const unsigned l1 = o > 0 ? o - 1 : 0, h1 = o + (unsigned)cp.L - 1;
+    _Float16 h = (_Float16)x;
+    unsigned short b;
+    __builtin_memcpy(&b, &h, 2);
+    if ((float)h < x) b++;  // next representable (also subnormal -> normal, max -> inf)
+    return b;
+}
+__device__ __forceinline__ float half_from_bits(unsigned int b)
+{
+    const unsigned short u = (unsigned short)b;
+    _Float16 h;
+    __builtin_memcpy(&h, &u, 2);
+    return (float)h;
+}
+
+// cT: centring constant of the loudness channel of this file's image.
+__device__ __forceinline__ WindowStatic window_static(int L, int numCh, const HalfPrefix &hp, unsigned o,
+                                                      const WindowRecords &rec, double cT)
+{
+    const double nTd = (double)L, nSd = (double)L * (double)(numCh - 1);
+    const double rnT = 1.0 / nTd, rnS = 1.0 / nSd;
+    const unsigned l1 = o > 0 ? o - 1 : 0, h1 = o + (unsigned)L - 1;
     const float4 ph = rec.hi, pl = rec.lo;
     const unsigned th = h1 >> hp.tileShift, tl = l1 >> hp.tileShift;
-    double bh[4], bl[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        if (hp.tab) {
-            bh[q] = hp.tab[(2 * q + 1) * kHalfTabTiles + (th - hp.hi0)];
-            bl[q] = hp.tab[(2 * q) * kHalfTabTiles + (tl - hp.lo0)];
-        } else {
-            bh[q] = hp.tbase[q * hp.nptiles + th];
-            bl[q] = hp.tbase[q * hp.nptiles + tl];
-        }
-    }
     const bool first = o == 0;  // nothing to subtract
     const float phv[4] = {ph.x, ph.y, ph.z, ph.w}, plv[4] = {pl.x, pl.y, pl.z, pl.w};
     double d[4];
     float E[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        d[q] = ((double)phv[q] + bh[q]) - (first ? 0.0 : (double)plv[q] + bl[q]);
+        const double bh = hp.tbase[q * hp.nptiles + th], bl = hp.tbase[q * hp.nptiles + tl];
+        d[q] = ((double)phv[q] + bh) - (first ? 0.0 : (double)plv[q] + bl);
         E[q] = 6.0e-8f * (fabsf(phv[q]) + (first ? 0.0f : fabsf(plv[q])));  // 2^-24 = 5.96e-8
     }
     const double dmTd = d[0] * rnT;
@@ -158,39 +168,63 @@ __device__ __forceinline__ WindowCoeffs window_coeffs(const CorrParams &cp, cons
     const double dmSd = d[2] * rnS;
     const double varS = d[3] * rnS - dmSd * dmSd;
     const float avgF = (float)(cT + dmTd);
-    const float kLn2 = 0.6931471805599453f, kLog2e = 1.4426950408889634f;
-    const float lnAvg = __builtin_amdgcn_logf(avgF) * kLn2;  // avg <= 0: NaN / -inf, the window reads as gated
-    const float boost = __builtin_amdgcn_exp2f(((float)cp.lnAvgIn - lnAvg) * (kLog2e / 0.6f));
+    WindowStatic ws;
+    ws.lnAvg = __builtin_amdgcn_logf(avgF) * 0.6931471805599453f;  // avg <= 0: NaN / -inf, the window reads as gated
+    float hT, hS;
+    {
+        const float rn = (float)rnT, dm = (float)dmTd, var = fmaxf((float)varT, 0.0f);
+        const float rsd = __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(var));  // sd = 0: inf, and g says so
+        const float dv = (E[1] + 2.0f * fabsf(dm) * E[0]) * rn;
+        ws.rsdT = rsd;
+        ws.dmT = dm;
+        ws.gT = var > 0.0f && 2.0f * dv <= var ? dv * (rsd * rsd) : INFINITY;
+        hT = rsd * E[0] * rn;
+    }
+    {
+        const float rn = (float)rnS, dm = (float)dmSd, var = fmaxf((float)varS, 0.0f);
+        const float rsd = __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(var));
+        const float dv = (E[3] + 2.0f * fabsf(dm) * E[2]) * rn;
+        ws.rsdS = rsd;
+        ws.dmS = dm;
+        ws.gS = var > 0.0f && 2.0f * dv <= var ? dv * (rsd * rsd) : INFINITY;
+        hS = rsd * E[2] * rn;
+    }
+    // (a NaN or negative h only occurs with g = +inf, which decides the bound)
+    ws.hTS = half_bits_up(hT >= 0.0f ? hT : INFINITY) | (half_bits_up(hS >= 0.0f ? hS : INFINITY) << 16);
+    return ws;
+}
+
+// relErrT / relErrS: relative error of the cross terms of the two channel groups.  Half-precision values below
+// 2^-14 round with an absolute error of up to 2^-25 instead of a relative one: over a whole window that moves a
+// normalised cross term by at most 2^-25 (1 / sd_b + sqrt(1 + (dm / sd_b)^2) / sd_a), which is added.
+__device__ __forceinline__ WindowCoeffs window_coeffs(const CorrParams &cp, const WindowStatic &ws, float relErrT,
+                                                      float relErrS, float &boostOut)
+{
+    constexpr float kSubAbs = 2.9802322e-8f;  // 2^-25
+    const float nT = (float)cp.L, nS = (float)cp.L * (float)(cp.numCh - 1);
+    const float kLog2e = 1.4426950408889634f;
+    const float boost = __builtin_amdgcn_exp2f(((float)cp.lnAvgIn - ws.lnAvg) * (kLog2e / 0.6f));
     boostOut = boost;
     WindowCoeffs wc = {0.0f, 0.0f, 0.0f, 0.0f};  // a gated window: sim = 0 exactly
     if (boost <= cp.maxBoost * 1.00001f) {
         float errT = 0.0f, errS = 0.0f;
         if (cp.w > 0.0f) {
-            const float rn = (float)rnT, dm = (float)dmTd, var = fmaxf((float)varT, 0.0f);
-            const float sd = __builtin_amdgcn_sqrtf(var);
-            const float rsd = __builtin_amdgcn_rcpf(sd);  // sd = 0: inf, and the error bound below says so
+            const float rsd = ws.rsdT, dm = ws.dmT;
             const float r = dm * rsd;
-            const float dv = (E[1] + 2.0f * fabsf(dm) * E[0]) * rn;
-            wc.a = (cp.w / ((float)cp.aStdT * (float)nTd)) * rsd;
+            wc.a = (cp.w / ((float)cp.aStdT * nT)) * rsd;
             wc.c = wc.a * dm * (float)cp.sumAT;
             const float q = __builtin_amdgcn_sqrtf(1.0f + r * r);
             const float eh = relErrT * q + kSubAbs * (rsd + q / (float)cp.aStdT);
-            errT = var > 0.0f && 2.0f * dv <= var ? eh + (1.0f + eh) * dv * (rsd * rsd) + fabsf(wc.a * (float)cp.sumAT) * E[0] * rn / cp.w
-                                    : INFINITY;
+            errT = eh + (1.0f + eh) * ws.gT + fabsf((float)cp.sumAT) / ((float)cp.aStdT * nT) * half_from_bits(ws.hTS);
         }
         if (cp.w < 1.0f) {
-            const float rn = (float)rnS, dm = (float)dmSd, var = fmaxf((float)varS, 0.0f);
-            const float sd = __builtin_amdgcn_sqrtf(var);
-            const float rsd = __builtin_amdgcn_rcpf(sd);
+            const float rsd = ws.rsdS, dm = ws.dmS;
             const float r = dm * rsd;
-            const float dv = (E[3] + 2.0f * fabsf(dm) * E[2]) * rn;
-            wc.b = ((1.0f - cp.w) / ((float)cp.aStdS * (float)nSd)) * rsd;
+            wc.b = ((1.0f - cp.w) / ((float)cp.aStdS * nS)) * rsd;
             wc.c += wc.b * dm * (float)cp.sumAS;
             const float q = __builtin_amdgcn_sqrtf(1.0f + r * r);
             const float eh = relErrS * q + kSubAbs * (rsd + q / (float)cp.aStdS);
-            errS = var > 0.0f && 2.0f * dv <= var
-                       ? eh + (1.0f + eh) * dv * (rsd * rsd) + fabsf(wc.b * (float)cp.sumAS) * E[2] * rn / (1.0f - cp.w)
-                       : INFINITY;
+            errS = eh + (1.0f + eh) * ws.gS + fabsf((float)cp.sumAS) / ((float)cp.aStdS * nS) * half_from_bits(ws.hTS >> 16);
         }
         wc.e = errT * cp.w + errS * (1.0f - cp.w) + 1e-5f;
         if (boost > cp.maxBoost * 0.99999f) wc.e = -wc.e;  // the exact path may gate this window

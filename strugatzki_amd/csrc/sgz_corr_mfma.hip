@@ -91,21 +91,20 @@ constexpr int half_wgs_per_cu(int NB) { return NB <= 5 ? 3 : 2; }
 // the phase, so no registers hold data in flight.
 template <int NB>
 __global__ __launch_bounds__(kHThreads, 2 * half_wgs_per_cu(NB)) void corr_mfma_kernel(
-    const FileDesc *__restrict__ files, const TileDesc *__restrict__ tiles, const _Float16 *__restrict__ planarH,
-    const float4 *__restrict__ prefix, const double *__restrict__ tbase, const uint32_t *__restrict__ aimg,
-    CorrParams cp, HalfGeom hg, float *__restrict__ simOut, float *__restrict__ boostOut, float *__restrict__ loOut,
-    int *__restrict__ lokey, int *__restrict__ lokeyNext, int *__restrict__ hflags)
+    const HalfTile *__restrict__ tiles, const _Float16 *__restrict__ planarH, const float4 *__restrict__ wstat,
+    const uint32_t *__restrict__ aimg, CorrParams cp, HalfGeom hg, float *__restrict__ simOut,
+    float *__restrict__ boostOut, float *__restrict__ loOut, int *__restrict__ lokey, int *__restrict__ lokeyNext,
+    int *__restrict__ hflags)
 {
     constexpr int kHTileW = NB * 256, kHSlabFloats = half_slab_floats(NB);
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const TileDesc td = tiles[blockIdx.x];
-    const FileDesc fd = files[td.file];
+    const HalfTile td = tiles[blockIdx.x];
     const size_t bufBytes = half_buf_bytes(hg.XU, hg.LAd, NB);
-    const long long rowLen = fd.M * kR;
-    const _Float16 *fplanar = planarH + fd.planar_off + td.o0;
+    const long long rowLen = td.rowLen;
+    const _Float16 *fplanar = planarH + td.planar;
 
     // Staging through buffer loads with the LDS as destination: the descriptor carries the wave-uniform row
     // base and the valid length (lanes past it fill padding with zeros), the lane its 16-byte offset.  (The
@@ -241,39 +240,18 @@ __global__ __launch_bounds__(kHThreads, 2 * half_wgs_per_cu(NB)) void corr_mfma_
             for (int t = 0; t < NB; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
-    // The prefix records of this thread's windows are requested before the last reduction and arrive during it;
-    // the part of the bounds that does not depend on the cross terms is evaluated here, after the matrix work,
-    // so that it holds no registers during it.
-    HalfPrefix hp;
-    hp.pre = prefix + fd.prefix_off / 4;  // (prefix_off counts four values per frame)
-    hp.tbase = tbase + fd.tbase_off;
-    hp.nptiles = fd.nptiles;
-    hp.tileShift = cp.prepTileShift;
-    hp.tab = nullptr;
-    // The tile bases this tile's windows can touch (a handful per moment and window end) go through LDS: one
-    // fetch per workgroup, in flight during the reduction, instead of eight per window.
-    const bool useTab = (kHTileW >> cp.prepTileShift) + 2 <= kHalfTabTiles;
-    hp.lo0 = (unsigned)(td.o0 > 0 ? td.o0 - 1 : 0) >> cp.prepTileShift;
-    hp.hi0 = (unsigned)(td.o0 + cp.L - 1) >> cp.prepTileShift;
-    double tabValue = 0.0;
-    if (useTab && tid < 8 * kHalfTabTiles) {
-        const int mq = tid / (2 * kHalfTabTiles), e = (tid / kHalfTabTiles) & 1, j = tid % kHalfTabTiles;
-        const long long tile = min((long long)(e ? hp.hi0 : hp.lo0) + j, (long long)fd.nptiles - 1);
-        tabValue = hp.tbase[mq * fd.nptiles + tile];
-    }
-    WindowRecords rec[kPerThread];
+    // What the bounds need of every window besides its cross terms (WindowStatic: two 16-byte loads a window,
+    // kept from the first search over this database on) is requested before the last reduction and arrives
+    // during it.
+    float4 ws0[kPerThread], ws1[kPerThread];
 #pragma unroll
     for (int k = 0; k < kPerThread; k++) {
-        const long long o = (long long)td.o0 + tid + k * kHThreads;
-        rec[k] = window_records(hp, (tid + k * kHThreads < kHTileW && o < fd.num_windows) ? (unsigned)o : 0u, cp.L);
+        const int wdw = tid + k * kHThreads;
+        const long long w = td.win + (wdw < td.valid ? wdw : 0);
+        ws0[k] = wstat[2 * w];
+        ws1[k] = wstat[2 * w + 1];
     }
     reduce(redT4, acc);
-    if (useTab) {  // behind the two slabs of the loudness sums
-        double *tab = reinterpret_cast<double *>(redT4) + kHSlabFloats;
-        if (tid < 8 * kHalfTabTiles) tab[tid] = tabValue;
-        __syncthreads();
-        hp.tab = tab;
-    }
     CorrParams cph = cp;  // the statistics of the half-precision target image
     cph.sumAT = hg.sumAT;
     cph.sumAS = hg.sumAS;
@@ -283,15 +261,17 @@ __global__ __launch_bounds__(kHThreads, 2 * half_wgs_per_cu(NB)) void corr_mfma_
 #pragma unroll
     for (int k = 0; k < kPerThread; k++) {
         const int wdw = tid + k * kHThreads;
-        const long long o = (long long)td.o0 + wdw;
-        if (wdw < kHTileW && o < fd.num_windows) {
+        if (wdw < td.valid) {
             float sim, lo;
             float boost;
-            const WindowCoeffs wc = window_coeffs(cph, hp, (unsigned)o, rec[k], (double)fd.cT, hg.relErrT, hg.relErrS, boost);
+            WindowStatic ws;
+            ws.rsdT = ws0[k].x, ws.dmT = ws0[k].y, ws.gT = ws0[k].z, ws.lnAvg = ws0[k].w;
+            ws.rsdS = ws1[k].x, ws.dmS = ws1[k].y, ws.gS = ws1[k].z, ws.hTS = __float_as_uint(ws1[k].w);
+            const WindowCoeffs wc = window_coeffs(cph, ws, hg.relErrT, hg.relErrS, boost);
             window_bounds(wc, red_read(redT4, wdw), red_read(redS4, wdw), sim, lo);
-            boostOut[fd.win_off + o] = boost;
-            simOut[fd.win_off + o] = sim;
-            loOut[fd.win_off + o] = lo;
+            boostOut[td.win + wdw] = boost;
+            simOut[td.win + wdw] = sim;
+            loOut[td.win + wdw] = lo;
             best = fmaxf(best, lo);
             bad |= (lo != lo) || (sim != sim);
         }
@@ -303,7 +283,7 @@ __global__ __launch_bounds__(kHThreads, 2 * half_wgs_per_cu(NB)) void corr_mfma_
         best = fmaxf(best, __shfl_xor(best, off, 64));
         bad |= __shfl_xor(bad, off, 64);
     }
-    float *wbest = reinterpret_cast<float *>(lds) + 2 * kHSlabFloats + 128;  // behind the sums (and a table) of buffer 0
+    float *wbest = reinterpret_cast<float *>(lds) + 2 * kHSlabFloats;  // behind the sums of buffer 0
     int *wbad = reinterpret_cast<int *>(wbest) + kHWaves;
     if (lane == 0) {
         wbest[q] = best;
@@ -462,9 +442,8 @@ int half_screen_launch(sgz_context *ctx, int tile_begin, int tile_end, hipStream
             SGZ_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
         hipExtLaunchKernelGGL(kern, dim3(tile_end - tile_begin), dim3(kHThreads), ldsBytes, stream, start, stop, 0,
-                              ctx->d_files, ctx->d_tiles_h + tile_begin, planarH,
-                              reinterpret_cast<const float4 *>(ctx->d_prefix_h), ctx->d_tbase_h, aimg, ctx->cp, hg,
-                              ctx->d_sim, ctx->d_boost, ctx->d_lo, lokey, lokeyNext, ctx->d_hflags);
+                              ctx->d_tiles_h + tile_begin, planarH, reinterpret_cast<const float4 *>(ctx->d_wstat_h),
+                              aimg, ctx->cp, hg, ctx->d_sim, ctx->d_boost, ctx->d_lo, lokey, lokeyNext, ctx->d_hflags);
         SGZ_HIP(ctx, hipGetLastError());
         return SGZ_OK;
     };

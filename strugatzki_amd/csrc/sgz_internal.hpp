@@ -41,6 +41,18 @@ struct TileDesc {
     int o0;  // first window of the tile
 };
 
+// A tile of the matrix-core screening kernel: everything a workgroup needs of its file, so that one (scalar)
+// load of this record is all that stands between the start of a workgroup and its first staging loads.
+struct HalfTile {
+    int file;
+    int o0;                  // first window of the tile
+    int valid;               // windows of the file in this tile (>= 1)
+    int pad;
+    long long planar;        // offset (elements) of the tile's first frame in channel 0 of the half-precision image
+    long long rowLen;        // elements per channel row of the file's image
+    long long win;           // index of the tile's first window in the dense per-window arrays
+};
+
 struct PrepTile {
     int file;
     int chunk0;  // first chunk of the tile
@@ -125,9 +137,9 @@ struct sgz_context {
     std::vector<int> ptile_begin;
     std::vector<float *> stale_images;       // L-frame images of files shorter than the target (see build_layout)
     std::map<int, std::vector<float>> ring_images;  // caller-supplied ring contents behind a short file's own frames
-    std::vector<sgz::TileDesc> h_tiles_h;    // tiles of the matrix-core screening kernel
+    std::vector<sgz::HalfTile> h_tiles_h;    // tiles of the matrix-core screening kernel
     std::vector<int> tile_h_begin;
-    sgz::TileDesc *d_tiles_h = nullptr;
+    sgz::HalfTile *d_tiles_h = nullptr;
     size_t d_tiles_h_cap = 0;
     int prep_cb = 64;                        // chunks per prep tile
     sgz::FileDesc *d_files = nullptr;
@@ -167,6 +179,8 @@ struct sgz_context {
     size_t prefix_h_cap = 0;
     double *d_tbase_h = nullptr;             // tile bases of those sums
     size_t tbase_h_cap = 0;
+    float *d_wstat_h = nullptr;              // per window: the target-independent part of its bounds (8 floats,
+    size_t wstat_h_cap = 0;                  // sgz::WindowStatic), built with the image and kept as long as it
     int hc_begin = 0, hc_end = 0;
     float *d_thr = nullptr;                  // smallest of the head files' bounds (filter of the tail files)
     size_t thr_cap = 0;
