@@ -135,7 +135,7 @@ def main() -> int:
     ap.add_argument("--settle-ms", type=float, default=100.0,
                     help="untimed steps for about this long (counted as 0.3 ms each) before the warm-up steps, so that the "
                          "clocks have settled")
-    ap.add_argument("--timing-every", type=int, default=8,
+    ap.add_argument("--timing-every", type=int, default=32,
                     help="HIP events with one launch in n of the dominant kernel (matrix-core path).  A launch that "
                          "carries events costs the host about 20 us more than one that does not (measured: "
                          "tools/search_loop.cpp), a tenth of a step at the default workload, so the kernel's average "
