@@ -441,9 +441,15 @@ int half_screen_launch(sgz_context *ctx, int tile_begin, int tile_end, hipStream
         if (ldsBytes > 64 * 1024)
             SGZ_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
-        hipExtLaunchKernelGGL(kern, dim3(tile_end - tile_begin), dim3(kHThreads), ldsBytes, stream, start, stop, 0,
-                              ctx->d_tiles_h + tile_begin, planarH, reinterpret_cast<const float4 *>(ctx->d_wstat_h),
-                              aimg, ctx->cp, hg, ctx->d_sim, ctx->d_boost, ctx->d_lo, lokey, lokeyNext, ctx->d_hflags);
+        if (start || stop)
+            hipExtLaunchKernelGGL(kern, dim3(tile_end - tile_begin), dim3(kHThreads), ldsBytes, stream, start, stop, 0,
+                                  ctx->d_tiles_h + tile_begin, planarH, reinterpret_cast<const float4 *>(ctx->d_wstat_h),
+                                  aimg, ctx->cp, hg, ctx->d_sim, ctx->d_boost, ctx->d_lo, lokey, lokeyNext,
+                                  ctx->d_hflags);
+        else
+            hipLaunchKernelGGL(kern, dim3(tile_end - tile_begin), dim3(kHThreads), ldsBytes, stream,
+                               ctx->d_tiles_h + tile_begin, planarH, reinterpret_cast<const float4 *>(ctx->d_wstat_h),
+                               aimg, ctx->cp, hg, ctx->d_sim, ctx->d_boost, ctx->d_lo, lokey, lokeyNext, ctx->d_hflags);
         SGZ_HIP(ctx, hipGetLastError());
         return SGZ_OK;
     };
