@@ -347,9 +347,8 @@ int half_screen_pick_tile(sgz_context *ctx, const long long *numWindows, int num
 {
     if (ctx->hg.S2 <= 0) return SGZ_OK;
     int numCUs = 256;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0)
-        numCUs = prop.multiProcessorCount;
+    if (hipDeviceGetAttribute(&numCUs, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || numCUs < 1)
+        numCUs = 256;
     int forced = 0;
     if (const char *e = std::getenv("SGZ_HALF_NB")) forced = std::atoi(e);
     double bestCost = 0.0;
