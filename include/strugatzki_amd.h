@@ -204,11 +204,13 @@ SGZ_API int sgz_corr_run_screen(sgz_context *ctx, int file_begin, int file_end);
  * error the operand roundings can cause for that window (about 1e-3 * sqrt(1 +
  * (mean offset / std-dev)^2); observed errors are near 1e-5), so that a
  * threshold test never loses a window; boosts are fp32 evaluations (about 1e-6).  Several times
- * the throughput of sgz_corr_run_screen.  Only for normalised features
- * (sgz_set_norms with norms) and targets whose staged channel fits LDS:
- * sgz_corr_screen_f16_available tells (1 / 0), and the run fails with
- * SGZ_E_STATE otherwise.  A file whose normalised values leave the
- * half-precision range makes sgz_corr_compact* over it report SGZ_E_OVERFLOW. */
+ * the throughput of sgz_corr_run_screen.  For targets whose staged channel
+ * fits LDS (up to about 12 500 frames) and whose centred values stay within
+ * the half-precision range (with or without normalisation: every file's image
+ * is centred on the file's own mean level): sgz_corr_screen_f16_available
+ * tells (1 / 0), and the run fails with SGZ_E_STATE otherwise.  A file whose
+ * values leave the half-precision range makes sgz_corr_compact* over it
+ * report SGZ_E_OVERFLOW. */
 SGZ_API int sgz_corr_run_screen_f16(sgz_context *ctx, int file_begin, int file_end);
 SGZ_API int sgz_corr_screen_f16_available(const sgz_context *ctx);
 

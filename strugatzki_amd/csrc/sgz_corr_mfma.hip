@@ -329,9 +329,9 @@ static bool half_geom(int L, int NB, HalfGeom &hg)
 
 bool half_screen_fits(const sgz_context *ctx)
 {
-    HalfGeom hg{};
-    // Half precision needs a bounded value range: only normalised features qualify.
-    return ctx->have_target && ctx->norm.enabled && half_geom(ctx->cp.L, kHalfWidths[0], hg);
+    // (half precision needs a bounded value range: a target that leaves it has no image, half_screen_set_target;
+    // database files that leave it are marked by the preparation and sent to the exact path)
+    return ctx->have_target && ctx->hg.S2 > 0;
 }
 
 // The tile width for the files and the target of the context's layout: the variant with the smallest estimate of
@@ -390,6 +390,12 @@ int half_screen_set_target(sgz_context *ctx, const std::vector<double> &aprime, 
         ctx->hg = HalfGeom{};
         return SGZ_OK;
     }
+    for (int c = 0; c < numCh; c++)
+        for (int i = 0; i < L; i++)
+            if (!(std::fabs(aprime[(size_t)c * Lpad + i]) <= 60000.0)) {  // also NaN: no half-precision image
+                ctx->hg = HalfGeom{};
+                return SGZ_OK;
+            }
     const size_t perCopy = (size_t)2 * hg.LAd;  // halfwords
     std::vector<uint16_t> img((size_t)numCh * 2 * perCopy, 0);
     double sumT = 0.0, sumS = 0.0;

@@ -293,17 +293,47 @@ def test_new_target_of_the_same_length_reuses_the_half_precision_preparation(ctx
     assert [(g.file, g.start, g.stop) for g in got] == [(w.file, w.start, w.stop) for w in want]
 
 
-def test_screening_f16_needs_norms(ctx):
+def test_screening_f16_without_normalisation(ctx):
+    """Features that are not normalised go through the matrix-core kernel as well (every file's image is centred
+    on the file's own mean level); only values beyond the half-precision range do not: a target like that has no
+    image (the search then screens with the fp32 kernel), a database file like that is marked and sent to the
+    exact path.  Same matches as the oracle either way."""
     import strugatzki_amd as S
     from strugatzki_amd import _native as N
-    db = synth_db(1, 300)
+    L, ts, nf, frames = 431, 20, 6, 2583
+    db = synth_db(nf, frames, make_plants(2, L, nf, frames, ts))
+    tgt = synth_target(ts, L)
+    cfg = corr_config(ts, L, num_matches=3, normalize=False)
+    want, sims, boosts = O.correlation_run(cfg, tgt, None, db)
     _load(ctx, db, None)
-    ctx.corr_set_target(synth_target(3, 50)[3:53], 0.5, 8.0)
+    ctx.corr_set_target(tgt[ts:ts + L], 0.5, 8.0)
+    assert ctx.screen_f16_available
+    ctx.corr_run_screen_f16(0, nf)
+    for f in range(nf):
+        gs, _ = ctx.corr_read_dense(f)
+        open_ = boosts[f] <= 8.0 * (1 - 1e-4)
+        d = gs.astype(np.float64) - sims[f]
+        assert np.all(d[open_] >= 0.0) and np.all(d[open_] <= 2e-2)
+    got = S.search(ctx, S.SearchParams(3, 1, 0, STEP))
+    assert [(g.sim, g.file, g.start, g.stop) for g in got] == [(w.sim, w.file, w.start, w.stop) for w in want]
+    # a database file beyond the half-precision range: marked, the search takes the exact path for the result
+    big = [x.copy() for x in db]
+    big[2] = big[2] * np.float32(3.0e5)
+    want2, _, _ = O.correlation_run(cfg, tgt, None, big, dense=False)
+    _load(ctx, big, None)
+    ctx.corr_set_target(tgt[ts:ts + L], 0.5, 8.0)
+    got2 = S.search(ctx, S.SearchParams(3, 1, 0, STEP))
+    assert [(g.sim, g.file, g.start, g.stop) for g in got2] == [(w.sim, w.file, w.start, w.stop) for w in want2]
+    # a target beyond the range: no image, "auto" screens with the fp32 kernel
+    tbig = tgt * np.float32(3.0e5)
+    want3, _, _ = O.correlation_run(cfg, tbig, None, db, dense=False)
+    _load(ctx, db, None)
+    ctx.corr_set_target(tbig[ts:ts + L], 0.5, 8.0)
     assert not ctx.screen_f16_available
     with pytest.raises(N.NativeError):
-        ctx.corr_run_screen_f16(0, 1)
-    got = S.search(ctx, S.SearchParams(1, 1, 0, STEP))  # "auto" falls back to the fp32 screening kernel
-    assert len(got) == 1
+        ctx.corr_run_screen_f16(0, nf)
+    got3 = S.search(ctx, S.SearchParams(3, 1, 0, STEP))
+    assert [(g.file, g.start, g.stop) for g in got3] == [(w.file, w.start, w.stop) for w in want3]
 
 
 @pytest.mark.parametrize("screen", [False, "f32", "f16"])
