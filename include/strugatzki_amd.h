@@ -214,6 +214,13 @@ SGZ_API int sgz_corr_run_screen(sgz_context *ctx, int file_begin, int file_end);
 SGZ_API int sgz_corr_run_screen_f16(sgz_context *ctx, int file_begin, int file_end);
 SGZ_API int sgz_corr_screen_f16_available(const sgz_context *ctx);
 
+/* Starts the transfer of sim / boost of all windows of files [file_begin, file_end) to the host, in order
+ * behind the runs queued so far (a kernel writes them to pinned memory); the next sgz_corr_read_dense_range over
+ * exactly these files waits for it and copies from there.  For a caller that queues more GPU work between a run
+ * and the read of its results (sgz_corr_search: the screening of the other files behind the exact run over the
+ * first ones) -- a plain read would be carried out behind that work.  Ranges of more than 4 Mi windows are left
+ * to the plain read.  No counterpart in the reference (its results are in host memory to begin with). */
+SGZ_API int sgz_corr_prefetch_dense(sgz_context *ctx, int file_begin, int file_end);
 /* Copies sim / boost of all windows of one file to the host (either pointer
  * may be NULL).  Synchronises the stream. */
 SGZ_API int sgz_corr_read_dense(sgz_context *ctx, int file, float *sim_out, float *boost_out);

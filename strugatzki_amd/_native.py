@@ -111,6 +111,7 @@ SIGNATURES = {
     "sgz_corr_compact_rescored": (C.c_int, [_vp, C.c_int, C.c_int, C.c_float, _vp, C.c_int64, C.POINTER(C.c_int64)]),
     "sgz_corr_compact_bounded": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int64, C.POINTER(C.c_int64)]),
     "sgz_corr_compact_bounded_device": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int64, _vp]),
+    "sgz_corr_prefetch_dense": (C.c_int, [_vp, C.c_int, C.c_int]),
     "sgz_corr_compact_top": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int64, C.POINTER(C.c_int64),
                                        C.POINTER(C.c_float)]),
     "sgz_corr_compact_top_device": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int64, _vp]),

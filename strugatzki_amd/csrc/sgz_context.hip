@@ -63,10 +63,11 @@ void sgz_destroy(sgz_context *ctx)
                     ctx->d_files,    ctx->d_tiles,    ctx->d_tiles_h, ctx->d_ptiles,  ctx->d_planar, ctx->d_prefix,
                     ctx->d_tbase,    ctx->d_sim,      ctx->d_boost,   ctx->d_cand,    ctx->d_hflags,
                     ctx->d_lo,       ctx->d_suspect,  ctx->d_done,     ctx->d_lokey,    ctx->d_thr,      ctx->d_rs_part,  ctx->d_normtab,
-                    ctx->d_prefix_h, ctx->d_tbase_h, ctx->d_wstat_h};
+                    ctx->d_prefix_h, ctx->d_tbase_h, ctx->d_wstat_h, ctx->d_prefetch_done};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+    if (ctx->h_dense_pin) (void)hipHostFree(ctx->h_dense_pin);
     for (auto &slot : ctx->pin_pool) {
         (void)hipEventDestroy(slot.done[0]);
         (void)hipEventDestroy(slot.done[1]);

@@ -1179,6 +1179,33 @@ __global__ __launch_bounds__(kRsThreads) void rescore_pass_kernel(
 
 // Where the last workgroup of rescore_final_kernel leaves a copy of the result for the host: pinned memory
 // the host polls, which saves a copy command and the wake-up of a blocking stream wait per search.
+// sgz_corr_prefetch_dense: similarities and boosts of a run of windows to pinned host memory, then a sequence
+// word the host polls (the last workgroup publishes it).  A copy command on another stream would be carried
+// out by a copy kernel on the compute queue, behind whatever kernel the caller has queued next -- for the head
+// of a search that is the screening run over all other files.
+__global__ __launch_bounds__(256) void dense_to_host_kernel(const float *__restrict__ sim, const float *__restrict__ boost,
+                                                            long long n, float *__restrict__ simHost,
+                                                            float *__restrict__ boostHost, unsigned int *done,
+                                                            unsigned long long *seqHost, unsigned long long seq)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        simHost[i] = sim[i];
+        boostHost[i] = boost[i];
+    }
+    __shared__ bool isLast;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence_system();
+        isLast = atomicAdd(done, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (isLast && threadIdx.x == 0) {
+        __threadfence_system();
+        *done = 0u;
+        __hip_atomic_store(seqHost, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 struct HostReport {
     unsigned long long *host;       // pinned: headers and records as in the device buffer; word maxWords = sequence
     const unsigned long long *dev;  // device buffer: [two count headers][records]
@@ -1419,6 +1446,7 @@ int build_layout(sgz_context *ctx)
     if ((rc = ensure(ctx, ctx->d_hflags, ctx->hflags_cap, (size_t)nf))) return rc;
     if (nf) SGZ_HIP(ctx, hipMemsetAsync(ctx->d_hflags, 0, sizeof(int) * nf, ctx->stream));
     ctx->hc_begin = ctx->hc_end = 0;  // no half-precision preparation of this layout yet
+    ctx->prefetch_valid = false;
     if (halfOk) {
         if ((rc = ensure(ctx, ctx->d_prefix_h, ctx->prefix_h_cap, (size_t)prefix))) return rc;
         if ((rc = ensure(ctx, ctx->d_tbase_h, ctx->tbase_h_cap, (size_t)tb))) return rc;
@@ -1836,6 +1864,8 @@ static int corr_run_impl(sgz_context *ctx, int file_begin, int file_end, int mod
     ctx->last_windows = 0;
     ctx->last_flops = 0.0;
     if (file_begin == file_end) return SGZ_OK;
+    if (ctx->prefetch_valid && file_begin < ctx->prefetch_fe && file_end > ctx->prefetch_fb)
+        ctx->prefetch_valid = false;  // these files get new values
 
     const int pt0 = ctx->ptile_begin[file_begin], pt1 = ctx->ptile_begin[file_end];
     const bool half = mode == kRunScreenF16;
@@ -1980,6 +2010,67 @@ static int corr_run_impl(sgz_context *ctx, int file_begin, int file_end, int mod
     return SGZ_OK;
 }
 
+// Pinned staging of dense read-backs: room for `count` similarities and as many boosts (up to 16 MB each; a copy
+// straight into pageable memory is staged by the runtime in small pieces, each with its own wait) and the
+// sequence word of a prefetch.  False when the range is larger or no pinned memory is to be had.
+static bool dense_staging(sgz_context *ctx, size_t count)
+{
+    constexpr size_t kPinFloats = (size_t)4 << 20;
+    if (count == 0 || count > kPinFloats) return false;
+    if (ctx->dense_pin_floats < count) {
+        // (a prefetch kernel may still be writing into the buffer that is about to go)
+        if (ctx->h_dense_pin && ctx->prefetch_seq > 0) (void)hipStreamSynchronize(ctx->stream);
+        if (ctx->h_dense_pin) (void)hipHostFree(ctx->h_dense_pin);
+        ctx->h_dense_pin = nullptr;
+        ctx->dense_pin_floats = 0;
+        ctx->prefetch_valid = false;
+        const size_t want = std::min(kPinFloats, std::max(count, (size_t)1 << 18));
+        if (hipHostMalloc(reinterpret_cast<void **>(&ctx->h_dense_pin), 2 * want * sizeof(float) + 64, hipHostMallocDefault) !=
+            hipSuccess) {
+            ctx->h_dense_pin = nullptr;
+            return false;
+        }
+        ctx->dense_pin_floats = want;
+        std::memset(ctx->h_dense_pin + 2 * want, 0, 64);
+    }
+    return true;
+}
+
+int sgz_corr_prefetch_dense(sgz_context *ctx, int file_begin, int file_end)
+{
+    if (!ctx) return SGZ_E_ARG;
+    if (ctx->layout_dirty || !ctx->have_target) return ctx->fail(SGZ_E_STATE, "no correlation results");
+    const int nf = (int)ctx->files.size();
+    if (file_begin < 0 || file_end > nf || file_begin > file_end) return ctx->fail(SGZ_E_ARG, "bad file range");
+    ctx->prefetch_valid = false;
+    if (file_begin == file_end) return SGZ_OK;
+    SGZ_HIP(ctx, hipSetDevice(ctx->device));
+    const long long w0 = ctx->h_files[file_begin].win_off;
+    const long long w1 = ctx->h_files[file_end - 1].win_off + ctx->h_files[file_end - 1].num_windows;
+    if (!dense_staging(ctx, (size_t)(w1 - w0))) return SGZ_OK;  // too large: the read will copy the plain way
+    bool covered = false;
+    for (auto &run : ctx->runs)
+        if (run.fb < file_end && run.fe > file_begin) {
+            const int wrc = ctx->wait_for_run(run, ctx->stream);
+            if (wrc) return wrc;
+            covered = true;
+        }
+    if (!covered) return ctx->fail(SGZ_E_STATE, "sgz_corr_run has not covered these files");
+    int rc;
+    if ((rc = ensure(ctx, ctx->d_prefetch_done, ctx->prefetch_done_cap, (size_t)1))) return rc;
+    if (ctx->prefetch_seq == 0) SGZ_HIP(ctx, hipMemsetAsync(ctx->d_prefetch_done, 0, sizeof(unsigned int), ctx->stream));
+    const unsigned long long seq = ++ctx->prefetch_seq;
+    const int grid = (int)std::min<long long>((w1 - w0 + 255) / 256, 512);
+    hipLaunchKernelGGL(dense_to_host_kernel, dim3(grid), dim3(256), 0, ctx->stream, ctx->d_sim + w0, ctx->d_boost + w0,
+                       w1 - w0, ctx->h_dense_pin, ctx->h_dense_pin + ctx->dense_pin_floats, ctx->d_prefetch_done,
+                       reinterpret_cast<unsigned long long *>(ctx->h_dense_pin + 2 * ctx->dense_pin_floats), seq);
+    SGZ_HIP(ctx, hipGetLastError());
+    ctx->prefetch_valid = true;
+    ctx->prefetch_fb = file_begin;
+    ctx->prefetch_fe = file_end;
+    return SGZ_OK;
+}
+
 int sgz_corr_read_dense_range(sgz_context *ctx, int file_begin, int file_end, float *sim_out, float *boost_out)
 {
     if (!ctx) return SGZ_E_ARG;
@@ -2000,12 +2091,45 @@ int sgz_corr_read_dense_range(sgz_context *ctx, int file_begin, int file_end, fl
     if (!covered) return ctx->fail(SGZ_E_STATE, "sgz_corr_run has not covered these files");
     const long long w0 = ctx->h_files[file_begin].win_off;
     const long long w1 = ctx->h_files[file_end - 1].win_off + ctx->h_files[file_end - 1].num_windows;
-    const size_t bytes = sizeof(float) * (size_t)(w1 - w0);
+    const size_t count = (size_t)(w1 - w0), bytes = sizeof(float) * count;
+    if (ctx->prefetch_valid && ctx->prefetch_fb == file_begin && ctx->prefetch_fe == file_end) {
+        // a copy by kernel is on its way (or done): wait for its sequence word
+        ctx->prefetch_valid = false;
+        const unsigned long long *flag =
+            reinterpret_cast<const unsigned long long *>(ctx->h_dense_pin + 2 * ctx->dense_pin_floats);
+        const auto t0 = std::chrono::steady_clock::now();
+        bool arrived = false;
+        for (unsigned long long spins = 0;; spins++) {
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == ctx->prefetch_seq) {
+                arrived = true;
+                break;
+            }
+            if ((spins & 0xffff) == 0xffff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) break;
+        }
+        if (arrived) {
+            if (sim_out) std::memcpy(sim_out, ctx->h_dense_pin, bytes);
+            if (boost_out) std::memcpy(boost_out, ctx->h_dense_pin + ctx->dense_pin_floats, bytes);
+            return SGZ_OK;
+        }
+        SGZ_HIP(ctx, hipStreamSynchronize(ctx->stream));  // something is wrong on the device: this reports it
+    }
+    // (while a prefetch of other files is pending the staging buffer is its: copy the plain way; an abandoned
+    // prefetch -- its files were run again -- may still be writing: let it finish first)
+    if (!ctx->prefetch_valid && ctx->prefetch_seq > 0 && ctx->h_dense_pin &&
+        __atomic_load_n(reinterpret_cast<const unsigned long long *>(ctx->h_dense_pin + 2 * ctx->dense_pin_floats),
+                        __ATOMIC_ACQUIRE) != ctx->prefetch_seq)
+        SGZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const bool staged = !ctx->prefetch_valid && dense_staging(ctx, count);
+    float *simTo = staged ? ctx->h_dense_pin : sim_out, *boostTo = staged ? ctx->h_dense_pin + ctx->dense_pin_floats : boost_out;
     if (bytes && sim_out)
-        SGZ_HIP(ctx, hipMemcpyAsync(sim_out, ctx->d_sim + w0, bytes, hipMemcpyDeviceToHost, ctx->copy_stream));
+        SGZ_HIP(ctx, hipMemcpyAsync(simTo, ctx->d_sim + w0, bytes, hipMemcpyDeviceToHost, ctx->copy_stream));
     if (bytes && boost_out)
-        SGZ_HIP(ctx, hipMemcpyAsync(boost_out, ctx->d_boost + w0, bytes, hipMemcpyDeviceToHost, ctx->copy_stream));
+        SGZ_HIP(ctx, hipMemcpyAsync(boostTo, ctx->d_boost + w0, bytes, hipMemcpyDeviceToHost, ctx->copy_stream));
     SGZ_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+    if (staged) {
+        if (sim_out) std::memcpy(sim_out, simTo, bytes);
+        if (boost_out) std::memcpy(boost_out, boostTo, bytes);
+    }
     return SGZ_OK;
 }
 

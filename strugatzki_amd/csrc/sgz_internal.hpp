@@ -215,6 +215,14 @@ struct sgz_context {
     std::vector<Run> runs;
     std::vector<hipEvent_t> event_pool;
     hipStream_t copy_stream = nullptr;       // device-to-host result copies
+    float *h_dense_pin = nullptr;            // pinned staging of dense read-backs (two halves: sims, boosts;
+    size_t dense_pin_floats = 0;             // floats per half), followed by the sequence word of a prefetch
+    // sgz_corr_prefetch_dense: a copy by kernel, in order on `stream`, that the next read of the same files takes
+    bool prefetch_valid = false;
+    int prefetch_fb = 0, prefetch_fe = 0;
+    unsigned long long prefetch_seq = 0;
+    unsigned int *d_prefetch_done = nullptr;
+    size_t prefetch_done_cap = 0;
     struct PinSlot {                         // staging of large copies from / to pageable memory (copy_large)
         void *pin = nullptr;                 // two halves: one is filled or emptied by the host while the
         hipStream_t stream = nullptr;        // other is in flight

@@ -83,6 +83,7 @@ extern "C" int sgz_corr_search(sgz_context *ctx, int target_frames, int num_matc
     if (!(margin >= 0.0f)) margin = f16 ? 1e-6f : 1e-5f;
     bool screened = screen && head < nf;
     if ((rc = sgz_corr_run(ctx, 0, head))) return rc;
+    if (head < nf && (rc = sgz_corr_prefetch_dense(ctx, 0, head))) return rc;  // on its way before the tail's run
     if (head < nf) {
         rc = !screened ? sgz_corr_run(ctx, head, nf)
                        : (f16 ? sgz_corr_run_screen_f16(ctx, head, nf) : sgz_corr_run_screen(ctx, head, nf));

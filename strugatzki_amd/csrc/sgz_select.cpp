@@ -168,18 +168,29 @@ int sgz_sel_feed_file(sgz_selector *sel, int file, int64_t n, const int32_t *off
     sel->entry.clear();
     sel->has_last = false;
     for (int64_t i = 0; i < n; i++) {
-        const float sim = sims[i];
-        if (sel->entry_has_space() || sim > sel->lowest_sim()) {
-            const int64_t off = offsets ? offsets[i] : i;
-            Entry m;
-            m.sim = sim;
-            m.file = file;
-            m.start = off * sel->step_size;
-            m.stop = (off + sel->target_frames) * sel->step_size;
-            m.boost_in = boosts[i];
-            m.boost_out = 1.0f;
-            sel->add_match(m);
+        if (!sel->entry_has_space()) {
+            // The gate (impl/FeatureCorrelationImpl.scala:234) only changes when a match is added: the windows up
+            // to the next one that beats the current bound are skipped in a loop the compiler can vectorise
+            // (a dense file is hundreds of thousands of windows, of which a handful pass).
+            const float low = sel->lowest_sim();
+            while (i + 8 <= n) {
+                int any = 0;
+                for (int k = 0; k < 8; k++) any |= sims[i + k] > low;
+                if (any) break;
+                i += 8;
+            }
+            while (i < n && !(sims[i] > low)) i++;
+            if (i >= n) break;
         }
+        const int64_t off = offsets ? offsets[i] : i;
+        Entry m;
+        m.sim = sims[i];
+        m.file = file;
+        m.start = off * sel->step_size;
+        m.stop = (off + sel->target_frames) * sel->step_size;
+        m.boost_in = boosts[i];
+        m.boost_out = 1.0f;
+        sel->add_match(m);
     }
     for (const Entry &e : sel->entry.items()) sel->all.add(e);
     sel->all.truncate((size_t)sel->num_matches);

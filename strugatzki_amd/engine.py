@@ -173,6 +173,11 @@ class Context:
         self._check(lib.sgz_corr_read_dense(self._h, file, N.ptr(sim), N.ptr(boost)))
         return sim, boost
 
+    def corr_prefetch_dense(self, file_begin: int, file_end: int) -> None:
+        """Starts the transfer of the dense results of these files to the host, in order behind the runs queued so
+        far; the next corr_read_dense_range over exactly these files picks it up (sgz_corr_prefetch_dense)."""
+        self._check(lib.sgz_corr_prefetch_dense(self._h, file_begin, file_end))
+
     def corr_read_dense_range(self, file_begin: int, file_end: int) -> list[tuple[np.ndarray, np.ndarray]]:
         """(sim, boost) of every file in [file_begin, file_end), fetched with one pair of copies."""
         counts = [max(0, self.corr_num_windows(f)) for f in range(file_begin, file_end)]

@@ -651,6 +651,36 @@ def test_smaller_database_after_a_larger_one_with_unscreenable_file(ctx):
             assert abs(g.sim - w.sim) <= TOL
 
 
+def test_prefetch_of_dense_results(ctx):
+    """sgz_corr_prefetch_dense: the read that follows returns what a plain read returns, also with more work queued
+    behind the prefetch; a read of other files in between goes its own way; a new run over the files discards it."""
+    L, ts, nf, frames = 100, 7, 6, 1500
+    db = synth_db(nf, frames, make_plants(2, L, nf, frames, ts))
+    tgt = synth_target(ts, L)
+    _load(ctx, db, norms_default())
+    ctx.corr_set_target(tgt[ts:ts + L], 0.5, 8.0)
+    ctx.corr_run(0, nf)
+    plain = ctx.corr_read_dense_range(0, nf)
+    ctx.corr_run(0, 3)
+    ctx.corr_prefetch_dense(0, 3)
+    ctx.corr_run_screen_f16(3, nf)  # queued behind the prefetch
+    other = ctx.corr_read_dense_range(1, 2)  # not the prefetched range
+    got = ctx.corr_read_dense_range(0, 3)
+    for f in range(3):
+        assert np.array_equal(got[f][0], plain[f][0]) and np.array_equal(got[f][1], plain[f][1])
+    assert np.array_equal(other[0][0], plain[1][0])
+    # a second read is a plain one again; a run over the files in between makes a pending prefetch void
+    again = ctx.corr_read_dense_range(0, 3)
+    assert np.array_equal(again[2][0], plain[2][0])
+    ctx.corr_prefetch_dense(0, 2)
+    ctx.corr_set_target(tgt[ts + 1:ts + 1 + L], 0.5, 8.0)
+    ctx.corr_run(0, 2)
+    fresh = ctx.corr_read_dense_range(0, 2)
+    ctx.corr_run(0, 2)
+    assert np.array_equal(fresh[0][0], ctx.corr_read_dense_range(0, 2)[0][0])
+    assert not np.array_equal(fresh[0][0], plain[0][0])
+
+
 def test_synthetic_generator_matches_oracle_bits(ctx):
     L, ts, frames = 50, 8, 300
     plants = make_plants(2, L, 3, frames, ts)

@@ -64,6 +64,42 @@ int main()
     }
     std::printf("fine-grained: %.2f us per search = launch of the matrix kernel %.2f + compaction, re-scoring and wait %.2f"
                 " + selection %.2f\n", usSince(t1) / steps, tRun / steps, tCompact / steps, tFeed / steps);
+    // the general path (numPerFile 2), phase by phase
+    {
+        const int head = 10;
+        std::vector<float> sim((size_t)head * (FR - L + 1)), boost(sim.size());
+        double tLaunch = 0, tRead = 0, tReplay = 0, tTail = 0;
+        const int reps = 200;
+        const auto tg = now();
+        for (int i = 0; i < reps; i++) {
+            auto a = now();
+            sgz_corr_run(ctx, 0, head);
+            sgz_corr_run_screen_f16(ctx, head, NF);
+            tLaunch += usSince(a);
+            a = now();
+            sgz_corr_read_dense_range(ctx, 0, head, sim.data(), boost.data());
+            tRead += usSince(a);
+            a = now();
+            sgz_selector *sel = sgz_sel_create(10, 2, 0, 512, L);
+            size_t pos = 0;
+            for (int f = 0; f < head; f++) {
+                const int64_t nw = sgz_corr_num_windows(ctx, f);
+                sgz_sel_feed_file(sel, f, nw, nullptr, sim.data() + pos, boost.data() + pos);
+                pos += (size_t)nw;
+            }
+            tReplay += usSince(a);
+            a = now();
+            int64_t cnt = 0;
+            sgz_corr_compact_rescored(ctx, head, NF, sgz_sel_threshold(sel) - 1e-6f, cands.data(), 1 << 16, &cnt);
+            sgz_sel_feed_candidates(sel, cands.data(), cnt);
+            n = sgz_sel_result(sel, m, 10);
+            sgz_sel_destroy(sel);
+            tTail += usSince(a);
+        }
+        std::printf("general path: %.1f us per search = launches %.1f + wait for and read the dense head %.1f + replay %.1f"
+                    " + tail compaction, re-scoring, replay %.1f\n", usSince(tg) / reps, tLaunch / reps, tRead / reps,
+                    tReplay / reps, tTail / reps);
+    }
     sgz_destroy(ctx);
     return 0;
 }
