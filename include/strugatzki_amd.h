@@ -213,6 +213,24 @@ SGZ_API int sgz_corr_run_screen(sgz_context *ctx, int file_begin, int file_end);
  * report SGZ_E_OVERFLOW. */
 SGZ_API int sgz_corr_run_screen_f16(sgz_context *ctx, int file_begin, int file_end);
 SGZ_API int sgz_corr_screen_f16_available(const sgz_context *ctx);
+/* Which kernel produces the bounds of sgz_corr_run_screen_f16 (same sums, impl/MathUtil.scala:177-196; the
+ * reference has one loop, this choice has no counterpart there):
+ *   1  the matrix-core kernel described above (direct sums, half-precision products);
+ *   2  the spectral kernel: the cross terms of N - L + 1 consecutive windows are one circular correlation of
+ *      an N-frame block with the target, evaluated from fp32 spectra of the blocks that are kept with the
+ *      database (N = 4096, 8192 or 16384; about 1.3 x the database's size in HBM).  HBM-bound instead of
+ *      compute-bound, bounds about ten times tighter; needs a target of at most 3/4 of the largest N;
+ *   0  (default) the spectral kernel for targets of 1024 frames and more, else the matrix cores.
+ * Bounds from either kernel enclose sgz_corr_run's value, and every search result is re-scored exactly, so the
+ * choice never changes a result.  Takes effect with the next run (the layout is rebuilt).  The environment
+ * variable SGZ_SCREEN_KERNEL=matrix|spectral overrides the setting.
+ * sgz_corr_screen_kernel_in_use: 1 or 2 once a run has built the layout, 0 if neither applies, -1 before. */
+SGZ_API int sgz_corr_set_screen_kernel(sgz_context *ctx, int kernel);
+SGZ_API int sgz_corr_screen_kernel_in_use(const sgz_context *ctx);
+/* The N-point complex fp32 transform of the spectral kernel (N = 4096, 8192, 16384; forward or inverse without the
+ * 1 / N factor; interleaved re, im), run thread by thread on the host with the kernels' own index arithmetic and
+ * operations: test support, no GPU needed, no counterpart in the reference. */
+SGZ_API int sgz_fft_reference_host(int n, int inverse, const float *in, float *out);
 
 /* Starts the transfer of sim / boost of all windows of files [file_begin, file_end) to the host, in order
  * behind the runs queued so far (a kernel writes them to pinned memory); the next sgz_corr_read_dense_range over

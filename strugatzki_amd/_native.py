@@ -102,6 +102,9 @@ SIGNATURES = {
     "sgz_write_norms_file": (C.c_int, [C.c_char_p, _vp, C.c_int]),
     "sgz_corr_run_screen_f16": (C.c_int, [_vp, C.c_int, C.c_int]),
     "sgz_corr_screen_f16_available": (C.c_int, [_vp]),
+    "sgz_corr_set_screen_kernel": (C.c_int, [_vp, C.c_int]),
+    "sgz_corr_screen_kernel_in_use": (C.c_int, [_vp]),
+    "sgz_fft_reference_host": (C.c_int, [C.c_int, C.c_int, _vp, _vp]),
     "sgz_corr_read_dense": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "sgz_corr_read_dense_range": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
     "sgz_corr_compact": (C.c_int, [_vp, C.c_int, C.c_int, C.c_float, _vp, C.c_int64, C.POINTER(C.c_int64)]),

@@ -66,6 +66,7 @@ void sgz_destroy(sgz_context *ctx)
                     ctx->d_prefix_h, ctx->d_tbase_h, ctx->d_wstat_h, ctx->d_prefetch_done};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
+    sgz::fft_screen_free(ctx);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     if (ctx->h_dense_pin) (void)hipHostFree(ctx->h_dense_pin);
     for (auto &slot : ctx->pin_pool) {

@@ -1434,6 +1434,7 @@ int build_layout(sgz_context *ctx)
     ctx->total_windows = wins;
 
     int rc;
+    if ((rc = fft_screen_layout(ctx))) return rc;  // (its table is uploaded on ctx->stream, synchronised below)
     if ((rc = ensure(ctx, ctx->d_files, ctx->d_files_cap, (size_t)nf))) return rc;
     if ((rc = ensure(ctx, ctx->d_tiles, ctx->d_tiles_cap, ctx->h_tiles.size()))) return rc;
     if ((rc = ensure(ctx, ctx->d_ptiles, ctx->d_ptiles_cap, ctx->h_ptiles.size()))) return rc;
@@ -1797,6 +1798,20 @@ int sgz_corr_set_target(sgz_context *ctx, const float *frames, int num_frames, f
     ctx->aMeanS = sMean;
     std::vector<float> apf(ap.size());
     for (size_t i = 0; i < ap.size(); i++) apf[i] = (float)ap[i];
+    {  // what the spectral screening needs of the fp32 values: their sums and Euclidean norms per channel group
+        double s[2] = {0.0, 0.0}, q[2] = {0.0, 0.0};
+        for (int c = 0; c < numCh; c++)
+            for (int i = 0; i < L; i++) {
+                const double v = (double)apf[(size_t)c * Lpad + i];
+                s[c > 0] += v;
+                q[c > 0] += v * v;
+            }
+        ctx->tgt_sumT = s[0];
+        ctx->tgt_sumS = s[1];
+        ctx->tgt_nrmT = std::sqrt(q[0]);
+        ctx->tgt_nrmS = std::sqrt(q[1]);
+        ctx->aspec_dirty = true;
+    }
     if ((rc = ensure(ctx, ctx->d_aprime_f, ctx->aprime_f_cap, apf.size()))) return rc;
     SGZ_HIP(ctx, hipMemcpy(ctx->d_aprime_f, apf.data(), sizeof(float) * apf.size(), hipMemcpyHostToDevice));
     ctx->have_target = true;
@@ -1869,6 +1884,7 @@ static int corr_run_impl(sgz_context *ctx, int file_begin, int file_end, int mod
 
     const int pt0 = ctx->ptile_begin[file_begin], pt1 = ctx->ptile_begin[file_end];
     const bool half = mode == kRunScreenF16;
+    const bool spectral = half && ctx->fg.N > 0;  // the bounds come from the spectral kernel instead
     const int t0 = half ? ctx->tile_h_begin[file_begin] : ctx->tile_begin[file_begin];
     const int t1 = half ? ctx->tile_h_begin[file_end] : ctx->tile_begin[file_end];
     long long wins = 0;
@@ -1937,6 +1953,9 @@ static int corr_run_impl(sgz_context *ctx, int file_begin, int file_end, int mod
         ctx->hc_begin = file_begin;
         ctx->hc_end = file_end;
     }
+    if (spectral && !(ctx->fc_begin <= file_begin && file_end <= ctx->fc_end) &&
+        (rc = fft_screen_prepare(ctx, file_begin, file_end, stream)))
+        return rc;
     const size_t corrLds = exact ? corr_lds_bytes<double>() : corr_lds_bytes<float>();
     // windows whose prefix-sum statistics cannot be trusted (constant stretches): see SuspectList
     SuspectList suspects{nullptr, nullptr, 0, INFINITY};
@@ -1951,7 +1970,11 @@ static int corr_run_impl(sgz_context *ctx, int file_begin, int file_end, int mod
     // kernel time for sgz_corr_last_kernel_ms: the matrix-core kernel carries the two events in its own
     // dispatch (no separate marker packets, which would each cost a few idle microseconds on the stream)
     if (!half && timed) SGZ_HIP(ctx, hipEventRecord(ctx->ev0, stream));
-    if (half) {
+    if (spectral) {
+        if ((rc = fft_screen_launch(ctx, file_begin, file_end, stream, timed ? ctx->ev0 : nullptr,
+                                    timed ? ctx->ev1 : nullptr)))
+            return rc;
+    } else if (half) {
         if ((rc = half_screen_launch(ctx, t0, t1, stream, timed ? ctx->ev0 : nullptr, timed ? ctx->ev1 : nullptr)))
             return rc;
     } else if (exact)

@@ -197,8 +197,15 @@ __device__ __forceinline__ WindowStatic window_static(int L, int numCh, const Ha
 // relErrT / relErrS: relative error of the cross terms of the two channel groups.  Half-precision values below
 // 2^-14 round with an absolute error of up to 2^-25 instead of a relative one: over a whole window that moves a
 // normalised cross term by at most 2^-25 (1 / sd_b + sqrt(1 + (dm / sd_b)^2) / sd_a), which is added.
+//
+// kSpectral: cross terms from the fp32 transforms of the spectral screening instead.  Their error is bounded against
+// the norm of the whole transformed block, not of the window: absT / absS = eta |a'| |x_block| / (aStd n) of the
+// channel group, which times 1 / sd_b bounds the normalised cross term; relErr then only covers the fp32
+// rounding of the target values.
+template <bool kSpectral = false>
 __device__ __forceinline__ WindowCoeffs window_coeffs(const CorrParams &cp, const WindowStatic &ws, float relErrT,
-                                                      float relErrS, float &boostOut)
+                                                      float relErrS, float &boostOut, float absT = 0.0f,
+                                                      float absS = 0.0f)
 {
     constexpr float kSubAbs = 2.9802322e-8f;  // 2^-25
     const float nT = (float)cp.L, nS = (float)cp.L * (float)(cp.numCh - 1);
@@ -214,7 +221,7 @@ __device__ __forceinline__ WindowCoeffs window_coeffs(const CorrParams &cp, cons
             wc.a = (cp.w / ((float)cp.aStdT * nT)) * rsd;
             wc.c = wc.a * dm * (float)cp.sumAT;
             const float q = __builtin_amdgcn_sqrtf(1.0f + r * r);
-            const float eh = relErrT * q + kSubAbs * (rsd + q / (float)cp.aStdT);
+            const float eh = kSpectral ? relErrT * q + absT * rsd : relErrT * q + kSubAbs * (rsd + q / (float)cp.aStdT);
             errT = eh + (1.0f + eh) * ws.gT + fabsf((float)cp.sumAT) / ((float)cp.aStdT * nT) * half_from_bits(ws.hTS);
         }
         if (cp.w < 1.0f) {
@@ -223,7 +230,7 @@ __device__ __forceinline__ WindowCoeffs window_coeffs(const CorrParams &cp, cons
             wc.b = ((1.0f - cp.w) / ((float)cp.aStdS * nS)) * rsd;
             wc.c += wc.b * dm * (float)cp.sumAS;
             const float q = __builtin_amdgcn_sqrtf(1.0f + r * r);
-            const float eh = relErrS * q + kSubAbs * (rsd + q / (float)cp.aStdS);
+            const float eh = kSpectral ? relErrS * q + absS * rsd : relErrS * q + kSubAbs * (rsd + q / (float)cp.aStdS);
             errS = eh + (1.0f + eh) * ws.gS + fabsf((float)cp.sumAS) / ((float)cp.aStdS * nS) * half_from_bits(ws.hTS >> 16);
         }
         wc.e = errT * cp.w + errS * (1.0f - cp.w) + 1e-5f;

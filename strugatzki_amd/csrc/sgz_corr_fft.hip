@@ -1,0 +1,579 @@
+// Spectral screening of the sliding cross term
+// (impl/FeatureCorrelationImpl.scala:193-232 evaluates, per window o and channel c,
+//  sum_i a'[c][i] * b[c][o + i] through MathUtil.correlate, impl/MathUtil.scala:177-196).
+//
+// For a block of N frames of a file starting at frame s, the sums of the windows o = s + k, 0 <= k <= N - L, are
+// the first N - L + 1 values of the circular correlation of the block with the zero-padded target,
+//
+//     y[k] = IFFT( conj(FFT(a')) * FFT(x[s .. s + N)) )[k],
+//
+// about 95 times fewer operations than the direct sum at L = 2584 and no longer bound by arithmetic at all: the
+// kernel streams the block's spectra (kept in HBM per database / norms / target length, like the half-precision
+// image of the matrix-core path), multiplies them with the target's spectra, adds the channels of a group in
+// the frequency domain, and inverts ONE complex transform per block whose real part is the loudness cross term
+// and whose imaginary part the cross term of the other channels.  It is HBM-bound: per block 8 N numCh / 2
+// bytes of spectra, per window 32 bytes of cached statistics in and 12 bytes of bounds out.
+//
+// Everything is fp32.  The result is a screening value with a certified error like the matrix-core kernel's:
+// every output of an FFT-based correlation differs from the exact sum by at most eta * |a'| * |x_block|
+// (Euclidean norms over the channel group; each output is an inner product of the spectra evaluated through a
+// butterfly tree, every path of which carries (1 + delta)^depth - 1, and sum |A_j X_j| / N <= |a'| |x| by
+// Cauchy-Schwarz and Parseval; the forward transforms add the same again through their norm-wise bounds).
+// eta (fft_eta): three transforms of `passes` passes at 40 roundings each (table-derived twiddle <= 10 ulp, its
+// product, four butterfly levels with their inner factors), the channel sums, the rounding of the operands.
+// At N = 16384, L = 2584 that is 5e-5 of the similarity where half-precision products give 1e-3.
+#include <hip/hip_ext.h>
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "sgz_corr_dev.hpp"
+#include "sgz_fft_dev.hpp"
+#include "sgz_internal.hpp"
+
+using namespace sgz;
+
+namespace {
+
+// Deterministic sum of one float per thread over the workgroup (fixed order); result valid in thread 0.
+template <int T>
+__device__ __forceinline__ float block_sum(float v, float *scratch /* T / 64 floats */)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float s = 0.0f;
+    if (threadIdx.x == 0)
+        for (int k = 0; k < T / 64; k++) s += scratch[k];
+    __syncthreads();
+    return s;
+}
+
+// Two real sequences transformed as one complex one: spectra of the real and of the imaginary part at bin j
+// from Z[j] and Z[N - j].
+__device__ __forceinline__ void untangle(float2 zj, float2 zm, float2 &xa, float2 &xb)
+{
+    xa = make_float2(0.5f * (zj.x + zm.x), 0.5f * (zj.y - zm.y));
+    xb = make_float2(0.5f * (zj.y + zm.y), 0.5f * (zm.x - zj.x));
+}
+
+// fft_spectra_kernel: workgroup = (block, channel pair).  The block's frames of two channels, normalised and
+// centred exactly as the half-precision preparation does it (the window statistics of the bounds are sums of
+// these very values), one forward transform, the two spectra to HBM; per channel the sum of squares.
+template <int N>
+__global__ __launch_bounds__(N / 16) void fft_spectra_kernel(const FileDesc *__restrict__ files,
+                                                             const FftBlock *__restrict__ blocks, int numPairs,
+                                                             NormParams nrm, int numCh,
+                                                             const float2 *__restrict__ tab, float2 *__restrict__ spec,
+                                                             float *__restrict__ blksq)
+{
+    constexpr int T = N / 16, NH = N / 2;
+    extern __shared__ __attribute__((aligned(16))) float2 buf[];
+    __shared__ float red[16];
+    const int tid = threadIdx.x;
+    const int blk = blockIdx.x / numPairs, p = blockIdx.x - blk * numPairs;
+    const FftBlock bd = blocks[blk];
+    const FileDesc fd = files[bd.file];
+    const int c0 = 2 * p, c1 = 2 * p + 1;
+    const bool two = c1 < numCh;
+    const float mn0 = nrm.enabled ? nrm.mn[c0] : 0.0f, mn1 = nrm.enabled && two ? nrm.mn[c1] : 0.0f;
+    const float rc0 = nrm.enabled ? __builtin_amdgcn_rcpf(nrm.d[c0]) : 1.0f;
+    const float rc1 = nrm.enabled && two ? __builtin_amdgcn_rcpf(nrm.d[c1]) : 1.0f;
+    const float k0 = c0 == 0 ? fd.cT : fd.cS, k1 = fd.cS;
+    float sq0 = 0.0f, sq1 = 0.0f;
+#pragma unroll 4
+    for (int m = 0; m < 16; m++) {
+        const int n = tid + m * T;
+        const long long fr = (long long)bd.o0 + n;
+        float a = 0.0f, b = 0.0f;
+        if (fr < fd.frames) {
+            const float *src = fd.raw + fr * numCh;
+            a = (src[c0] - mn0) * rc0 - k0;
+            if (two) b = (src[c1] - mn1) * rc1 - k1;
+        }
+        buf[fft_phys(n)] = make_float2(a, b);
+        sq0 = fmaf(a, a, sq0);
+        sq1 = fmaf(b, b, sq1);
+    }
+    const float t0 = block_sum<T>(sq0, red);
+    const float t1 = block_sum<T>(sq1, red);
+    if (tid == 0) {
+        blksq[(size_t)blk * numCh + c0] = t0;
+        if (two) blksq[(size_t)blk * numCh + c1] = t1;
+    }
+    __syncthreads();
+    fft_lds<N, -1>(buf, tab, tid);
+    float2 *out0 = spec + bd.spec + (long long)c0 * NH;
+    float2 *out1 = spec + bd.spec + (long long)c1 * NH;
+#pragma unroll 4
+    for (int m = 0; m < 8; m++) {
+        const int j = tid + m * T;
+        const float2 zj = buf[fft_phys(j)], zm = buf[fft_phys((N - j) & (N - 1))];
+        float2 xa, xb;
+        untangle(zj, zm, xa, xb);
+        if (j == 0) {  // both real: the Nyquist bin rides in the imaginary part
+            const float2 zn = buf[fft_phys(NH)];
+            xa = make_float2(zj.x, zn.x);
+            xb = make_float2(zj.y, zn.y);
+        }
+        out0[j] = xa;
+        if (two) out1[j] = xb;
+    }
+}
+
+// fft_target_kernel: workgroup = channel pair of the target; the conjugated spectra divided by N (the inverse
+// transform's factor), packed like the database spectra.
+template <int N>
+__global__ __launch_bounds__(N / 16) void fft_target_kernel(const float *__restrict__ aprime, int Lpad, int L, int numCh,
+                                                            const float2 *__restrict__ tab, float2 *__restrict__ aspec)
+{
+    constexpr int T = N / 16, NH = N / 2;
+    extern __shared__ __attribute__((aligned(16))) float2 buf[];
+    const int tid = threadIdx.x;
+    const int c0 = 2 * blockIdx.x, c1 = c0 + 1;
+    const bool two = c1 < numCh;
+#pragma unroll 4
+    for (int m = 0; m < 16; m++) {
+        const int n = tid + m * T;
+        float a = 0.0f, b = 0.0f;
+        if (n < L) {
+            a = aprime[(size_t)c0 * Lpad + n];
+            if (two) b = aprime[(size_t)c1 * Lpad + n];
+        }
+        buf[fft_phys(n)] = make_float2(a, b);
+    }
+    __syncthreads();
+    fft_lds<N, -1>(buf, tab, tid);
+    constexpr float rN = 1.0f / (float)N;
+#pragma unroll 4
+    for (int m = 0; m < 8; m++) {
+        const int j = tid + m * T;
+        const float2 zj = buf[fft_phys(j)], zm = buf[fft_phys((N - j) & (N - 1))];
+        float2 xa, xb;
+        untangle(zj, zm, xa, xb);
+        xa = make_float2(xa.x * rN, -xa.y * rN);
+        xb = make_float2(xb.x * rN, -xb.y * rN);
+        if (j == 0) {
+            const float2 zn = buf[fft_phys(NH)];
+            xa = make_float2(zj.x * rN, zn.x * rN);
+            xb = make_float2(zj.y * rN, zn.y * rN);
+        }
+        aspec[(size_t)c0 * NH + j] = xa;
+        if (two) aspec[(size_t)c1 * NH + j] = xb;
+    }
+}
+
+// Euclidean norms of a block's loudness channel and of its other channels, rounded up.
+__global__ void fft_blknorm_kernel(const float *__restrict__ blksq, int numCh, int nblocks, float2 *__restrict__ blknorm)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblocks) return;
+    const float *sq = blksq + (size_t)b * numCh;
+    float s = 0.0f;
+    for (int c = 1; c < numCh; c++) s += sq[c];
+    blknorm[b] = make_float2(sqrtf(sq[0]) * 1.0001f, sqrtf(s) * 1.0001f);
+}
+
+// corr_fft_kernel: workgroup = one block of N frames, N / 16 threads.
+//   1. per bin j < N / 2: Zt = A_0 X_0, Zs = sum_{c >= 1} A_c X_c (A: conjugated target spectra / N), and the two
+//      Hermitian spectra combined into one, W[j] = Zt + i Zs, W[N - j] = conj(Zt) + i conj(Zs), written to LDS;
+//   2. inverse transform in LDS: w[k] = crossT[k] + i crossS[k];
+//   3. per window the bounds from its cached statics, as in the matrix-core kernel's epilogue.
+template <int N, int NCH>
+__global__ __launch_bounds__(N / 16) void corr_fft_kernel(const FftBlock *__restrict__ blocks,
+                                                          const float2 *__restrict__ spec,
+                                                          const float2 *__restrict__ aspec,
+                                                          const float2 *__restrict__ tab,
+                                                          const float2 *__restrict__ blknorm,
+                                                          const float4 *__restrict__ wstat, CorrParams cp, FftGeom fg,
+                                                          float *__restrict__ simOut, float *__restrict__ boostOut,
+                                                          float *__restrict__ loOut, int *__restrict__ lokey,
+                                                          int *__restrict__ lokeyNext, int *__restrict__ hflags)
+{
+    constexpr int T = N / 16, NH = N / 2;
+    extern __shared__ __attribute__((aligned(16))) float2 buf[];
+    __shared__ float wbest[16];
+    __shared__ int wbad[16];
+    const int tid = threadIdx.x;
+    const FftBlock bd = blocks[blockIdx.x];
+    const int numCh = NCH ? NCH : cp.numCh;
+    const float2 *xs = spec + bd.spec;
+
+#pragma unroll 2
+    for (int m = 0; m < 8; m++) {
+        const int j = tid + m * T;
+        float2 zt = c_mul(aspec[j], xs[j]);
+        float2 zs = make_float2(0.0f, 0.0f);
+#pragma unroll
+        for (int c = 1; c < numCh; c++) {
+            const float2 a = aspec[(size_t)c * NH + j], x = xs[(size_t)c * NH + j];
+            zs.x = fmaf(a.x, x.x, zs.x);
+            zs.x = fmaf(-a.y, x.y, zs.x);
+            zs.y = fmaf(a.x, x.y, zs.y);
+            zs.y = fmaf(a.y, x.x, zs.y);
+        }
+        buf[fft_phys((N - j) & (N - 1))] = make_float2(zt.x + zs.y, zs.x - zt.y);
+        buf[fft_phys(j)] = make_float2(zt.x - zs.y, zt.y + zs.x);
+    }
+    if (tid == 0) {  // bin 0 holds two real bins, DC and Nyquist: component-wise products
+        float2 zt = make_float2(aspec[0].x * xs[0].x, aspec[0].y * xs[0].y);
+        float2 zs = make_float2(0.0f, 0.0f);
+        for (int c = 1; c < numCh; c++) {
+            const float2 a = aspec[(size_t)c * NH], x = xs[(size_t)c * NH];
+            zs.x = fmaf(a.x, x.x, zs.x);
+            zs.y = fmaf(a.y, x.y, zs.y);
+        }
+        buf[fft_phys(0)] = make_float2(zt.x, zs.x);
+        buf[fft_phys(NH)] = make_float2(zt.y, zs.y);
+    }
+    __syncthreads();
+    fft_lds<N, 1>(buf, tab, tid);
+
+    const float2 bn = blknorm[blockIdx.x];
+    const float absT = fg.etaT * bn.x, absS = fg.etaS * bn.y;
+    CorrParams cpf = cp;  // the statistics of the fp32 target values
+    cpf.sumAT = fg.sumAT;
+    cpf.sumAS = fg.sumAS;
+    float best = -INFINITY;
+    int bad = 0;
+    for (int m0 = 0; m0 < 16 && m0 * T < bd.valid; m0 += 4) {
+        float4 ws0[4], ws1[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int k = tid + (m0 + u) * T;
+            const long long w = bd.win + (k < bd.valid ? k : 0);
+            ws0[u] = wstat[2 * w];
+            ws1[u] = wstat[2 * w + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int k = tid + (m0 + u) * T;
+            if (k < bd.valid) {
+                const float2 y = buf[fft_phys(k)];
+                float sim, lo, boost;
+                WindowStatic ws;
+                ws.rsdT = ws0[u].x, ws.dmT = ws0[u].y, ws.gT = ws0[u].z, ws.lnAvg = ws0[u].w;
+                ws.rsdS = ws1[u].x, ws.dmS = ws1[u].y, ws.gS = ws1[u].z, ws.hTS = __float_as_uint(ws1[u].w);
+                const WindowCoeffs wc = window_coeffs<true>(cpf, ws, fg.relErr, fg.relErr, boost, absT, absS);
+                window_bounds(wc, y.x, y.y, sim, lo);
+                boostOut[bd.win + k] = boost;
+                simOut[bd.win + k] = sim;
+                loOut[bd.win + k] = lo;
+                best = fmaxf(best, lo);
+                bad |= (lo != lo) || (sim != sim);
+            }
+        }
+    }
+    // the file's largest lower bound (one atomic per workgroup); NaN similarities mark the file for the exact path
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        best = fmaxf(best, __shfl_xor(best, off, 64));
+        bad |= __shfl_xor(bad, off, 64);
+    }
+    if ((tid & 63) == 0) {
+        wbest[tid >> 6] = best;
+        wbad[tid >> 6] = bad;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int k = 1; k < T / 64; k++) {
+            best = fmaxf(best, wbest[k]);
+            bad |= wbad[k];
+        }
+        atomicMax(&lokey[bd.file], bound_key(best));
+        if (bad) atomicOr(&hflags[bd.file], 2);
+        // the run after this one folds its bounds into the other array: the file's first block resets its entry
+        if (bd.o0 == 0) lokeyNext[bd.file] = bound_key(-INFINITY);
+    }
+}
+
+// eta of the header comment for a transform of N points and a group of `channels` channels.
+double fft_eta(int N, int channels)
+{
+    const double u = std::ldexp(1.0, -24);
+    const int passes = N > 4096 ? 4 : 3;
+    const double epsFft = std::expm1(passes * std::log1p(40.0 * u));
+    return (3.0 * epsFft + (channels + 8.0) * 3.0 * u) * 1.01;
+}
+
+template <typename K>
+int set_lds(const sgz_context *ctx, K kern, size_t bytes)
+{
+    if (bytes > 64 * 1024)
+        SGZ_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)bytes));
+    return SGZ_OK;
+}
+
+int ensure_tab(sgz_context *ctx)
+{
+    if (ctx->d_fft_tab) return SGZ_OK;
+    std::vector<float2> tab(kFftTab);
+    const double step = 2.0 * 3.14159265358979323846 / kFftTab;
+    for (int j = 0; j < kFftTab; j++) tab[(size_t)j] = make_float2((float)std::cos(step * j), (float)std::sin(step * j));
+    SGZ_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_fft_tab), sizeof(float2) * kFftTab));
+    SGZ_HIP(ctx, hipMemcpy(ctx->d_fft_tab, tab.data(), sizeof(float2) * kFftTab, hipMemcpyHostToDevice));
+    return SGZ_OK;
+}
+
+// Target spectra and the target-dependent factors of the error bound (per target; N from the layout).
+int fft_target(sgz_context *ctx, hipStream_t stream)
+{
+    FftGeom &fg = ctx->fg;
+    const int N = fg.N, numCh = ctx->cp.numCh, L = ctx->cp.L;
+    const int numPairs = (numCh + 1) / 2;
+    int rc;
+    if ((rc = ensure(ctx, ctx->d_aspec, ctx->aspec_cap, (size_t)numCh * (N / 2)))) return rc;
+    const size_t lds = sizeof(float2) * fft_lds_elems(N);
+    const int Lpad = ctx->cp.S * kR;
+    auto launch = [&](auto kern) -> int {
+        if ((rc = set_lds(ctx, kern, lds))) return rc;
+        hipLaunchKernelGGL(kern, dim3(numPairs), dim3(N / 16), lds, stream, ctx->d_aprime_f, Lpad, L, numCh, ctx->d_fft_tab,
+                           ctx->d_aspec);
+        SGZ_HIP(ctx, hipGetLastError());
+        return SGZ_OK;
+    };
+    if (N == 4096) rc = launch(fft_target_kernel<4096>);
+    else if (N == 8192) rc = launch(fft_target_kernel<8192>);
+    else rc = launch(fft_target_kernel<16384>);
+    if (rc) return rc;
+    const double nT = (double)L, nS = (double)L * (numCh - 1);
+    fg.sumAT = ctx->tgt_sumT;
+    fg.sumAS = ctx->tgt_sumS;
+    // |a'| / (aStd n): about 1 / sqrt(n); a target without spread gives inf / NaN, like its similarities
+    fg.etaT = (float)(fft_eta(N, 1) * ctx->tgt_nrmT / (ctx->cp.aStdT * nT) * 1.0001);
+    fg.etaS = numCh > 1 ? (float)(fft_eta(N, numCh - 1) * ctx->tgt_nrmS / (ctx->cp.aStdS * nS) * 1.0001) : 0.0f;
+    fg.relErr = (float)std::ldexp(1.0, -22);
+    ctx->aspec_dirty = false;
+    return SGZ_OK;
+}
+
+}  // namespace
+
+namespace sgz {
+
+void fft_screen_free(sgz_context *ctx)
+{
+    void *bufs[] = {ctx->d_fblocks, ctx->d_spec, ctx->d_aspec, ctx->d_fft_tab, ctx->d_blksq, ctx->d_blknorm};
+    for (void *b : bufs)
+        if (b) (void)hipFree(b);
+}
+
+// Transform length for the files and the target of the layout: the one that moves the fewest bytes,
+// sum over files of blocks * N, among the lengths whose blocks hold at least N / 4 windows; 0 (not in use) when
+// the caller asked for the matrix-core kernel, when no length fits the target, or -- left to itself -- when the
+// target is short enough for the matrix cores to be faster.  Then the block table.
+int fft_screen_layout(sgz_context *ctx)
+{
+    ctx->fg = FftGeom{};
+    ctx->h_fblocks.clear();
+    const int nf = (int)ctx->files.size();
+    ctx->fblock_begin.assign((size_t)nf + 1, 0);
+    ctx->fc_begin = ctx->fc_end = 0;
+    ctx->aspec_dirty = true;
+    const int L = ctx->cp.L, numCh = ctx->cp.numCh;
+    int mode = ctx->screen_kernel;
+    if (const char *e = std::getenv("SGZ_SCREEN_KERNEL")) {
+        if (!std::strcmp(e, "matrix")) mode = 1;
+        if (!std::strcmp(e, "spectral")) mode = 2;
+    }
+    if (mode == 1 || ctx->hg.S2 <= 0 || nf == 0) return SGZ_OK;
+    if (mode == 0 && L < 1024) return SGZ_OK;
+    int bestN = 0;
+    double bestCost = 0.0;
+    for (int N : {4096, 8192, 16384}) {
+        const int hop = N - L + 1;
+        if (hop < N / 4) continue;
+        double cost = 0.0;
+        for (int f = 0; f < nf; f++) {
+            const long long w = ctx->h_files[(size_t)f].num_windows;
+            cost += (double)((w + hop - 1) / hop) * N;
+        }
+        if (!bestN || cost < bestCost) {
+            bestN = N;
+            bestCost = cost;
+        }
+    }
+    if (const char *e = std::getenv("SGZ_FFT_N")) {
+        const int N = std::atoi(e);
+        if ((N == 4096 || N == 8192 || N == 16384) && N - L + 1 >= 1) bestN = N;
+    }
+    if (!bestN) return SGZ_OK;
+    FftGeom fg{};
+    fg.N = bestN;
+    fg.hop = bestN - L + 1;
+    long long specOff = 0;
+    for (int f = 0; f < nf; f++) {
+        const FileDesc &fd = ctx->h_files[(size_t)f];
+        ctx->fblock_begin[(size_t)f] = (int)ctx->h_fblocks.size();
+        for (long long o0 = 0; o0 < fd.num_windows; o0 += fg.hop) {
+            FftBlock b;
+            b.file = f;
+            b.o0 = (int)o0;
+            b.valid = (int)std::min<long long>(fg.hop, fd.num_windows - o0);
+            b.pad = 0;
+            b.spec = specOff;
+            b.win = fd.win_off + o0;
+            specOff += (long long)numCh * (bestN / 2);
+            ctx->h_fblocks.push_back(b);
+        }
+    }
+    ctx->fblock_begin[(size_t)nf] = (int)ctx->h_fblocks.size();
+    const size_t nb = ctx->h_fblocks.size();
+    if (nb == 0) return SGZ_OK;
+    int rc;
+    if ((rc = ensure_tab(ctx))) return rc;
+    if ((rc = ensure(ctx, ctx->d_fblocks, ctx->d_fblocks_cap, nb))) return rc;
+    if ((rc = ensure(ctx, ctx->d_spec, ctx->spec_cap, (size_t)specOff))) return rc;
+    if ((rc = ensure(ctx, ctx->d_blksq, ctx->blksq_cap, nb * (size_t)numCh))) return rc;
+    if ((rc = ensure(ctx, ctx->d_blknorm, ctx->blknorm_cap, nb))) return rc;
+    SGZ_HIP(ctx, hipMemcpyAsync(ctx->d_fblocks, ctx->h_fblocks.data(), sizeof(FftBlock) * nb, hipMemcpyHostToDevice,
+                                ctx->stream));
+    ctx->fg = fg;
+    return SGZ_OK;
+}
+
+// Spectra and block norms of files [file_begin, file_end): after the half-precision preparation of the same
+// files (it writes the centring constants this reads from the file table).
+int fft_screen_prepare(sgz_context *ctx, int file_begin, int file_end, hipStream_t stream)
+{
+    const int N = ctx->fg.N, numCh = ctx->cp.numCh;
+    const int b0 = ctx->fblock_begin[(size_t)file_begin], b1 = ctx->fblock_begin[(size_t)file_end];
+    if (b1 == b0) return SGZ_OK;
+    const int numPairs = (numCh + 1) / 2;
+    const size_t lds = sizeof(float2) * fft_lds_elems(N);
+    int rc = SGZ_OK;
+    auto launch = [&](auto kern) -> int {
+        if ((rc = set_lds(ctx, kern, lds))) return rc;
+        hipLaunchKernelGGL(kern, dim3((unsigned)(b1 - b0) * numPairs), dim3(N / 16), lds, stream, ctx->d_files,
+                           ctx->d_fblocks + b0, numPairs, ctx->norm, numCh, ctx->d_fft_tab, ctx->d_spec,
+                           ctx->d_blksq + (size_t)b0 * numCh);
+        SGZ_HIP(ctx, hipGetLastError());
+        return SGZ_OK;
+    };
+    if (N == 4096) rc = launch(fft_spectra_kernel<4096>);
+    else if (N == 8192) rc = launch(fft_spectra_kernel<8192>);
+    else rc = launch(fft_spectra_kernel<16384>);
+    if (rc) return rc;
+    hipLaunchKernelGGL(fft_blknorm_kernel, dim3((b1 - b0 + 255) / 256), dim3(256), 0, stream,
+                       ctx->d_blksq + (size_t)b0 * numCh, numCh, b1 - b0, ctx->d_blknorm + b0);
+    SGZ_HIP(ctx, hipGetLastError());
+    ctx->fc_begin = file_begin;
+    ctx->fc_end = file_end;
+    return SGZ_OK;
+}
+
+int fft_screen_launch(sgz_context *ctx, int file_begin, int file_end, hipStream_t stream, hipEvent_t start,
+                      hipEvent_t stop)
+{
+    const int N = ctx->fg.N;
+    if (N <= 0) return ctx->fail(SGZ_E_STATE, "spectral screening is not set up for this layout");
+    int rc;
+    if (ctx->aspec_dirty && (rc = fft_target(ctx, stream))) return rc;
+    const FftGeom &fg = ctx->fg;
+    const int b0 = ctx->fblock_begin[(size_t)file_begin], b1 = ctx->fblock_begin[(size_t)file_end];
+    // per-file bounds: two alternating arrays, as in the matrix-core launch (half_screen_launch)
+    const int nf = (int)ctx->files.size();
+    const int par = ctx->lokey_parity;
+    int *lokey = ctx->d_lokey + (size_t)par * nf, *lokeyNext = ctx->d_lokey + (size_t)(1 - par) * nf;
+    if (!ctx->lokey_clean[par])
+        SGZ_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(lokey), (int)0x807fffff, (size_t)nf, stream));
+    const bool whole = b0 == 0 && b1 == (int)ctx->h_fblocks.size();
+    ctx->lokey_clean[par] = false;
+    ctx->lokey_clean[1 - par] = whole || ctx->lokey_clean[1 - par];
+    ctx->lokey_cur = lokey;
+    ctx->lokey_parity = 1 - par;
+    if (b1 == b0) return SGZ_OK;
+    const size_t lds = sizeof(float2) * fft_lds_elems(N);
+    auto launch = [&](auto kern) -> int {
+        if ((rc = set_lds(ctx, kern, lds))) return rc;
+        if (start || stop)
+            hipExtLaunchKernelGGL(kern, dim3(b1 - b0), dim3(N / 16), lds, stream, start, stop, 0, ctx->d_fblocks + b0,
+                                  ctx->d_spec, ctx->d_aspec, ctx->d_fft_tab, ctx->d_blknorm + b0,
+                                  reinterpret_cast<const float4 *>(ctx->d_wstat_h), ctx->cp, fg, ctx->d_sim, ctx->d_boost,
+                                  ctx->d_lo, lokey, lokeyNext, ctx->d_hflags);
+        else
+            hipLaunchKernelGGL(kern, dim3(b1 - b0), dim3(N / 16), lds, stream, ctx->d_fblocks + b0, ctx->d_spec,
+                               ctx->d_aspec, ctx->d_fft_tab, ctx->d_blknorm + b0,
+                               reinterpret_cast<const float4 *>(ctx->d_wstat_h), ctx->cp, fg, ctx->d_sim, ctx->d_boost,
+                               ctx->d_lo, lokey, lokeyNext, ctx->d_hflags);
+        SGZ_HIP(ctx, hipGetLastError());
+        return SGZ_OK;
+    };
+    const bool std14 = ctx->cp.numCh == 14;
+    if (N == 4096) return std14 ? launch(corr_fft_kernel<4096, 14>) : launch(corr_fft_kernel<4096, 0>);
+    if (N == 8192) return std14 ? launch(corr_fft_kernel<8192, 14>) : launch(corr_fft_kernel<8192, 0>);
+    return std14 ? launch(corr_fft_kernel<16384, 14>) : launch(corr_fft_kernel<16384, 0>);
+}
+
+}  // namespace sgz
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+extern "C" {
+
+int sgz_corr_set_screen_kernel(sgz_context *ctx, int kernel)
+{
+    if (!ctx) return SGZ_E_ARG;
+    if (kernel < 0 || kernel > 2) return ctx->fail(SGZ_E_ARG, "screen kernel: 0 (auto), 1 (matrix cores) or 2 (spectral)");
+    if (kernel != ctx->screen_kernel) ctx->layout_dirty = true;
+    ctx->screen_kernel = kernel;
+    return SGZ_OK;
+}
+
+int sgz_corr_screen_kernel_in_use(const sgz_context *ctx)
+{
+    if (!ctx || !ctx->have_target || ctx->layout_dirty) return -1;
+    if (ctx->fg.N > 0) return 2;
+    return ctx->hg.S2 > 0 ? 1 : 0;
+}
+
+// The transform the kernels run, thread by thread on the host (same index arithmetic, same fp32 operations).
+int sgz_fft_reference_host(int n, int inverse, const float *in, float *out)
+{
+    if (!in || !out || (n != 4096 && n != 8192 && n != 16384)) return SGZ_E_ARG;
+    std::vector<float2> tab(kFftTab);
+    const double step = 2.0 * 3.14159265358979323846 / kFftTab;
+    for (int j = 0; j < kFftTab; j++) tab[(size_t)j] = make_float2((float)std::cos(step * j), (float)std::sin(step * j));
+    std::vector<float2> buf((size_t)fft_lds_elems(n));
+    for (int i = 0; i < n; i++) buf[(size_t)fft_phys(i)] = make_float2(in[2 * i], in[2 * i + 1]);
+    auto run = [&](auto N_, auto DIR_) {
+        constexpr int N = decltype(N_)::value, DIR = decltype(DIR_)::value, T = N / 16;
+        std::vector<float2> regs((size_t)T * 16);
+        auto pass = [&](auto Ns_) {
+            constexpr int Ns = decltype(Ns_)::value;
+            for (int t = 0; t < T; t++) {
+                float2(&v)[16] = *reinterpret_cast<float2(*)[16]>(&regs[(size_t)t * 16]);
+                fft16_load<N>(buf.data(), t, v);
+                fft16_math<DIR, Ns>(v, t, tab.data());
+            }
+            for (int t = 0; t < T; t++) {
+                float2(&v)[16] = *reinterpret_cast<float2(*)[16]>(&regs[(size_t)t * 16]);
+                fft16_store<Ns>(buf.data(), t, v);
+            }
+        };
+        pass(std::integral_constant<int, 1>{});
+        pass(std::integral_constant<int, 16>{});
+        pass(std::integral_constant<int, 256>{});
+        if constexpr (N > 4096)
+            for (int j = 0; j < 4096; j++) fft_last<N, DIR>(buf.data(), j, tab.data());
+    };
+    using I = std::integral_constant<int, 1>;
+    using F = std::integral_constant<int, -1>;
+    if (n == 4096) inverse ? run(std::integral_constant<int, 4096>{}, I{}) : run(std::integral_constant<int, 4096>{}, F{});
+    else if (n == 8192) inverse ? run(std::integral_constant<int, 8192>{}, I{}) : run(std::integral_constant<int, 8192>{}, F{});
+    else inverse ? run(std::integral_constant<int, 16384>{}, I{}) : run(std::integral_constant<int, 16384>{}, F{});
+    for (int i = 0; i < n; i++) {
+        out[2 * i] = buf[(size_t)fft_phys(i)].x;
+        out[2 * i + 1] = buf[(size_t)fft_phys(i)].y;
+    }
+    return SGZ_OK;
+}
+
+}  // extern "C"

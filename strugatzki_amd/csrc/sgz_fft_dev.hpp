@@ -1,0 +1,186 @@
+// Complex fp32 FFT of N = 4096, 8192 or 16384 points held in LDS, for the spectral screening of the sliding
+// cross term (the sum over lags of impl/MathUtil.scala:177-196, as a circular correlation).
+//
+// Stockham auto-sort passes: three of radix 16 (strides 1, 16, 256), then one of radix N / 4096 (2 or 4) where
+// N > 4096.  A pass works on N / radix butterflies; butterfly j of a pass with stride Ns reads the elements
+// j + r * N / radix, multiplies element r by exp(DIR 2 pi i r k / (Ns radix)), k = j mod Ns, transforms, and
+// writes element r of the result to (j - k) * radix + k + r * Ns: input and output are both in natural order.
+// A workgroup of N / 16 threads owns one radix-16 butterfly per thread and pass; all threads read, meet at a
+// barrier, write to the same buffer, meet again.
+//
+// Element i lives at fft_phys(i) = i + (i >> 4) (one 8-byte pad per 16 elements): the strided writes of the
+// first two passes (16 j + r, resp. 256 a + k + 16 r) then fall on distinct LDS banks.
+//
+// The pieces are __host__ __device__ so that a host loop over "threads" runs the same index arithmetic and the
+// same fp32 operations (explicit fma, no contraction) as the kernels: sgz_fft_reference_host.
+//
+// Twiddle factors come from a table tab[j] = (cos, sin)(2 pi j / kFftTab) rounded from fp64; per butterfly the
+// powers 1, 2, 4, 8 are read and the other eleven formed by at most three multiplications (error <= 10 ulp).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace sgz {
+
+constexpr int kFftTab = 16384;  // entries of the twiddle table == the largest transform
+
+__host__ __device__ constexpr int fft_phys(int i) { return i + (i >> 4); }
+__host__ __device__ constexpr int fft_lds_elems(int N) { return N + (N >> 4); }
+
+__host__ __device__ inline float2 c_mul(float2 a, float2 b)
+{
+    return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
+}
+__host__ __device__ inline float2 c_add(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__host__ __device__ inline float2 c_sub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+// a * (DIR i)
+template <int DIR>
+__host__ __device__ inline float2 c_mul_i(float2 a)
+{
+    return DIR > 0 ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x);
+}
+// table entry as exp(DIR i angle)
+template <int DIR>
+__host__ __device__ inline float2 c_dir(float2 w)
+{
+    return DIR > 0 ? w : make_float2(w.x, -w.y);
+}
+
+// 4-point transform in place: (a, b, c, d) = x0..x3 -> X0..X3, kernel exp(DIR 2 pi i n k / 4)
+template <int DIR>
+__host__ __device__ inline void dft4(float2 &a, float2 &b, float2 &c, float2 &d)
+{
+    const float2 s02 = c_add(a, c), d02 = c_sub(a, c), s13 = c_add(b, d), d13 = c_mul_i<DIR>(c_sub(b, d));
+    a = c_add(s02, s13);
+    b = c_add(d02, d13);
+    c = c_sub(s02, s13);
+    d = c_sub(d02, d13);
+}
+
+// 16-point transform of v[0..15] (natural order in).  Element k of the result is left in v[fft16_slot(k)].
+__host__ __device__ constexpr int fft16_slot(int k) { return 4 * (k & 3) + (k >> 2); }
+
+template <int DIR>
+__host__ __device__ inline void dft16(float2 (&v)[16])
+{
+    // n = 4 n1 + n2, k = k1 + 4 k2: 4-point transforms over n1, factors W16^(n2 k1), 4-point transforms over n2
+#pragma unroll
+    for (int n2 = 0; n2 < 4; n2++) dft4<DIR>(v[n2], v[4 + n2], v[8 + n2], v[12 + n2]);  // -> v[4 k1 + n2]
+    constexpr float c1 = 0.9238795325112867f, s1 = 0.3826834323650898f, h = 0.7071067811865476f;
+    const float2 w1 = make_float2(c1, DIR * s1), w2 = make_float2(h, DIR * h), w3 = make_float2(s1, DIR * c1);
+    const float2 w6 = make_float2(-h, DIR * h), w9 = make_float2(-c1, -DIR * s1);
+    v[4 * 1 + 1] = c_mul(v[4 * 1 + 1], w1);
+    v[4 * 2 + 1] = c_mul(v[4 * 2 + 1], w2);
+    v[4 * 3 + 1] = c_mul(v[4 * 3 + 1], w3);
+    v[4 * 1 + 2] = c_mul(v[4 * 1 + 2], w2);
+    v[4 * 2 + 2] = c_mul_i<DIR>(v[4 * 2 + 2]);  // W16^4
+    v[4 * 3 + 2] = c_mul(v[4 * 3 + 2], w6);
+    v[4 * 1 + 3] = c_mul(v[4 * 1 + 3], w3);
+    v[4 * 2 + 3] = c_mul(v[4 * 2 + 3], w6);
+    v[4 * 3 + 3] = c_mul(v[4 * 3 + 3], w9);
+#pragma unroll
+    for (int k1 = 0; k1 < 4; k1++) dft4<DIR>(v[4 * k1], v[4 * k1 + 1], v[4 * k1 + 2], v[4 * k1 + 3]);  // -> v[4 k1 + k2]
+}
+
+// ---- one radix-16 pass, butterfly j (0 <= j < N / 16) ----
+template <int N>
+__host__ __device__ inline void fft16_load(const float2 *buf, int j, float2 (&v)[16])
+{
+#pragma unroll
+    for (int r = 0; r < 16; r++) v[r] = buf[fft_phys(j + r * (N / 16))];
+}
+
+template <int DIR, int Ns>
+__host__ __device__ inline void fft16_math(float2 (&v)[16], int j, const float2 *__restrict__ tab)
+{
+    if constexpr (Ns > 1) {
+        const int k = j & (Ns - 1);
+        constexpr int stride = kFftTab / (16 * Ns);  // table steps per unit angle 2 pi / (16 Ns)
+        float2 w[16];
+        w[1] = c_dir<DIR>(tab[k * stride]);
+        w[2] = c_dir<DIR>(tab[2 * k * stride]);
+        w[4] = c_dir<DIR>(tab[4 * k * stride]);
+        w[8] = c_dir<DIR>(tab[8 * k * stride]);
+        w[3] = c_mul(w[1], w[2]);
+        w[5] = c_mul(w[1], w[4]);
+        w[6] = c_mul(w[2], w[4]);
+        w[9] = c_mul(w[1], w[8]);
+        w[10] = c_mul(w[2], w[8]);
+        w[12] = c_mul(w[4], w[8]);
+        w[7] = c_mul(w[3], w[4]);
+        w[11] = c_mul(w[3], w[8]);
+        w[13] = c_mul(w[5], w[8]);
+        w[14] = c_mul(w[6], w[8]);
+        w[15] = c_mul(w[7], w[8]);
+#pragma unroll
+        for (int r = 1; r < 16; r++) v[r] = c_mul(v[r], w[r]);
+    }
+    dft16<DIR>(v);
+}
+
+template <int Ns>
+__host__ __device__ inline void fft16_store(float2 *buf, int j, const float2 (&v)[16])
+{
+    const int k = j & (Ns - 1);
+    const int j0 = (j - k) * 16 + k;
+#pragma unroll
+    for (int r = 0; r < 16; r++) buf[fft_phys(j0 + r * Ns)] = v[fft16_slot(r)];
+}
+
+// ---- the last pass (radix N / 4096, stride 4096), butterfly j (0 <= j < 4096), in place ----
+template <int N, int DIR>
+__host__ __device__ inline void fft_last(float2 *buf, int j, const float2 *__restrict__ tab)
+{
+    constexpr int R = N / 4096;
+    static_assert(R == 2 || R == 4, "last pass is radix 2 or 4");
+    constexpr int stride = kFftTab / N;
+    if constexpr (R == 2) {
+        const float2 a = buf[fft_phys(j)];
+        const float2 b = c_mul(buf[fft_phys(j + 4096)], c_dir<DIR>(tab[j * stride]));
+        buf[fft_phys(j)] = c_add(a, b);
+        buf[fft_phys(j + 4096)] = c_sub(a, b);
+    } else {
+        float2 a = buf[fft_phys(j)];
+        float2 b = c_mul(buf[fft_phys(j + 4096)], c_dir<DIR>(tab[j * stride]));
+        float2 c = c_mul(buf[fft_phys(j + 8192)], c_dir<DIR>(tab[2 * j * stride]));
+        float2 d = c_mul(buf[fft_phys(j + 12288)], c_dir<DIR>(tab[3 * j * stride]));
+        dft4<DIR>(a, b, c, d);
+        buf[fft_phys(j)] = a;
+        buf[fft_phys(j + 4096)] = b;
+        buf[fft_phys(j + 8192)] = c;
+        buf[fft_phys(j + 12288)] = d;
+    }
+}
+
+#if defined(__HIPCC__)
+// The whole transform by a workgroup of N / 16 threads; buf holds the input in natural order (the caller has
+// synchronised after filling it) and the result on return (synchronised).
+template <int N, int DIR>
+__device__ __forceinline__ void fft_lds(float2 *buf, const float2 *__restrict__ tab, int tid)
+{
+    constexpr int T = N / 16;
+    float2 v[16];
+    fft16_load<N>(buf, tid, v);
+    fft16_math<DIR, 1>(v, tid, tab);
+    __syncthreads();
+    fft16_store<1>(buf, tid, v);
+    __syncthreads();
+    fft16_load<N>(buf, tid, v);
+    fft16_math<DIR, 16>(v, tid, tab);
+    __syncthreads();
+    fft16_store<16>(buf, tid, v);
+    __syncthreads();
+    fft16_load<N>(buf, tid, v);
+    fft16_math<DIR, 256>(v, tid, tab);
+    __syncthreads();
+    fft16_store<256>(buf, tid, v);
+    __syncthreads();
+    if constexpr (N > 4096) {
+#pragma unroll
+        for (int m = 0; m < 4096 / T; m++) fft_last<N, DIR>(buf, tid + m * T, tab);
+        __syncthreads();
+    }
+}
+#endif
+
+}  // namespace sgz

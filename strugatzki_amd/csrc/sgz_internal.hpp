@@ -94,6 +94,27 @@ struct HalfGeom {
     float relErrT, relErrS;
 };
 
+// ---- spectral (FFT) screening: the cross terms of N - L + 1 consecutive windows from one N-point transform ----
+struct FftGeom {
+    int N;      // transform length (0: spectral screening is not in use for this layout)
+    int hop;    // windows per block: N - L + 1
+    // error of a cross term of the channel group, relative to |a'| |x_block| (both Euclidean norms), times
+    // |a'| / (aStd n): multiplied by the block's norm and 1 / sd of the window it bounds the normalised term
+    float etaT, etaS;
+    float relErr;          // fp32 rounding of the target values, relative to |a'| |x_window|
+    double sumAT, sumAS;   // sums of the fp32 target values
+};
+
+// One block of the spectral screening kernel: N frames of one file from frame o0 on, `valid` windows.
+struct FftBlock {
+    int file;
+    int o0;
+    int valid;
+    int pad;
+    long long spec;  // offset (complex values) of the block's spectra [numCh][N / 2]
+    long long win;   // index of the block's first window in the dense per-window arrays
+};
+
 struct DbFile {
     float *d_raw = nullptr;
     long long frames = 0;
@@ -182,6 +203,27 @@ struct sgz_context {
     float *d_wstat_h = nullptr;              // per window: the target-independent part of its bounds (8 floats,
     size_t wstat_h_cap = 0;                  // sgz::WindowStatic), built with the image and kept as long as it
     int hc_begin = 0, hc_end = 0;
+    // Spectral screening (sgz_corr_fft.hip): per block of N frames the spectra of all channels, built with the
+    // half-precision preparation and kept as long as it; the target's spectra are rebuilt per target.
+    int screen_kernel = 0;                   // sgz_corr_set_screen_kernel: 0 auto, 1 matrix cores, 2 spectral
+    sgz::FftGeom fg{};
+    std::vector<sgz::FftBlock> h_fblocks;
+    std::vector<int> fblock_begin;           // first block of each file (+ sentinel)
+    sgz::FftBlock *d_fblocks = nullptr;
+    size_t d_fblocks_cap = 0;
+    float2 *d_spec = nullptr;                // [block][numCh][N / 2] complex, bin 0 holds (DC, Nyquist)
+    size_t spec_cap = 0;
+    float2 *d_aspec = nullptr;               // conjugated target spectra / N, same packing
+    size_t aspec_cap = 0;
+    float2 *d_fft_tab = nullptr;             // (cos, sin)(2 pi j / kFftTab)
+    float *d_blksq = nullptr;                // [block][numCh] sum of squares of the block's centred values
+    size_t blksq_cap = 0;
+    float2 *d_blknorm = nullptr;             // per block: Euclidean norm of the loudness channel, of the others
+    size_t blknorm_cap = 0;
+    bool aspec_dirty = true;
+    int fc_begin = 0, fc_end = 0;            // files whose spectra are current
+    double tgt_sumT = 0.0, tgt_sumS = 0.0;   // sums and Euclidean norms of the fp32 target values
+    double tgt_nrmT = 0.0, tgt_nrmS = 0.0;
     float *d_thr = nullptr;                  // smallest of the head files' bounds (filter of the tail files)
     size_t thr_cap = 0;
     sgz_candidate *h_pinned = nullptr;       // pinned staging of the first candidate transfer
@@ -264,6 +306,13 @@ int half_screen_pick_tile(sgz_context *ctx, const long long *numWindows, int num
 int half_screen_set_target(sgz_context *ctx, const std::vector<double> &aprime, size_t Lpad);
 int half_screen_launch(sgz_context *ctx, int tile_begin, int tile_end, hipStream_t stream, hipEvent_t start,
                        hipEvent_t stop);
+
+// sgz_corr_fft.hip
+int fft_screen_layout(sgz_context *ctx);  // after the file table of a layout is built: block table, buffers
+int fft_screen_prepare(sgz_context *ctx, int file_begin, int file_end, hipStream_t stream);
+int fft_screen_launch(sgz_context *ctx, int file_begin, int file_end, hipStream_t stream, hipEvent_t start,
+                      hipEvent_t stop);
+void fft_screen_free(sgz_context *ctx);
 
 // sgz_corr.hip: address of the device's scratch array of sgz_corr_rescore_device_noalloc (device must be current)
 int noalloc_scratch_init(sgz_context *ctx);

@@ -166,6 +166,17 @@ class Context:
     def screen_f16_available(self) -> bool:
         return bool(lib.sgz_corr_screen_f16_available(self._h))
 
+    SCREEN_KERNELS = {"auto": 0, "matrix": 1, "spectral": 2}
+
+    def set_screen_kernel(self, kernel: str) -> None:
+        """Which kernel produces the bounds of corr_run_screen_f16: "matrix" (half-precision products on the
+        matrix cores), "spectral" (fp32 transforms of whole blocks, HBM-bound) or "auto"."""
+        self._check(lib.sgz_corr_set_screen_kernel(self._h, self.SCREEN_KERNELS[kernel]))
+
+    @property
+    def screen_kernel_in_use(self) -> str | None:
+        return {1: "matrix", 2: "spectral", 0: "none"}.get(lib.sgz_corr_screen_kernel_in_use(self._h))
+
     def corr_read_dense(self, file: int) -> tuple[np.ndarray, np.ndarray]:
         n = max(0, self.corr_num_windows(file))
         sim = np.empty(n, dtype=np.float32)
