@@ -15,8 +15,11 @@ against a 10 h database (120 files x 300 s), 13 MFCC + loudness,
 temporalWeight 0.5, top-10.  For N>1 the default is the large-database configuration:
 60 s target (5168 frames) against 1500 files x 300 s per GPU (125 h per GPU,
 1000 h on 8 GPUs), sharded by file; --target-seconds / --files-per-gpu override
-either.  The same run also times the reference-precision dense path (fp64
-kernel over every window) and reports it as roofline.exact.
+either.  The bounds of every window come from the spectral kernel (fp32 block
+transforms, HBM-bound) where the target is long enough, else from the matrix-core
+kernel; --screen-kernel forces one.  The same run also times the search with the
+other screening kernel (roofline.matrix_cores) and the reference-precision dense
+path (fp64 kernel over every window, roofline.exact).
 """
 from __future__ import annotations
 
@@ -97,11 +100,11 @@ def cpu_baseline(L: int, frames_per_file: int, budget_s: float) -> dict:
     }
 
 
-def pmc_traffic_bytes(kernel: str):
+def pmc_traffic_bytes(kernel: str, summary: str = "r02_pmc_summary.csv"):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of the default N=1 command
-    (profiles/r02_pmc_summary.csv): 2 x FETCH_SIZE (gfx950 tallies 128-byte read requests at 64 bytes) +
+    (profiles/<summary>): 2 x FETCH_SIZE (gfx950 tallies 128-byte read requests at 64 bytes) +
     WRITE_SIZE, both in KiB.  None when the summary does not hold the kernel."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_summary.csv")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", summary)
     try:
         import csv
         vals = {}
@@ -146,7 +149,14 @@ def main() -> int:
     ap.add_argument("--sharded", action="store_true",
                     help="take the multi-GPU code path (RCCL group, candidate exchange) even with one rank")
     ap.add_argument("--screen-mode", choices=["auto", "f16", "f32"], default="auto",
-                    help="screening kernel: half-precision matrix-core kernel (f16) or fp32-product kernel (f32)")
+                    help="screening path: certified bounds from the spectral / matrix-core kernels (f16) or the "
+                         "fp32-product kernel (f32)")
+    ap.add_argument("--screen-kernel", choices=["auto", "matrix", "spectral"], default="auto",
+                    help="kernel behind the certified bounds: fp32 block transforms (spectral, HBM-bound), "
+                         "half-precision products on the matrix cores (matrix), or the library's choice")
+    ap.add_argument("--other-steps", type=int, default=400,
+                    help="steps of the same search with the screening kernel the library did not pick, timed after "
+                         "the main loop at N=1 (roofline.matrix_cores / roofline.spectral); 0 disables")
     args = ap.parse_args()
 
     import torch
@@ -216,6 +226,7 @@ def main() -> int:
     target = ctx_t.db_read_file(0)[TARGET_START:TARGET_START + L].copy()
     ctx_t.close()
     ctx.corr_set_target(target, 0.5, 8.0)
+    ctx.set_screen_kernel(args.screen_kernel)
 
     params = S.SearchParams(args.num_matches, 1, 0, STEP, capacity=1 << 16, screen=not args.exact_only,
                             screen_mode=args.screen_mode)
@@ -246,7 +257,10 @@ def main() -> int:
     # Clock settling, untimed and reported as such: after an idle period the chip needs some tens of
     # milliseconds of load before it holds its clocks; the first steps then run 5-10 % slower than the rest.
     # (a fixed count, the same on every rank: the sharded step holds a collective)
-    matches = []
+    matches = step()
+    # which kernel the layout of this database and target uses for the bounds
+    spectral = mode == "f16" and ctx.screen_kernel_in_use == "spectral"
+    fft_n, fft_hop, fft_blocks = ctx.screen_geometry
     settle_steps = int(args.settle_ms / 0.3)
     for _ in range(settle_steps):
         matches = step()
@@ -294,6 +308,31 @@ def main() -> int:
             step()
             cold_ms.append((time.perf_counter() - tc) * 1e3)
 
+    # The same search with the other screening kernel, timed in the same run (the layout is rebuilt, so the first
+    # steps are cold and untimed).
+    alt = None
+    if world == 1 and not sharded and mode == "f16" and args.other_steps > 0 and args.screen_kernel == "auto":
+        other_name = "matrix" if spectral else "spectral"
+        ctx.set_screen_kernel(other_name)
+        ctx.set_kernel_timing(8)
+        for _ in range(100):
+            om = step()
+        if ctx.screen_kernel_in_use == other_name:
+            ctx.synchronize()
+            to = time.perf_counter()
+            for _ in range(args.other_steps):
+                om = step()
+            ctx.synchronize()
+            o_elapsed = time.perf_counter() - to
+            o_ms = [float(x) for x in ctx.kernel_ms_history(args.other_steps // 8) if x > 0]
+            o_windows, o_flops = ctx.corr_last_work()
+            alt = (other_name, o_elapsed / args.other_steps, float(np.mean(o_ms)) if o_ms else 0.0, o_windows, o_flops,
+                     [(m.file, m.start, m.stop, m.sim) for m in om] == [(m.file, m.start, m.stop, m.sim) for m in matches],
+                     ctx.screen_geometry)
+        ctx.set_screen_kernel(args.screen_kernel)
+        ctx.set_kernel_timing(timing_every)
+        step()
+
     # The same search at reference arithmetic: the fp64 kernel evaluates every window (no screening), the
     # selection replays over its values.  Timed here, after the main loop, so that the driver's own run carries
     # the number next to the screened one.
@@ -338,23 +377,90 @@ def main() -> int:
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        # dominant kernel: corr_kernel of the tail launch (the last sgz_corr_run of a step)
+        # dominant kernel: the launch that evaluates every window of the step
         tail_windows, tail_flops = screened_work
         k_ms = float(np.mean(kernel_ms))
-        achieved = tail_flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
-        alg_bytes = tail_windows * 64.0
-        peak = {"f64": PEAK_F64_TFLOPS, "f32": PEAK_F32_TFLOPS, "f16": PEAK_F16_TFLOPS}[mode]
-        kernel = {"f64": "corr_kernel<double>", "f32": "corr_kernel<float>", "f16": "corr_mfma_kernel"}[mode]
-        note = {
-            "f64": "fp64 FMA on the vector pipe; MI355X fp64 vector and matrix peaks are both 78.6 TFLOP/s",
-            "f32": "tail launch: fp32 products / partial sums on the vector pipe (157.3 TFLOP/s peak, the same as the "
-                   "f32-input MFMA peak), fp64 window statistics; head files and every candidate above the bound are "
-                   "evaluated in fp64",
-            "f16": "one launch over all files: v_mfma_f32_16x16x32_f16 on half-precision copies of target and "
-                   "database (dense f16 MFMA peak 2516.6 TFLOP/s = 256 CU x 4 SIMD x 1024 flop/clk x 2.4 GHz), fp32 "
-                   "sums, fp64 window statistics; it yields certified bounds, and every window the bounds cannot "
-                   "exclude is re-evaluated in fp64 from the raw frames before the selection replay",
-        }[mode]
+        alg_bytes = tail_windows * 64.0  # one new frame in (56 B), similarity and boost out (8 B)
+
+        def matrix_roofline(kms, flops):
+            ach = flops / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
+            return {
+                "bound": "mfma", "kernel": "corr_mfma_kernel", "achieved": ach, "peak": PEAK_F16_TFLOPS,
+                "unit": "TFLOP/s", "frac": ach / PEAK_F16_TFLOPS,
+                # what tools/mfma_peak.hip sustains with this instruction shape, register operands only, on
+                # pseudo-random half-precision data (the chip's clock under matrix load depends on operand bit
+                # activity: 2480 TFLOP/s on zeros, 2320 on smooth small numbers, 1965 on random data)
+                "sustained_peak_random_operands": SUSTAINED_F16_RANDOM_TFLOPS,
+                "frac_of_sustained": ach / SUSTAINED_F16_RANDOM_TFLOPS,
+                "note": "one launch over all files: v_mfma_f32_16x16x32_f16 on half-precision copies of target and "
+                        "database (dense f16 MFMA peak 2516.6 TFLOP/s = 256 CU x 4 SIMD x 1024 flop/clk x 2.4 GHz), fp32 "
+                        "sums, fp64 window statistics; it yields certified bounds, and every window the bounds cannot "
+                        "exclude is re-evaluated in fp64 from the raw frames before the selection replay",
+            }
+
+        def spectral_roofline(kms, windows, geom):
+            n, hop, blocks = geom
+            ach = windows * 64.0 / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+            # what the kernel is built to move: the blocks' spectra, 32 B of cached statistics per window in,
+            # upper bound, lower bound and boost (12 B) per window out
+            moved = blocks * 4.0 * NUM_CH * n + windows * (32.0 + 12.0)
+            return {
+                "bound": "hbm", "kernel": "corr_fft_kernel", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": ach / PEAK_HBM_GBS,
+                "algorithmic_bytes": windows * 64.0,
+                "bytes_by_design": moved,
+                "gbs_by_design": moved / (kms * 1e-3) / 1e9 if kms > 0 else 0.0,
+                "transform_length": n, "windows_per_block": hop, "blocks": blocks,
+                "note": "one launch over all files, one workgroup per block of N frames: the cross terms of a block's "
+                        "N - L + 1 windows are one circular correlation, evaluated from fp32 spectra of the blocks kept "
+                        "in HBM with the database (product with the target's spectra, channels summed in the frequency "
+                        "domain, one inverse transform in LDS); achieved = 64 algorithmic bytes per window (one new "
+                        "frame in, similarity and boost out) over the kernel's duration, against 8 TB/s; "
+                        "bytes_by_design is what this formulation has to move (overlapping blocks, cached window "
+                        "statistics, two bounds and the boost per window).  It yields certified bounds, and every "
+                        "window the bounds cannot exclude is re-evaluated in fp64 from the raw frames before the "
+                        "selection replay",
+            }
+
+        is_c3 = (L, total_files) == (2584, 120)
+        if spectral:
+            roof = spectral_roofline(k_ms, tail_windows, (fft_n, fft_hop, fft_blocks))
+            roof["traffic"] = pmc_traffic_bytes("corr_fft_kernel", "r02_spectral_pmc_summary.csv") if is_c3 else None
+        elif mode == "f16":
+            roof = matrix_roofline(k_ms, tail_flops)
+            roof["traffic"] = pmc_traffic_bytes("corr_mfma_kernel") if is_c3 else None
+        else:
+            achieved = tail_flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+            peak = {"f64": PEAK_F64_TFLOPS, "f32": PEAK_F32_TFLOPS}[mode]
+            roof = {
+                "bound": "mfma", "kernel": {"f64": "corr_kernel<double>", "f32": "corr_kernel<float>"}[mode],
+                "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                "note": {
+                    "f64": "fp64 FMA on the vector pipe; MI355X fp64 vector and matrix peaks are both 78.6 TFLOP/s",
+                    "f32": "tail launch: fp32 products / partial sums on the vector pipe (157.3 TFLOP/s peak, the same as "
+                           "the f32-input MFMA peak), fp64 window statistics; head files and every candidate above the "
+                           "bound are evaluated in fp64",
+                }[mode],
+            }
+        roof.update({
+            "kernel_ms": k_ms,
+            "kernel_ms_samples": len(kernel_ms),
+            "windows_per_launch": tail_windows,
+            "flop_per_window_direct_form": 2.0 * NUM_CH * L,
+            "hbm_frac_algorithmic": (alg_bytes / (k_ms * 1e-3) / 1e9) / PEAK_HBM_GBS if k_ms > 0 else 0.0,
+        })
+        if alt is not None:
+            a_name, a_step, a_kms, a_windows, a_flops, a_same, a_geom = alt
+            sub = matrix_roofline(a_kms, a_flops) if a_name == "matrix" else spectral_roofline(a_kms, a_windows, a_geom)
+            sub.update({"kernel_ms": a_kms, "ms_per_step": a_step * 1e3, "steps": args.other_steps,
+                        "windows_per_s": unique_windows / a_step, "same_matches": a_same})
+            if a_name == "matrix":
+                sub["traffic"] = pmc_traffic_bytes("corr_mfma_kernel") if is_c3 else None
+            roof["matrix_cores" if a_name == "matrix" else "spectral"] = sub
+        dtype = {"f16": "f16 screening (matrix cores), f64 re-scoring of every returned similarity",
+                 "f32": "f32 screening, f64 re-scoring of every returned similarity", "f64": "f64"}[mode]
+        if spectral:
+            dtype = "f32 spectral screening (block transforms), f64 re-scoring of every returned similarity"
         out = {
             "metric": "candidate windows/sec, 30 s target vs 10 h DB, 13-MFCC; 1/2/4/8 GPU",
             "value": unique_windows / (elapsed / args.steps),
@@ -368,8 +474,7 @@ def main() -> int:
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": {"f16": "f16 screening (matrix cores), f64 re-scoring of every returned similarity",
-                      "f32": "f32 screening, f64 re-scoring of every returned similarity", "f64": "f64"}[mode],
+            "dtype": dtype,
             "data": "synthetic",
             "config": {
                 "workload": f"FeatureCorrelation: {args.target_seconds:g} s target ({L} frames) vs "
@@ -383,29 +488,10 @@ def main() -> int:
                 "baseline_config": "configs[2]" if (L, args.files_per_gpu) == (2584, 120) else (
                     "configs[4] (per-GPU shard)" if (L, args.files_per_gpu) == (5168, 1500) else "custom"),
             },
-            # work per window grows with the target length: this figure compares runs of different configurations
-            "whole_job_tflops": unique_windows * 2.0 * NUM_CH * L / (elapsed / args.steps) / 1e12,
-            "roofline": {
-                "bound": "mfma",
-                "kernel": kernel,
-                "achieved": achieved,
-                "peak": peak,
-                "unit": "TFLOP/s",
-                "frac": achieved / peak,
-                # (the committed counter passes are of the default N=1 workload)
-                "traffic": pmc_traffic_bytes(kernel) if (L, total_files) == (2584, 120) else None,
-                "kernel_ms": k_ms,
-                "kernel_ms_samples": len(kernel_ms),
-                "windows_per_launch": tail_windows,
-                "flop_per_window": 2.0 * NUM_CH * L,
-                "hbm_frac_algorithmic": (alg_bytes / (k_ms * 1e-3) / 1e9) / PEAK_HBM_GBS if k_ms > 0 else 0.0,
-                # what tools/mfma_peak.hip sustains with this instruction shape, register operands only, on
-                # pseudo-random half-precision data (the chip's clock under matrix load depends on operand bit
-                # activity: 2480 TFLOP/s on zeros, 2320 on smooth small numbers, 1965 on random data)
-                "sustained_peak_random_operands": SUSTAINED_F16_RANDOM_TFLOPS if mode == "f16" else None,
-                "frac_of_sustained": achieved / SUSTAINED_F16_RANDOM_TFLOPS if mode == "f16" else None,
-                "note": note,
-            },
+            # direct-form work per window grows with the target length: this figure compares runs of different
+            # configurations (the spectral kernel does not carry out these operations)
+            "whole_job_tflops_direct_form": unique_windows * 2.0 * NUM_CH * L / (elapsed / args.steps) / 1e12,
+            "roofline": roof,
             "verified": verified,
         }
         if exact is not None:

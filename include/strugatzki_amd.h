@@ -227,6 +227,10 @@ SGZ_API int sgz_corr_screen_f16_available(const sgz_context *ctx);
  * sgz_corr_screen_kernel_in_use: 1 or 2 once a run has built the layout, 0 if neither applies, -1 before. */
 SGZ_API int sgz_corr_set_screen_kernel(sgz_context *ctx, int kernel);
 SGZ_API int sgz_corr_screen_kernel_in_use(const sgz_context *ctx);
+/* Geometry of the spectral kernel for the current layout: transform length N, windows per block (N - L + 1) and
+ * the number of blocks over all files; zeros when the spectral kernel is not in use.  Any pointer may be NULL.
+ * For reports (a block moves 4 * numCh * N bytes of spectra); no counterpart in the reference. */
+SGZ_API int sgz_corr_screen_geometry(const sgz_context *ctx, int *n_out, int *hop_out, long long *blocks_out);
 /* The N-point complex fp32 transform of the spectral kernel (N = 4096, 8192, 16384; forward or inverse without the
  * 1 / N factor; interleaved re, im), run thread by thread on the host with the kernels' own index arithmetic and
  * operations: test support, no GPU needed, no counterpart in the reference. */

@@ -534,6 +534,16 @@ int sgz_corr_screen_kernel_in_use(const sgz_context *ctx)
     return ctx->hg.S2 > 0 ? 1 : 0;
 }
 
+int sgz_corr_screen_geometry(const sgz_context *ctx, int *n_out, int *hop_out, long long *blocks_out)
+{
+    if (!ctx) return SGZ_E_ARG;
+    const bool on = ctx->have_target && !ctx->layout_dirty && ctx->fg.N > 0;
+    if (n_out) *n_out = on ? ctx->fg.N : 0;
+    if (hop_out) *hop_out = on ? ctx->fg.hop : 0;
+    if (blocks_out) *blocks_out = on ? (long long)ctx->h_fblocks.size() : 0;
+    return SGZ_OK;
+}
+
 // The transform the kernels run, thread by thread on the host (same index arithmetic, same fp32 operations).
 int sgz_fft_reference_host(int n, int inverse, const float *in, float *out)
 {

@@ -177,6 +177,13 @@ class Context:
     def screen_kernel_in_use(self) -> str | None:
         return {1: "matrix", 2: "spectral", 0: "none"}.get(lib.sgz_corr_screen_kernel_in_use(self._h))
 
+    @property
+    def screen_geometry(self) -> tuple[int, int, int]:
+        """(N, windows per block, blocks) of the spectral kernel for the current layout; zeros when not in use."""
+        n, hop, blocks = C.c_int(0), C.c_int(0), C.c_longlong(0)
+        self._check(lib.sgz_corr_screen_geometry(self._h, C.byref(n), C.byref(hop), C.byref(blocks)))
+        return n.value, hop.value, blocks.value
+
     def corr_read_dense(self, file: int) -> tuple[np.ndarray, np.ndarray]:
         n = max(0, self.corr_num_windows(file))
         sim = np.empty(n, dtype=np.float32)
