@@ -62,7 +62,7 @@ void sgz_destroy(sgz_context *ctx)
     void *bufs[] = {ctx->d_planar_f, ctx->d_planar_h, ctx->d_aprime, ctx->d_aprime_f, ctx->d_aimg_h, ctx->d_tnorm,
                     ctx->d_files,    ctx->d_tiles,    ctx->d_tiles_h, ctx->d_ptiles,  ctx->d_planar, ctx->d_prefix,
                     ctx->d_tbase,    ctx->d_sim,      ctx->d_boost,   ctx->d_cand,    ctx->d_hflags,
-                    ctx->d_lo,       ctx->d_suspect,  ctx->d_done,     ctx->d_lokey,    ctx->d_thr,      ctx->d_rs_part,  ctx->d_normtab,
+                    ctx->d_suspect,  ctx->d_done,     ctx->d_lokey,    ctx->d_thr,      ctx->d_rs_part,  ctx->d_normtab,
                     ctx->d_prefix_h, ctx->d_tbase_h, ctx->d_wstat_h, ctx->d_prefetch_done};
     for (void *b : bufs)
         if (b) (void)hipFree(b);

@@ -943,19 +943,17 @@ __global__ __launch_bounds__(64) void bound_min_kernel(const int *__restrict__ l
 
 // The k-th largest of the per-file bounds (lokey[0 .. n)), -inf when there are fewer than k files: with
 // numPerFile = 1 and k = numMatches, a file whose similarities all lie below it cannot be in the result when at
-// least k files reach it with distinct values (the caller checks that on the finished selection).  One
-// workgroup; radix selection over the order-preserving keys, a byte per round.
-__global__ __launch_bounds__(256) void bound_kth_kernel(const int *__restrict__ lokey, int n, int k, float *__restrict__ out)
+// least k files reach it with distinct values (the caller checks that on the finished selection).  Work of one
+// workgroup of 256 threads (every thread returns the value); radix selection over the order-preserving keys, a
+// byte per round.
+__device__ float bound_kth_select(const int *__restrict__ lokey, int n, int k)
 {
     __shared__ int hist[256];
     __shared__ int waveTotal[4];
     __shared__ unsigned int chosenPrefix;
     __shared__ int chosenLeft;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (n < k || k < 1) {
-        if (tid == 0) out[0] = -INFINITY;
-        return;
-    }
+    if (n < k || k < 1) return -INFINITY;
     // (the keys of up to four files per thread stay in registers; more are read again every round)
     unsigned int mine[4];
 #pragma unroll
@@ -994,14 +992,17 @@ __global__ __launch_bounds__(256) void bound_kth_kernel(const int *__restrict__ 
         left = chosenLeft;
         mask |= 255u << shift;
     }
-    if (tid == 0) out[0] = bound_from_key((int)(prefix ^ 0x80000000u));
+    return bound_from_key((int)(prefix ^ 0x80000000u));
 }
 
-// Windows of head files (file < headEnd) whose upper bound reaches the file's own bound (and topThr[0], the
-// bound of bound_kth_kernel, when given), windows of the other files whose upper bound exceeds the minimum of
-// the head bounds (thr[headEnd]).
+// Windows of head files (file < headEnd) whose upper bound reaches the file's own bound (and, with topK > 0, the
+// topK-th largest of the head files' bounds), windows of the other files whose upper bound exceeds the minimum of
+// the head bounds (tailThr[0]).  A workgroup works through tiles blockIdx.x, blockIdx.x + gridDim.x, ...; with
+// topK > 0 every workgroup first selects that bound for itself from the per-file keys -- a few microseconds of
+// redundant work that cost less than a kernel of one workgroup ahead of this one -- and workgroup 0 leaves it in
+// topThrOut[0] for the host.
 __global__ __launch_bounds__(256) void compact_bounded_kernel(const FileDesc *__restrict__ files,
-                                                              const TileDesc *__restrict__ tiles,
+                                                              const TileDesc *__restrict__ tiles, int numTiles,
                                                               const float *__restrict__ up,
                                                               const float *__restrict__ boost,
                                                               const int *__restrict__ lokey,
@@ -1009,35 +1010,51 @@ __global__ __launch_bounds__(256) void compact_bounded_kernel(const FileDesc *__
                                                               sgz_candidate *__restrict__ out, long long capacity,
                                                               unsigned long long *__restrict__ count,
                                                               const int *__restrict__ hflags,
-                                                              unsigned long long *__restrict__ zeroOther,
-                                                              const float *__restrict__ topThr)
+                                                              unsigned long long *__restrict__ zeroOther, int topK,
+                                                              float *__restrict__ topThrOut)
 {
-    const TileDesc td = tiles[blockIdx.x];
-    const FileDesc fd = files[td.file];
     if (zeroOther && blockIdx.x == 0 && threadIdx.x == 0) *zeroOther = 0ull;
-    // (every file this kernel sees holds bounds of a half-precision run: the host checks)
-    if (hflags[td.file] && td.o0 == 0 && threadIdx.x == 0) atomicAdd(count, (unsigned long long)capacity + 1ull);
-    const bool headFile = td.file < headEnd;
-    float t = headFile ? bound_from_key(lokey[td.file]) : tailThr[0];
-    if (topThr && headFile) t = fmaxf(t, topThr[0]);
+    float top = -INFINITY;
+    if (topK > 0) {
+        top = bound_kth_select(lokey, headEnd, topK);
+        if (blockIdx.x == 0 && threadIdx.x == 0) topThrOut[0] = top;
+    }
+    for (int tile = blockIdx.x; tile < numTiles; tile += gridDim.x) {
+        const TileDesc td = tiles[tile];
+        const FileDesc fd = files[td.file];
+        // (every file this kernel sees holds bounds of a half-precision run: the host checks)
+        if (hflags[td.file] && td.o0 == 0 && threadIdx.x == 0) atomicAdd(count, (unsigned long long)capacity + 1ull);
+        const bool headFile = td.file < headEnd;
+        float t = headFile ? bound_from_key(lokey[td.file]) : tailThr[0];
+        if (headFile) t = fmaxf(t, top);
+        float s[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const long long o = (long long)td.o0 + k * 256 + threadIdx.x;
-        if (o < fd.num_windows) {
-            const float s = up[fd.win_off + o];
-            if (headFile ? s >= t : s > t) {
+        for (int k = 0; k < 4; k++) {
+            const long long o = (long long)td.o0 + k * 256 + threadIdx.x;
+            s[k] = o < fd.num_windows ? up[fd.win_off + o] : -INFINITY;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const long long o = (long long)td.o0 + k * 256 + threadIdx.x;
+            if (o < fd.num_windows && (headFile ? s[k] >= t : s[k] > t)) {
                 const unsigned long long slot = atomicAdd(count, 1ull);
                 if ((long long)slot < capacity) {
                     sgz_candidate c;
                     c.file = td.file;
                     c.offset = (int)o;
-                    c.sim = s;
+                    c.sim = s[k];
                     c.boost = boost[fd.win_off + o];
                     out[slot] = c;
                 }
             }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void bound_kth_kernel(const int *__restrict__ lokey, int n, int k, float *__restrict__ out)
+{
+    const float v = bound_kth_select(lokey, n, k);
+    if (threadIdx.x == 0) out[0] = v;
 }
 
 // ---------------------------------------------------------------------------
@@ -1456,7 +1473,6 @@ int build_layout(sgz_context *ctx)
     if ((rc = ensure(ctx, ctx->d_tbase, ctx->tbase_cap, (size_t)tb))) return rc;
     if ((rc = ensure(ctx, ctx->d_sim, ctx->dense_cap, (size_t)wins))) return rc;
     if ((rc = ensure(ctx, ctx->d_boost, ctx->boost_cap, (size_t)wins))) return rc;
-    if (halfOk && (rc = ensure(ctx, ctx->d_lo, ctx->lo_cap, (size_t)wins))) return rc;
     if (halfOk && (rc = ensure(ctx, ctx->d_wstat_h, ctx->wstat_h_cap, (size_t)8 * (size_t)wins))) return rc;
     if (halfOk && (rc = ensure(ctx, ctx->d_lokey, ctx->lokey_cap, (size_t)2 * nf))) return rc;
     if (halfOk && nf)  // key of -inf in both arrays; files without windows keep it (no tile ever writes them)
@@ -2227,18 +2243,22 @@ static int compact_bounded_device_impl(sgz_context *ctx, int file_begin, int fil
         hipLaunchKernelGGL(bound_min_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->lokey_cur, head_end, ctx->d_thr);
         SGZ_HIP(ctx, hipGetLastError());
     }
-    float *topThr = nullptr;
-    if (top_k > 0) {
-        topThr = reinterpret_cast<float *>(device_count) + 2;
-        hipLaunchKernelGGL(bound_kth_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->lokey_cur, head_end, top_k, topThr);
-        SGZ_HIP(ctx, hipGetLastError());
-    }
+    // (the header that starts with the count takes the top_k-th largest bound as a float in its bytes 8..11)
+    float *topThr = top_k > 0 ? reinterpret_cast<float *>(device_count) + 2 : nullptr;
     const int t0 = ctx->tile_begin[file_begin], t1 = ctx->tile_begin[file_end];
     if (launched) *launched = t1 > t0;
     if (t1 > t0) {
-        hipLaunchKernelGGL(compact_bounded_kernel, dim3(t1 - t0), dim3(256), 0, ctx->stream, ctx->d_files,
-                           ctx->d_tiles + t0, ctx->d_sim, ctx->d_boost, ctx->lokey_cur, ctx->d_thr, head_end, device_out,
-                           (long long)capacity, device_count, ctx->d_hflags, zero_other, (const float *)topThr);
+        // four tiles per workgroup and more: enough workgroups to fill the chip, few enough that the bound
+        // selection each of them repeats stays cheap
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+        const int grid = std::max(1, std::min((t1 - t0 + 3) / 4, 8 * cus));
+        hipLaunchKernelGGL(compact_bounded_kernel, dim3(grid), dim3(256), 0, ctx->stream, ctx->d_files,
+                           ctx->d_tiles + t0, t1 - t0, ctx->d_sim, ctx->d_boost, ctx->lokey_cur, ctx->d_thr, head_end,
+                           device_out, (long long)capacity, device_count, ctx->d_hflags, zero_other, top_k, topThr);
+        SGZ_HIP(ctx, hipGetLastError());
+    } else if (top_k > 0) {
+        hipLaunchKernelGGL(bound_kth_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->lokey_cur, head_end, top_k, topThr);
         SGZ_HIP(ctx, hipGetLastError());
     }
     return SGZ_OK;

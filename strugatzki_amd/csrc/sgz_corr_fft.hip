@@ -192,7 +192,7 @@ __global__ __launch_bounds__(N / 16) void corr_fft_kernel(const FftBlock *__rest
                                                           const float2 *__restrict__ blknorm,
                                                           const float4 *__restrict__ wstat, CorrParams cp, FftGeom fg,
                                                           float *__restrict__ simOut, float *__restrict__ boostOut,
-                                                          float *__restrict__ loOut, int *__restrict__ lokey,
+                                                          int *__restrict__ lokey,
                                                           int *__restrict__ lokeyNext, int *__restrict__ hflags)
 {
     constexpr int T = N / 16, NH = N / 2;
@@ -263,7 +263,6 @@ __global__ __launch_bounds__(N / 16) void corr_fft_kernel(const FftBlock *__rest
                 window_bounds(wc, y.x, y.y, sim, lo);
                 boostOut[bd.win + k] = boost;
                 simOut[bd.win + k] = sim;
-                loOut[bd.win + k] = lo;
                 best = fmaxf(best, lo);
                 bad |= (lo != lo) || (sim != sim);
             }
@@ -496,12 +495,12 @@ int fft_screen_launch(sgz_context *ctx, int file_begin, int file_end, hipStream_
             hipExtLaunchKernelGGL(kern, dim3(b1 - b0), dim3(N / 16), lds, stream, start, stop, 0, ctx->d_fblocks + b0,
                                   ctx->d_spec, ctx->d_aspec, ctx->d_fft_tab, ctx->d_blknorm + b0,
                                   reinterpret_cast<const float4 *>(ctx->d_wstat_h), ctx->cp, fg, ctx->d_sim, ctx->d_boost,
-                                  ctx->d_lo, lokey, lokeyNext, ctx->d_hflags);
+                                  lokey, lokeyNext, ctx->d_hflags);
         else
             hipLaunchKernelGGL(kern, dim3(b1 - b0), dim3(N / 16), lds, stream, ctx->d_fblocks + b0, ctx->d_spec,
                                ctx->d_aspec, ctx->d_fft_tab, ctx->d_blknorm + b0,
                                reinterpret_cast<const float4 *>(ctx->d_wstat_h), ctx->cp, fg, ctx->d_sim, ctx->d_boost,
-                               ctx->d_lo, lokey, lokeyNext, ctx->d_hflags);
+                               lokey, lokeyNext, ctx->d_hflags);
         SGZ_HIP(ctx, hipGetLastError());
         return SGZ_OK;
     };

@@ -93,7 +93,7 @@ template <int NB>
 __global__ __launch_bounds__(kHThreads, 2 * half_wgs_per_cu(NB)) void corr_mfma_kernel(
     const HalfTile *__restrict__ tiles, const _Float16 *__restrict__ planarH, const float4 *__restrict__ wstat,
     const uint32_t *__restrict__ aimg, CorrParams cp, HalfGeom hg, float *__restrict__ simOut,
-    float *__restrict__ boostOut, float *__restrict__ loOut, int *__restrict__ lokey, int *__restrict__ lokeyNext,
+    float *__restrict__ boostOut, int *__restrict__ lokey, int *__restrict__ lokeyNext,
     int *__restrict__ hflags)
 {
     constexpr int kHTileW = NB * 256, kHSlabFloats = half_slab_floats(NB);
@@ -271,7 +271,6 @@ __global__ __launch_bounds__(kHThreads, 2 * half_wgs_per_cu(NB)) void corr_mfma_
             window_bounds(wc, red_read(redT4, wdw), red_read(redS4, wdw), sim, lo);
             boostOut[td.win + wdw] = boost;
             simOut[td.win + wdw] = sim;
-            loOut[td.win + wdw] = lo;
             best = fmaxf(best, lo);
             bad |= (lo != lo) || (sim != sim);
         }
@@ -449,12 +448,12 @@ int half_screen_launch(sgz_context *ctx, int tile_begin, int tile_end, hipStream
         if (start || stop)
             hipExtLaunchKernelGGL(kern, dim3(tile_end - tile_begin), dim3(kHThreads), ldsBytes, stream, start, stop, 0,
                                   ctx->d_tiles_h + tile_begin, planarH, reinterpret_cast<const float4 *>(ctx->d_wstat_h),
-                                  aimg, ctx->cp, hg, ctx->d_sim, ctx->d_boost, ctx->d_lo, lokey, lokeyNext,
+                                  aimg, ctx->cp, hg, ctx->d_sim, ctx->d_boost, lokey, lokeyNext,
                                   ctx->d_hflags);
         else
             hipLaunchKernelGGL(kern, dim3(tile_end - tile_begin), dim3(kHThreads), ldsBytes, stream,
                                ctx->d_tiles_h + tile_begin, planarH, reinterpret_cast<const float4 *>(ctx->d_wstat_h),
-                               aimg, ctx->cp, hg, ctx->d_sim, ctx->d_boost, ctx->d_lo, lokey, lokeyNext, ctx->d_hflags);
+                               aimg, ctx->cp, hg, ctx->d_sim, ctx->d_boost, lokey, lokeyNext, ctx->d_hflags);
         SGZ_HIP(ctx, hipGetLastError());
         return SGZ_OK;
     };

@@ -184,9 +184,7 @@ struct sgz_context {
     float *d_sim = nullptr;
     float *d_boost = nullptr;
     size_t dense_cap = 0, boost_cap = 0;
-    float *d_lo = nullptr;                   // lower bounds of the half-precision screening run
-    size_t lo_cap = 0;
-    int lo_begin = 0, lo_end = 0;            // files whose d_sim / d_lo hold bounds of the latest such run
+    int lo_begin = 0, lo_end = 0;            // files whose d_sim holds upper bounds of the latest screening run over bounds
     // per file: largest lower bound of a half-precision run, as an ordered integer key.  Two arrays of one entry
     // per file: a run folds its bounds into one of them and resets the other for the run after it.
     int *d_lokey = nullptr;
