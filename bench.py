@@ -401,9 +401,9 @@ def main() -> int:
         def spectral_roofline(kms, windows, geom):
             n, hop, blocks = geom
             ach = windows * 64.0 / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
-            # what the kernel is built to move: the blocks' spectra, 32 B of cached statistics per window in,
-            # upper bound, lower bound and boost (12 B) per window out
-            moved = blocks * 4.0 * NUM_CH * n + windows * (32.0 + 12.0)
+            # what the kernel is built to move: the blocks' spectra, 20 B of cached statistics per window in,
+            # upper bound and boost (8 B) per window out
+            moved = blocks * 4.0 * NUM_CH * n + windows * (20.0 + 8.0)
             return {
                 "bound": "hbm", "kernel": "corr_fft_kernel", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "frac": ach / PEAK_HBM_GBS,
@@ -417,7 +417,7 @@ def main() -> int:
                         "domain, one inverse transform in LDS); achieved = 64 algorithmic bytes per window (one new "
                         "frame in, similarity and boost out) over the kernel's duration, against 8 TB/s; "
                         "bytes_by_design is what this formulation has to move (overlapping blocks, cached window "
-                        "statistics, two bounds and the boost per window).  It yields certified bounds, and every "
+                        "statistics).  It yields certified bounds, and every "
                         "window the bounds cannot exclude is re-evaluated in fp64 from the raw frames before the "
                         "selection replay",
             }

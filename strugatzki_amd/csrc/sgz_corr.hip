@@ -551,12 +551,15 @@ __global__ __launch_bounds__(1024) void file_const_kernel(FileDesc *__restrict__
 // window_static_kernel: for every window of the files of a half-precision preparation, the part of its bounds
 // that does not depend on the target's values (sgz::WindowStatic, 32 bytes), from the fp32 prefix records and the
 // fp64 tile bases.  Runs once per database / norms / target length, after tile_scan_kernel; the matrix-core
-// kernel then reads two 16-byte words per window instead of doing these statistics in its epilogue.
+// kernel then reads two 16-byte words per window instead of doing these statistics in its epilogue.  For a layout
+// whose bounds come from the spectral kernel the same buffer takes that kernel's compact form instead
+// (compactWindows = all windows of the layout; sgz::SpectralStatics).
 __global__ __launch_bounds__(256) void window_static_kernel(const FileDesc *__restrict__ files,
                                                             const TileDesc *__restrict__ tiles,
                                                             const float4 *__restrict__ prefix,
                                                             const double *__restrict__ tbase, int L, int numCh,
-                                                            int tileShift, float4 *__restrict__ wstat)
+                                                            int tileShift, float4 *__restrict__ wstat,
+                                                            long long compactWindows)
 {
     const TileDesc td = tiles[blockIdx.x];
     const FileDesc fd = files[td.file];
@@ -570,8 +573,12 @@ __global__ __launch_bounds__(256) void window_static_kernel(const FileDesc *__re
         const long long o = (long long)td.o0 + k * 256 + threadIdx.x;
         if (o < fd.num_windows) {
             const WindowStatic ws = window_static(L, numCh, hp, (unsigned)o, window_records(hp, (unsigned)o, L), (double)fd.cT);
-            wstat[2 * (fd.win_off + o)] = make_float4(ws.rsdT, ws.dmT, ws.gT, ws.lnAvg);
-            wstat[2 * (fd.win_off + o) + 1] = make_float4(ws.rsdS, ws.dmS, ws.gS, __uint_as_float(ws.hTS));
+            if (compactWindows > 0) {  // the layout of the spectral kernel: 20 bytes per window in four arrays
+                spectral_statics_store(reinterpret_cast<float *>(wstat), compactWindows, fd.win_off + o, ws);
+            } else {
+                wstat[2 * (fd.win_off + o)] = make_float4(ws.rsdT, ws.dmT, ws.gT, ws.lnAvg);
+                wstat[2 * (fd.win_off + o) + 1] = make_float4(ws.rsdS, ws.dmS, ws.gS, __uint_as_float(ws.hTS));
+            }
         }
     }
 }
@@ -1473,7 +1480,8 @@ int build_layout(sgz_context *ctx)
     if ((rc = ensure(ctx, ctx->d_tbase, ctx->tbase_cap, (size_t)tb))) return rc;
     if ((rc = ensure(ctx, ctx->d_sim, ctx->dense_cap, (size_t)wins))) return rc;
     if ((rc = ensure(ctx, ctx->d_boost, ctx->boost_cap, (size_t)wins))) return rc;
-    if (halfOk && (rc = ensure(ctx, ctx->d_wstat_h, ctx->wstat_h_cap, (size_t)8 * (size_t)wins))) return rc;
+    if (halfOk && (rc = ensure(ctx, ctx->d_wstat_h, ctx->wstat_h_cap,
+                                std::max((size_t)8 * (size_t)wins, spectral_statics_floats(wins))))) return rc;
     if (halfOk && (rc = ensure(ctx, ctx->d_lokey, ctx->lokey_cap, (size_t)2 * nf))) return rc;
     if (halfOk && nf)  // key of -inf in both arrays; files without windows keep it (no tile ever writes them)
         SGZ_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ctx->d_lokey), (int)0x807fffff, (size_t)2 * nf,
@@ -1963,7 +1971,8 @@ static int corr_run_impl(sgz_context *ctx, int file_begin, int file_end, int mod
         if (s1 > s0) {
             hipLaunchKernelGGL(window_static_kernel, dim3(s1 - s0), dim3(256), 0, stream, ctx->d_files, ctx->d_tiles + s0,
                                reinterpret_cast<const float4 *>(ctx->d_prefix_h), ctx->d_tbase_h, ctx->cp.L, ctx->numCh,
-                               ctx->cp.prepTileShift, reinterpret_cast<float4 *>(ctx->d_wstat_h));
+                               ctx->cp.prepTileShift, reinterpret_cast<float4 *>(ctx->d_wstat_h),
+                               ctx->fg.N > 0 ? ctx->total_windows : 0ll);
             SGZ_HIP(ctx, hipGetLastError());
         }
         ctx->hc_begin = file_begin;

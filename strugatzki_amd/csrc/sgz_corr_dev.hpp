@@ -239,6 +239,70 @@ __device__ __forceinline__ WindowCoeffs window_coeffs(const CorrParams &cp, cons
     return wc;
 }
 
+// The spectral kernel streams the statics of every window of a block (it is bound by memory traffic), so it
+// keeps them in 20 instead of 32 bytes per window, as four arrays over all windows of the layout
+// (`stride` = the window count rounded up to an even number): 1 / sd of the two channel groups, ln of the average
+// loudness, and four half-precision numbers rounded up, g and u = h + |dm| / sd of both groups.  The mean-offset
+// term of the similarity, (w sum a' / (aStd n)) dm / sd, is not evaluated: a' is centred, so sum a' is what
+// rounding left of zero, and the term's magnitude goes into the error bound instead (it has the same factor as
+// h there); sqrt(1 + (dm / sd)^2) is replaced by its bound 1 + u.
+struct SpectralStatics {
+    const float *rsdT, *rsdS, *lnAvg;
+    const uint2 *gu;  // halves: x = gT | uT << 16, y = gS | uS << 16
+};
+__host__ __device__ inline long long spectral_statics_stride(long long windows) { return (windows + 1) & ~1ll; }
+__host__ __device__ inline size_t spectral_statics_floats(long long windows) { return 5 * (size_t)spectral_statics_stride(windows); }
+__device__ __forceinline__ SpectralStatics spectral_statics(float *base, long long windows)
+{
+    const long long W = spectral_statics_stride(windows);
+    return SpectralStatics{base, base + W, base + 2 * W, reinterpret_cast<const uint2 *>(base + 3 * W)};
+}
+__device__ __forceinline__ void spectral_statics_store(float *base, long long windows, long long w, const WindowStatic &ws)
+{
+    const long long W = spectral_statics_stride(windows);
+    base[w] = ws.rsdT;
+    base[W + w] = ws.rsdS;
+    base[2 * W + w] = ws.lnAvg;
+    float uT = half_from_bits(ws.hTS & 0xffffu) + fabsf(ws.dmT * ws.rsdT);
+    float uS = half_from_bits(ws.hTS >> 16) + fabsf(ws.dmS * ws.rsdS);
+    if (!(uT >= 0.0f)) uT = INFINITY;  // NaN (0 * inf: a window without spread): g is +inf there and decides
+    if (!(uS >= 0.0f)) uS = INFINITY;
+    const float gT = ws.gT >= 0.0f ? ws.gT : INFINITY, gS = ws.gS >= 0.0f ? ws.gS : INFINITY;
+    reinterpret_cast<uint2 *>(base + 3 * W)[w] = make_uint2(half_bits_up(gT) | (half_bits_up(uT * 1.0001f) << 16),
+                                                            half_bits_up(gS) | (half_bits_up(uS * 1.0001f) << 16));
+}
+
+// absT / absS = eta |a'| |x_block| / (aStd n) of the channel group, which times 1 / sd bounds the error of the
+// normalised cross term from the fp32 transforms; relErr covers the fp32 rounding of the target values.
+__device__ __forceinline__ WindowCoeffs window_coeffs_spectral(const CorrParams &cp, float rsdT, float rsdS, float lnAvg,
+                                                               uint2 gu, float relErr, float absT, float absS,
+                                                               float &boostOut)
+{
+    const float nT = (float)cp.L, nS = (float)cp.L * (float)(cp.numCh - 1);
+    const float kLog2e = 1.4426950408889634f;
+    const float boost = __builtin_amdgcn_exp2f(((float)cp.lnAvgIn - lnAvg) * (kLog2e / 0.6f));
+    boostOut = boost;
+    WindowCoeffs wc = {0.0f, 0.0f, 0.0f, 0.0f};  // a gated window: sim = 0 exactly
+    if (boost <= cp.maxBoost * 1.00001f) {
+        float errT = 0.0f, errS = 0.0f;
+        if (cp.w > 0.0f) {
+            const float g = half_from_bits(gu.x & 0xffffu), u = half_from_bits(gu.x >> 16);
+            wc.a = (cp.w / ((float)cp.aStdT * nT)) * rsdT;
+            const float eh = relErr * (1.0f + u) + absT * rsdT;
+            errT = eh + (1.0f + eh) * g + fabsf((float)cp.sumAT) / ((float)cp.aStdT * nT) * u * 1.0001f;
+        }
+        if (cp.w < 1.0f) {
+            const float g = half_from_bits(gu.y & 0xffffu), u = half_from_bits(gu.y >> 16);
+            wc.b = ((1.0f - cp.w) / ((float)cp.aStdS * nS)) * rsdS;
+            const float eh = relErr * (1.0f + u) + absS * rsdS;
+            errS = eh + (1.0f + eh) * g + fabsf((float)cp.sumAS) / ((float)cp.aStdS * nS) * u * 1.0001f;
+        }
+        wc.e = errT * cp.w + errS * (1.0f - cp.w) + 1e-5f;
+        if (boost > cp.maxBoost * 0.99999f) wc.e = -wc.e;  // the exact path may gate this window
+    }
+    return wc;
+}
+
 __device__ __forceinline__ void window_bounds(const WindowCoeffs &wc, float crossT, float crossS, float &upOut,
                                               float &loOut)
 {

@@ -12,7 +12,8 @@
 // image of the matrix-core path), multiplies them with the target's spectra, adds the channels of a group in
 // the frequency domain, and inverts ONE complex transform per block whose real part is the loudness cross term
 // and whose imaginary part the cross term of the other channels.  It is HBM-bound: per block 8 N numCh / 2
-// bytes of spectra, per window 32 bytes of cached statistics in and 12 bytes of bounds out.
+// bytes of spectra, per window 20 bytes of cached statistics in and 8 bytes out (upper bound and boost; the
+// largest lower bound of a file is kept per file).
 //
 // Everything is fp32.  The result is a screening value with a certified error like the matrix-core kernel's:
 // every output of an FFT-based correlation differs from the exact sum by at most eta * |a'| * |x_block|
@@ -183,14 +184,15 @@ __global__ void fft_blknorm_kernel(const float *__restrict__ blksq, int numCh, i
 //   1. per bin j < N / 2: Zt = A_0 X_0, Zs = sum_{c >= 1} A_c X_c (A: conjugated target spectra / N), and the two
 //      Hermitian spectra combined into one, W[j] = Zt + i Zs, W[N - j] = conj(Zt) + i conj(Zs), written to LDS;
 //   2. inverse transform in LDS: w[k] = crossT[k] + i crossS[k];
-//   3. per window the bounds from its cached statics, as in the matrix-core kernel's epilogue.
+//   3. per window the bounds from its cached statics (sgz::SpectralStatics, 20 bytes per window).
 template <int N, int NCH>
 __global__ __launch_bounds__(N / 16) void corr_fft_kernel(const FftBlock *__restrict__ blocks,
                                                           const float2 *__restrict__ spec,
                                                           const float2 *__restrict__ aspec,
                                                           const float2 *__restrict__ tab,
                                                           const float2 *__restrict__ blknorm,
-                                                          const float4 *__restrict__ wstat, CorrParams cp, FftGeom fg,
+                                                          float *__restrict__ wstat, long long totalWindows,
+                                                          CorrParams cp, FftGeom fg,
                                                           float *__restrict__ simOut, float *__restrict__ boostOut,
                                                           int *__restrict__ lokey,
                                                           int *__restrict__ lokeyNext, int *__restrict__ hflags)
@@ -241,14 +243,18 @@ __global__ __launch_bounds__(N / 16) void corr_fft_kernel(const FftBlock *__rest
     cpf.sumAS = fg.sumAS;
     float best = -INFINITY;
     int bad = 0;
+    const SpectralStatics st = spectral_statics(wstat, totalWindows);
     for (int m0 = 0; m0 < 16 && m0 * T < bd.valid; m0 += 4) {
-        float4 ws0[4], ws1[4];
+        float rsdT[4], rsdS[4], lnAvg[4];
+        uint2 gu[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int k = tid + (m0 + u) * T;
             const long long w = bd.win + (k < bd.valid ? k : 0);
-            ws0[u] = wstat[2 * w];
-            ws1[u] = wstat[2 * w + 1];
+            rsdT[u] = st.rsdT[w];
+            rsdS[u] = st.rsdS[w];
+            lnAvg[u] = st.lnAvg[w];
+            gu[u] = st.gu[w];
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -256,10 +262,8 @@ __global__ __launch_bounds__(N / 16) void corr_fft_kernel(const FftBlock *__rest
             if (k < bd.valid) {
                 const float2 y = buf[fft_phys(k)];
                 float sim, lo, boost;
-                WindowStatic ws;
-                ws.rsdT = ws0[u].x, ws.dmT = ws0[u].y, ws.gT = ws0[u].z, ws.lnAvg = ws0[u].w;
-                ws.rsdS = ws1[u].x, ws.dmS = ws1[u].y, ws.gS = ws1[u].z, ws.hTS = __float_as_uint(ws1[u].w);
-                const WindowCoeffs wc = window_coeffs<true>(cpf, ws, fg.relErr, fg.relErr, boost, absT, absS);
+                const WindowCoeffs wc =
+                    window_coeffs_spectral(cpf, rsdT[u], rsdS[u], lnAvg[u], gu[u], fg.relErr, absT, absS, boost);
                 window_bounds(wc, y.x, y.y, sim, lo);
                 boostOut[bd.win + k] = boost;
                 simOut[bd.win + k] = sim;
@@ -494,12 +498,12 @@ int fft_screen_launch(sgz_context *ctx, int file_begin, int file_end, hipStream_
         if (start || stop)
             hipExtLaunchKernelGGL(kern, dim3(b1 - b0), dim3(N / 16), lds, stream, start, stop, 0, ctx->d_fblocks + b0,
                                   ctx->d_spec, ctx->d_aspec, ctx->d_fft_tab, ctx->d_blknorm + b0,
-                                  reinterpret_cast<const float4 *>(ctx->d_wstat_h), ctx->cp, fg, ctx->d_sim, ctx->d_boost,
+                                  ctx->d_wstat_h, ctx->total_windows, ctx->cp, fg, ctx->d_sim, ctx->d_boost,
                                   lokey, lokeyNext, ctx->d_hflags);
         else
             hipLaunchKernelGGL(kern, dim3(b1 - b0), dim3(N / 16), lds, stream, ctx->d_fblocks + b0, ctx->d_spec,
                                ctx->d_aspec, ctx->d_fft_tab, ctx->d_blknorm + b0,
-                               reinterpret_cast<const float4 *>(ctx->d_wstat_h), ctx->cp, fg, ctx->d_sim, ctx->d_boost,
+                               ctx->d_wstat_h, ctx->total_windows, ctx->cp, fg, ctx->d_sim, ctx->d_boost,
                                lokey, lokeyNext, ctx->d_hflags);
         SGZ_HIP(ctx, hipGetLastError());
         return SGZ_OK;
