@@ -425,7 +425,7 @@ def main() -> int:
         is_c3 = (L, total_files) == (2584, 120)
         if spectral:
             roof = spectral_roofline(k_ms, tail_windows, (fft_n, fft_hop, fft_blocks))
-            roof["traffic"] = pmc_traffic_bytes("corr_fft_kernel", "r02_spectral_pmc_summary.csv") if is_c3 else None
+            roof["traffic"] = pmc_traffic_bytes("corr_fft_kernel") if is_c3 else None
         elif mode == "f16":
             roof = matrix_roofline(k_ms, tail_flops)
             roof["traffic"] = pmc_traffic_bytes("corr_mfma_kernel") if is_c3 else None

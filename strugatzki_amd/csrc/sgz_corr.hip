@@ -1026,35 +1026,53 @@ __global__ __launch_bounds__(256) void compact_bounded_kernel(const FileDesc *__
         top = bound_kth_select(lokey, headEnd, topK);
         if (blockIdx.x == 0 && threadIdx.x == 0) topThrOut[0] = top;
     }
-    for (int tile = blockIdx.x; tile < numTiles; tile += gridDim.x) {
-        const TileDesc td = tiles[tile];
-        const FileDesc fd = files[td.file];
-        // (every file this kernel sees holds bounds of a half-precision run: the host checks)
-        if (hflags[td.file] && td.o0 == 0 && threadIdx.x == 0) atomicAdd(count, (unsigned long long)capacity + 1ull);
-        const bool headFile = td.file < headEnd;
-        float t = headFile ? bound_from_key(lokey[td.file]) : tailThr[0];
-        if (headFile) t = fmaxf(t, top);
+    // The descriptors a tile needs hang on one another (tile -> file -> its bound and mark): the tile record is
+    // fetched two rounds ahead and the file's data one round ahead, so that a round waits for its windows only.
+    struct Ahead {
+        long long numWindows, winOff;
+        int file, o0, key, flag;
+    };
+    auto describe = [&](const TileDesc &t) {
+        const FileDesc f = files[t.file];
+        return Ahead{f.num_windows, f.win_off, t.file, t.o0, lokey[t.file], hflags[t.file]};
+    };
+    const int stride = gridDim.x;
+    int tile = blockIdx.x;
+    if (tile >= numTiles) return;
+    Ahead cur = describe(tiles[tile]);
+    TileDesc td2 = tiles[min(tile + stride, numTiles - 1)];
+    const float tail = tailThr[0];
+    for (; tile < numTiles; tile += stride) {
+        const TileDesc td3 = tiles[min(tile + 2 * stride, numTiles - 1)];
         float s[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const long long o = (long long)td.o0 + k * 256 + threadIdx.x;
-            s[k] = o < fd.num_windows ? up[fd.win_off + o] : -INFINITY;
+            const long long o = (long long)cur.o0 + k * 256 + threadIdx.x;
+            s[k] = o < cur.numWindows ? up[cur.winOff + o] : -INFINITY;
         }
+        const Ahead nxt = describe(td2);
+        // (every file this kernel sees holds bounds of a half-precision run: the host checks)
+        if (cur.flag && cur.o0 == 0 && threadIdx.x == 0) atomicAdd(count, (unsigned long long)capacity + 1ull);
+        const bool headFile = cur.file < headEnd;
+        float t = headFile ? bound_from_key(cur.key) : tail;
+        if (headFile) t = fmaxf(t, top);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const long long o = (long long)td.o0 + k * 256 + threadIdx.x;
-            if (o < fd.num_windows && (headFile ? s[k] >= t : s[k] > t)) {
+            const long long o = (long long)cur.o0 + k * 256 + threadIdx.x;
+            if (o < cur.numWindows && (headFile ? s[k] >= t : s[k] > t)) {
                 const unsigned long long slot = atomicAdd(count, 1ull);
                 if ((long long)slot < capacity) {
                     sgz_candidate c;
-                    c.file = td.file;
+                    c.file = cur.file;
                     c.offset = (int)o;
                     c.sim = s[k];
-                    c.boost = boost[fd.win_off + o];
+                    c.boost = boost[cur.winOff + o];
                     out[slot] = c;
                 }
             }
         }
+        cur = nxt;
+        td2 = td3;
     }
 }
 
