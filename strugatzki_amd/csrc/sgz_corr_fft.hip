@@ -69,7 +69,7 @@ __device__ __forceinline__ void untangle(float2 zj, float2 zm, float2 &xa, float
 template <int N>
 __global__ __launch_bounds__(N / 16) void fft_spectra_kernel(const FileDesc *__restrict__ files,
                                                              const FftBlock *__restrict__ blocks, int numPairs,
-                                                             NormParams nrm, int numCh,
+                                                             int numUnits, NormParams nrm, int numCh,
                                                              const float2 *__restrict__ tab, float2 *__restrict__ spec,
                                                              float *__restrict__ blksq)
 {
@@ -77,7 +77,12 @@ __global__ __launch_bounds__(N / 16) void fft_spectra_kernel(const FileDesc *__r
     extern __shared__ __attribute__((aligned(16))) float2 buf[];
     __shared__ float red[16];
     const int tid = threadIdx.x;
-    const int blk = blockIdx.x / numPairs, p = blockIdx.x - blk * numPairs;
+    // The channel pairs of a block read the same interleaved frames: workgroups are dealt to the chip's eight
+    // partitions (each with its own L2) in turn, so the grid is renumbered to give consecutive pairs to one of them.
+    const int perPart = gridDim.x >> 3;  // (the grid is a multiple of 8)
+    const int unit = (blockIdx.x & 7) * perPart + (blockIdx.x >> 3);
+    if (unit >= numUnits) return;
+    const int blk = unit / numPairs, p = unit - blk * numPairs;
     const FftBlock bd = blocks[blk];
     const FileDesc fd = files[bd.file];
     const int c0 = 2 * p, c1 = 2 * p + 1;
@@ -453,8 +458,9 @@ int fft_screen_prepare(sgz_context *ctx, int file_begin, int file_end, hipStream
     int rc = SGZ_OK;
     auto launch = [&](auto kern) -> int {
         if ((rc = set_lds(ctx, kern, lds))) return rc;
-        hipLaunchKernelGGL(kern, dim3((unsigned)(b1 - b0) * numPairs), dim3(N / 16), lds, stream, ctx->d_files,
-                           ctx->d_fblocks + b0, numPairs, ctx->norm, numCh, ctx->d_fft_tab, ctx->d_spec,
+        const int units = (b1 - b0) * numPairs;
+        hipLaunchKernelGGL(kern, dim3((unsigned)((units + 7) & ~7)), dim3(N / 16), lds, stream, ctx->d_files,
+                           ctx->d_fblocks + b0, numPairs, units, ctx->norm, numCh, ctx->d_fft_tab, ctx->d_spec,
                            ctx->d_blksq + (size_t)b0 * numCh);
         SGZ_HIP(ctx, hipGetLastError());
         return SGZ_OK;
