@@ -1841,13 +1841,15 @@ int sgz_corr_set_target(sgz_context *ctx, const float *frames, int num_frames, f
     std::vector<float> apf(ap.size());
     for (size_t i = 0; i < ap.size(); i++) apf[i] = (float)ap[i];
     {  // what the spectral screening needs of the fp32 values: their sums and Euclidean norms per channel group
-        double s[2] = {0.0, 0.0}, q[2] = {0.0, 0.0};
+        double s[2] = {0.0, 0.0}, q[2] = {0.0, 0.0}, q1 = 0.0;
         for (int c = 0; c < numCh; c++)
             for (int i = 0; i < L; i++) {
                 const double v = (double)apf[(size_t)c * Lpad + i];
                 s[c > 0] += v;
                 q[c > 0] += v * v;
+                if (c == 1) q1 += v * v;
             }
+        ctx->tgt_nrm1 = std::sqrt(q1);
         ctx->tgt_sumT = s[0];
         ctx->tgt_sumS = s[1];
         ctx->tgt_nrmT = std::sqrt(q[0]);

@@ -15,14 +15,24 @@
 // bytes of spectra, per window 20 bytes of cached statistics in and 8 bytes out (upper bound and boost; the
 // largest lower bound of a file is kept per file).
 //
-// Everything is fp32.  The result is a screening value with a certified error like the matrix-core kernel's:
-// every output of an FFT-based correlation differs from the exact sum by at most eta * |a'| * |x_block|
-// (Euclidean norms over the channel group; each output is an inner product of the spectra evaluated through a
-// butterfly tree, every path of which carries (1 + delta)^depth - 1, and sum |A_j X_j| / N <= |a'| |x| by
-// Cauchy-Schwarz and Parseval; the forward transforms add the same again through their norm-wise bounds).
-// eta (fft_eta): three transforms of `passes` passes at 40 roundings each (table-derived twiddle <= 10 ulp, its
-// product, four butterfly levels with their inner factors), the channel sums, the rounding of the operands.
-// At N = 16384, L = 2584 that is 5e-5 of the similarity where half-precision products give 1e-3.
+// Everything is fp32.  The result is a screening value with a certified error like the matrix-core kernel's.
+// A transform of `passes` passes is taken to be accurate to eps = (1 + 40 u)^passes - 1 of its input's norm (per
+// pass: a table-derived twiddle <= 10 ulp, its product, four butterfly levels with their inner factors; every output
+// is an inner product evaluated through a butterfly tree, every path of which carries that factor).  Two things
+// make the bound of a cross term more than eps |a'| |x|:
+//   * transforms are PACKED -- two real channels per forward transform, the two channel groups' cross terms as real
+//     and imaginary part of the inverse one -- and a complex transform's rounding errors are relative to the norm of
+//     the whole complex sequence: the partner's energy leaks in.  Forward: the spectrum of channel c is off by
+//     eps sqrt(N) |(x_c, x_partner)|; through sum_j |A_j dX_j| / N <= |a'| |dx| (Cauchy-Schwarz, Parseval) the
+//     loudness term gets eps (|a_01| |x_T| + |a_T| |x_01|) and the other channels' term
+//     eps (|a_P| |x_S| + |a_S| |x_P|), with 01 = channels 0 and 1 together and P^2 = T^2 + 2 S^2 (every other channel
+//     counted with its partner).  Inverse: both outputs get eps (sum |Zt| + beta sum |Zs|) / N
+//     <= eps (|a_T| |x_T| + beta |a_S| |x_S|), the imaginary one divided by beta again;
+//   * so the kernel BALANCES the two parts of the inverse transform: Zs is scaled by beta = |a_T||x_T| / (|a_S||x_S|)
+//     (per block, from the block's norms) before it is packed, and the imaginary output divided by it.  Each cross
+//     term's inverse-transform error is then 2 eps of its own norm product, whatever the other group's energy.
+// Plus the roundings outside the transforms (operands, products, channel sums, the scaling).  At N = 16384, L = 2584
+// the bound comes to about 1e-4 of the similarity where half-precision products give 1e-3.
 #include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 
@@ -174,15 +184,18 @@ __global__ __launch_bounds__(N / 16) void fft_target_kernel(const float *__restr
     }
 }
 
-// Euclidean norms of a block's loudness channel and of its other channels, rounded up.
-__global__ void fft_blknorm_kernel(const float *__restrict__ blksq, int numCh, int nblocks, float2 *__restrict__ blknorm)
+// Euclidean norms of a block, rounded up: loudness channel, the other channels, channels 0 and 1 together,
+// sqrt(|x_T|^2 + 2 |x_S|^2).
+__global__ void fft_blknorm_kernel(const float *__restrict__ blksq, int numCh, int nblocks, float4 *__restrict__ blknorm)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nblocks) return;
     const float *sq = blksq + (size_t)b * numCh;
     float s = 0.0f;
     for (int c = 1; c < numCh; c++) s += sq[c];
-    blknorm[b] = make_float2(sqrtf(sq[0]) * 1.0001f, sqrtf(s) * 1.0001f);
+    const float s1 = numCh > 1 ? sq[1] : 0.0f;
+    blknorm[b] = make_float4(sqrtf(sq[0]) * 1.0001f, sqrtf(s) * 1.0001f, sqrtf(sq[0] + s1) * 1.0001f,
+                             sqrtf(sq[0] + 2.0f * s) * 1.0001f);
 }
 
 // corr_fft_kernel: workgroup = one block of N frames, N / 16 threads.
@@ -195,7 +208,7 @@ __global__ __launch_bounds__(N / 16) void corr_fft_kernel(const FftBlock *__rest
                                                           const float2 *__restrict__ spec,
                                                           const float2 *__restrict__ aspec,
                                                           const float2 *__restrict__ tab,
-                                                          const float2 *__restrict__ blknorm,
+                                                          const float4 *__restrict__ blknorm,
                                                           float *__restrict__ wstat, long long totalWindows,
                                                           CorrParams cp, FftGeom fg,
                                                           float *__restrict__ simOut, float *__restrict__ boostOut,
@@ -210,6 +223,14 @@ __global__ __launch_bounds__(N / 16) void corr_fft_kernel(const FftBlock *__rest
     const FftBlock bd = blocks[blockIdx.x];
     const int numCh = NCH ? NCH : cp.numCh;
     const float2 *xs = spec + bd.spec;
+    // the factor that balances the two parts of the packed inverse transform, and the block's error terms
+    const float4 bn = blknorm[blockIdx.x];
+    const float pT = fg.aT * bn.x, pS = fg.aS * bn.y;  // |a'| |x_block| of the two channel groups
+    float beta = pT / pS;
+    if (!(beta >= 2.4414062e-4f && beta <= 4096.0f)) beta = beta > 4096.0f ? 4096.0f : (beta < 2.4414062e-4f ? 2.4414062e-4f : 1.0f);
+    const float rbeta = 1.0f / beta;
+    const float absT = (fg.epsT * (fg.a01 * bn.x + fg.aT * bn.z + pT + beta * pS) + fg.epsUT * pT) * 1.0001f * fg.kT;
+    const float absS = (fg.epsT * (fg.aP * bn.y + fg.aS * bn.w + pT * rbeta * 1.0001f + pS) + fg.epsUS * pS) * 1.0001f * fg.kS;
 
 #pragma unroll 2
     for (int m = 0; m < 8; m++) {
@@ -224,6 +245,8 @@ __global__ __launch_bounds__(N / 16) void corr_fft_kernel(const FftBlock *__rest
             zs.y = fmaf(a.x, x.y, zs.y);
             zs.y = fmaf(a.y, x.x, zs.y);
         }
+        zs.x *= beta;
+        zs.y *= beta;
         buf[fft_phys((N - j) & (N - 1))] = make_float2(zt.x + zs.y, zs.x - zt.y);
         buf[fft_phys(j)] = make_float2(zt.x - zs.y, zt.y + zs.x);
     }
@@ -235,14 +258,12 @@ __global__ __launch_bounds__(N / 16) void corr_fft_kernel(const FftBlock *__rest
             zs.x = fmaf(a.x, x.x, zs.x);
             zs.y = fmaf(a.y, x.y, zs.y);
         }
-        buf[fft_phys(0)] = make_float2(zt.x, zs.x);
-        buf[fft_phys(NH)] = make_float2(zt.y, zs.y);
+        buf[fft_phys(0)] = make_float2(zt.x, zs.x * beta);
+        buf[fft_phys(NH)] = make_float2(zt.y, zs.y * beta);
     }
     __syncthreads();
     fft_lds<N, 1>(buf, tab, tid);
 
-    const float2 bn = blknorm[blockIdx.x];
-    const float absT = fg.etaT * bn.x, absS = fg.etaS * bn.y;
     CorrParams cpf = cp;  // the statistics of the fp32 target values
     cpf.sumAT = fg.sumAT;
     cpf.sumAS = fg.sumAS;
@@ -269,7 +290,7 @@ __global__ __launch_bounds__(N / 16) void corr_fft_kernel(const FftBlock *__rest
                 float sim, lo, boost;
                 const WindowCoeffs wc =
                     window_coeffs_spectral(cpf, rsdT[u], rsdS[u], lnAvg[u], gu[u], fg.relErr, absT, absS, boost);
-                window_bounds(wc, y.x, y.y, sim, lo);
+                window_bounds(wc, y.x, y.y * rbeta, sim, lo);
                 boostOut[bd.win + k] = boost;
                 simOut[bd.win + k] = sim;
                 best = fmaxf(best, lo);
@@ -300,13 +321,12 @@ __global__ __launch_bounds__(N / 16) void corr_fft_kernel(const FftBlock *__rest
     }
 }
 
-// eta of the header comment for a transform of N points and a group of `channels` channels.
-double fft_eta(int N, int channels)
+// eps of the header comment for a transform of N points.
+double fft_eps(int N)
 {
     const double u = std::ldexp(1.0, -24);
     const int passes = N > 4096 ? 4 : 3;
-    const double epsFft = std::expm1(passes * std::log1p(40.0 * u));
-    return (3.0 * epsFft + (channels + 8.0) * 3.0 * u) * 1.01;
+    return std::expm1(passes * std::log1p(40.0 * u)) * 1.01;
 }
 
 template <typename K>
@@ -353,9 +373,17 @@ int fft_target(sgz_context *ctx, hipStream_t stream)
     const double nT = (double)L, nS = (double)L * (numCh - 1);
     fg.sumAT = ctx->tgt_sumT;
     fg.sumAS = ctx->tgt_sumS;
-    // |a'| / (aStd n): about 1 / sqrt(n); a target without spread gives inf / NaN, like its similarities
-    fg.etaT = (float)(fft_eta(N, 1) * ctx->tgt_nrmT / (ctx->cp.aStdT * nT) * 1.0001);
-    fg.etaS = numCh > 1 ? (float)(fft_eta(N, numCh - 1) * ctx->tgt_nrmS / (ctx->cp.aStdS * nS) * 1.0001) : 0.0f;
+    // (a target without spread gives inf / NaN factors, like its similarities)
+    const double u = std::ldexp(1.0, -24), up = 1.0001;
+    fg.epsT = (float)(fft_eps(N) * up);
+    fg.epsUT = (float)((1 + 8) * 3.0 * u * up);            // operand roundings, products, the untangling
+    fg.epsUS = (float)((numCh - 1 + 10) * 3.0 * u * up);   // the same, the channel sums and the scaling by beta
+    fg.aT = (float)(ctx->tgt_nrmT * up);
+    fg.aS = (float)(ctx->tgt_nrmS * up);
+    fg.a01 = (float)(std::sqrt(ctx->tgt_nrmT * ctx->tgt_nrmT + ctx->tgt_nrm1 * ctx->tgt_nrm1) * up);
+    fg.aP = (float)(std::sqrt(ctx->tgt_nrmT * ctx->tgt_nrmT + 2.0 * ctx->tgt_nrmS * ctx->tgt_nrmS) * up);
+    fg.kT = (float)(up / (ctx->cp.aStdT * nT));
+    fg.kS = numCh > 1 ? (float)(up / (ctx->cp.aStdS * nS)) : 0.0f;
     fg.relErr = (float)std::ldexp(1.0, -22);
     ctx->aspec_dirty = false;
     return SGZ_OK;

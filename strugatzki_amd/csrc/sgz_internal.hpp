@@ -98,9 +98,14 @@ struct HalfGeom {
 struct FftGeom {
     int N;      // transform length (0: spectral screening is not in use for this layout)
     int hop;    // windows per block: N - L + 1
-    // error of a cross term of the channel group, relative to |a'| |x_block| (both Euclidean norms), times
-    // |a'| / (aStd n): multiplied by the block's norm and 1 / sd of the window it bounds the normalised term
-    float etaT, etaS;
+    // What the kernel needs to bound the error of a block's cross terms (it combines them with the block's norms):
+    // epsT: norm-wise relative error of one transform (forward or inverse); epsUT / epsUS: the roundings outside the
+    // transforms (operands, products, channel sums); Euclidean norms of the fp32 target values -- loudness channel,
+    // other channels, channels 0 and 1 together (they share a packed transform), sqrt(|a_T|^2 + 2 |a_S|^2) (an upper
+    // bound of the norm over all packed pairs an other channel sits in) -- each rounded up; kT / kS = 1 / (aStd n).
+    float epsT, epsUT, epsUS;
+    float aT, aS, a01, aP;
+    float kT, kS;
     float relErr;          // fp32 rounding of the target values, relative to |a'| |x_window|
     double sumAT, sumAS;   // sums of the fp32 target values
 };
@@ -216,12 +221,13 @@ struct sgz_context {
     float2 *d_fft_tab = nullptr;             // (cos, sin)(2 pi j / kFftTab)
     float *d_blksq = nullptr;                // [block][numCh] sum of squares of the block's centred values
     size_t blksq_cap = 0;
-    float2 *d_blknorm = nullptr;             // per block: Euclidean norm of the loudness channel, of the others
+    float4 *d_blknorm = nullptr;             // per block, Euclidean norms: loudness channel, the others, channels 0 and 1,
+                                             // sqrt(|x_T|^2 + 2 |x_S|^2)
     size_t blknorm_cap = 0;
     bool aspec_dirty = true;
     int fc_begin = 0, fc_end = 0;            // files whose spectra are current
     double tgt_sumT = 0.0, tgt_sumS = 0.0;   // sums and Euclidean norms of the fp32 target values
-    double tgt_nrmT = 0.0, tgt_nrmS = 0.0;
+    double tgt_nrmT = 0.0, tgt_nrmS = 0.0, tgt_nrm1 = 0.0;  // (nrm1: channel 1 alone)
     float *d_thr = nullptr;                  // smallest of the head files' bounds (filter of the tail files)
     size_t thr_cap = 0;
     sgz_candidate *h_pinned = nullptr;       // pinned staging of the first candidate transfer

@@ -17,6 +17,15 @@ def test_random_configurations_match_the_oracle(ctx, seed):
     assert fuzz_parity.run(120, seed, ctx=ctx) == 0
 
 
+@pytest.mark.parametrize("seed", [13])
+def test_random_configurations_with_either_screening_kernel(ctx, seed):
+    """The same sweep with the screening kernel drawn per case (spectral with each transform length, matrix cores,
+    the library's choice), and the kernel's upper bounds checked against the oracle's dense similarities."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_parity
+    assert fuzz_parity.run(150, seed, ctx=ctx, kernels=True) == 0
+
+
 @pytest.mark.parametrize("seed", [21])
 def test_random_punch_out_searches_match_the_oracle(ctx, seed):
     """Punch-in / punch-out: random spans, gaps, punch ranges, files that the punch-in pass sees shorter than its

@@ -1,5 +1,7 @@
 """Random search configurations on the GPU against the oracle: match list (file, span) identical, similarities
-within one fp32 ulp.  usage: fuzz_parity.py [--big] [cases] [seed]"""
+within one fp32 ulp.  usage: fuzz_parity.py [--big] [--kernels] [cases] [seed]
+--kernels: every case also draws the screening kernel (library's choice, spectral with a random transform length,
+matrix cores) and, where the oracle's dense run is cheap, checks that the kernel's upper bounds enclose it."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -9,25 +11,35 @@ from common import STEP, O, corr_config, make_plants, norms_default, synth_db, s
 import strugatzki_amd as S
 
 BIG = False  # long targets and files of several kernel tiles (slow on the oracle's side: few cases)
+KERNELS = False  # draw the screening kernel per case
 
 
-def run(cases: int, seed: int, ctx=None, verbose=True) -> int:
+def run(cases: int, seed: int, ctx=None, verbose=True, kernels=None) -> int:
     """Runs `cases` random configurations; returns the number of mismatches."""
     rng = np.random.default_rng(seed)
     own = ctx is None
     if own:
         ctx = S.Context(0)
+    draw = KERNELS if kernels is None else kernels
+    saved = {k: os.environ.pop(k, None) for k in ("SGZ_FFT_N", "SGZ_SCREEN_KERNEL")}
     bad = 0
-    for case in range(cases):
-        bad += 0 if _one_case(ctx, rng, case, verbose) else 1
-        if verbose and case % 20 == 19:
-            print(f"{case + 1} cases, {bad} mismatches so far", flush=True)
+    try:
+        for case in range(cases):
+            bad += 0 if _one_case(ctx, rng, case, verbose, draw) else 1
+            if verbose and case % 20 == 19:
+                print(f"{case + 1} cases, {bad} mismatches so far", flush=True)
+    finally:
+        os.environ.pop("SGZ_FFT_N", None)
+        for k, v in saved.items():
+            if v is not None:
+                os.environ[k] = v
+        ctx.set_screen_kernel("auto")
     if own:
         ctx.close()
     return bad
 
 
-def _one_case(ctx, rng, case, verbose) -> bool:
+def _one_case(ctx, rng, case, verbose, draw_kernel=False) -> bool:
     num_ch = int(rng.choice([2, 5, 14, 14, 14, 21, 64]))
     L = int(rng.choice([431, 700, 1000, 2584] if BIG else [1, 2, 3, 16, 17, 40, 96, 150, 431, 700]))
     nf = int(rng.integers(1, 9))
@@ -62,12 +74,35 @@ def _one_case(ctx, rng, case, verbose) -> bool:
     norms = norms_default(num_ch) if normalize else None
     cfg = corr_config(ts, L, weight=weight, normalize=normalize, max_boost=max_boost, num_matches=num_matches,
                       num_per_file=num_per_file, min_spacing=min_spacing, num_ch=num_ch)
-    want, _, _ = O.correlation_run(cfg, tgt, norms, db, dense=False)
+    kern, fft_n = "auto", 0
+    if draw_kernel:
+        kern = str(rng.choice(["auto", "spectral", "spectral", "matrix"]))
+        fft_n = int(rng.choice([4096, 8192, 16384]))
+        os.environ.pop("SGZ_FFT_N", None)
+        if kern == "spectral" and fft_n > L:
+            os.environ["SGZ_FFT_N"] = str(fft_n)
+        ctx.set_screen_kernel(kern)
+    windows = sum(max(f - L + 1, 1) for f in frames)
+    dense = draw_kernel and windows * L * num_ch < 3e8
+    want, sims, boosts = O.correlation_run(cfg, tgt, norms, db, dense=dense)
     ctx.db_reset(num_ch)
     for f in db:
         ctx.db_add_file(f)
     ctx.set_norms(norms)
     ctx.corr_set_target(tgt[ts:ts + L], weight, max_boost)
+    if dense and ctx.screen_f16_available:
+        # the screening kernel's value is never below the oracle's similarity where the boost gate is open
+        ctx.corr_run_screen_f16(0, nf)
+        for f in range(nf):
+            gs, _ = ctx.corr_read_dense(f)
+            open_ = np.isfinite(sims[f]) & (boosts[f] <= max_boost * (1 - 1e-4))
+            d = gs.astype(np.float64)[open_] - sims[f][open_]
+            if d.size and not np.all(d >= 0.0):
+                if verbose:
+                    print(f"BOUND BELOW ORACLE case {case}: file {f} by {d.min():.3e} kern={kern} n={fft_n} "
+                          f"in use {ctx.screen_kernel_in_use} {ctx.screen_geometry} ch={num_ch} L={L} frames={frames} "
+                          f"w={weight} norm={normalize}", flush=True)
+                return False
     p = S.SearchParams(num_matches, num_per_file, min_spacing, STEP, screen=mode != "none",
                        screen_mode="auto" if mode == "none" else mode)
     got = S.search(ctx, p)
@@ -76,7 +111,7 @@ def _one_case(ctx, rng, case, verbose) -> bool:
                     for g, w in zip(got, want))
     if not ok and verbose:
         print(f"MISMATCH case {case}: ch={num_ch} L={L} frames={frames} ts={ts} nm={num_matches} npf={num_per_file} "
-              f"sp={min_spacing} w={weight} mb={max_boost} norm={normalize} mode={mode}", flush=True)
+              f"sp={min_spacing} w={weight} mb={max_boost} norm={normalize} mode={mode} kern={kern} n={fft_n}", flush=True)
         print("  got ", [(g.file, g.start, round(g.sim, 7)) for g in got], flush=True)
         print("  want", [(w.file, w.start, round(w.sim, 7)) for w in want], flush=True)
     return ok
@@ -86,6 +121,9 @@ if __name__ == "__main__":
     if "--big" in sys.argv:
         sys.argv.remove("--big")
         BIG = True
+    if "--kernels" in sys.argv:
+        sys.argv.remove("--kernels")
+        KERNELS = True
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     bad = run(n, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     print(f"{n} cases, {bad} mismatches", flush=True)
