@@ -28,3 +28,15 @@ def ctx():
     c = S.Context(0)
     yield c
     c.close()
+
+
+@pytest.fixture(params=["auto", "spectral"])
+def screen_kernel_env(request, monkeypatch):
+    """Runs a test twice: with the library's own choice of screening kernel (the matrix cores for the short targets
+    most tests use) and with the spectral kernel forced through the environment, which child processes inherit."""
+    monkeypatch.delenv("SGZ_FFT_N", raising=False)
+    if request.param == "spectral":
+        monkeypatch.setenv("SGZ_SCREEN_KERNEL", "spectral")
+    else:
+        monkeypatch.delenv("SGZ_SCREEN_KERNEL", raising=False)
+    return request.param

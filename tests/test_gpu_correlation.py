@@ -426,7 +426,7 @@ def test_bounds_hold_on_awkward_data(ctx, case):
     assert [(g.file, g.start, g.stop) for g in got] == [(w.file, w.start, w.stop) for w in want]
 
 
-def test_compact_top_leaves_out_files_below_the_kth_bound(ctx):
+def test_compact_top_leaves_out_files_below_the_kth_bound(ctx, screen_kernel_env):
     """sgz_corr_compact_top: T = the num_top-th largest per-file lower bound; only files that can reach it are
     collected (a subset of sgz_corr_compact_bounded's records, exactly re-scored), and the replay over them
     (sgz_sel_feed_top) gives the reference's matches.  More num_top than files: nothing is left out."""
@@ -482,7 +482,7 @@ def test_compact_top_with_more_files_than_one_selection_round_holds(ctx):
 
 
 @pytest.mark.parametrize("case", ["duplicate_head_files", "short_head_file", "single_file", "fewer_files_than_matches"])
-def test_search_over_bounds_and_its_fallbacks(ctx, case):
+def test_search_over_bounds_and_its_fallbacks(ctx, case, screen_kernel_env):
     """numPerFile = 1 with f16 screening searches over bounds; cases it cannot decide go to the exact path."""
     import strugatzki_amd as S
     L, ts, nf, frames = 96, 17, 12, 900
@@ -552,7 +552,7 @@ def test_search_sharded_single_rank_rccl(mode):
 
 
 @pytest.mark.parametrize("mode", ["bounds", "general", "exact", "headbounds", "nan"])
-def test_search_sharded_two_ranks_on_one_gpu(mode):
+def test_search_sharded_two_ranks_on_one_gpu(mode, screen_kernel_env):
     """Two ranks (two processes sharing the one GPU of the box, gloo for the exchange): both end with the
     single-process result, with and without replicated head files ("headbounds": replicated head files in the
     search over bounds, whose windows every rank reports), and over a database with constant stretches
@@ -571,7 +571,7 @@ def test_search_sharded_two_ranks_on_one_gpu(mode):
 
 
 @pytest.mark.parametrize("world,seed", [(2, 5), (3, 6)])
-def test_search_sharded_random_cases(world, seed):
+def test_search_sharded_random_cases(world, seed, screen_kernel_env):
     """Random databases, parameters and ways of sharding (search over bounds, replicated head files, exact),
     ranks without any file among them: every rank's result equals the oracle's."""
     outs = _run_ranks("fuzz", world, "gloo", extra=(40, seed))
@@ -622,7 +622,7 @@ def test_search_falls_back_to_dense_on_candidate_overflow(ctx):
     assert [(g.file, g.start, g.stop) for g in got] == [(w.file, w.start, w.stop) for w in want]
 
 
-def test_smaller_database_after_a_larger_one_with_unscreenable_file(ctx):
+def test_smaller_database_after_a_larger_one_with_unscreenable_file(ctx, screen_kernel_env):
     """A file the half-precision screening cannot handle (a constant stretch: NaN windows) is reported through the
     candidate count, without candidate records.  The re-scoring that follows must not read the slots of the
     candidate buffer, which still hold records of the earlier, larger database (file indices and frame pointers

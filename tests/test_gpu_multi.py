@@ -34,7 +34,7 @@ def _same(got, want, tol=1e-5):
 
 @pytest.mark.parametrize("num_ctx", [1, 2, 3])
 @pytest.mark.parametrize("num_matches,num_per_file,min_spacing", [(5, 1, 0), (6, 2, 30 * STEP), (3, 1, 0)])
-def test_multi_context_search_equals_the_oracle(num_ctx, num_matches, num_per_file, min_spacing):
+def test_multi_context_search_equals_the_oracle(num_ctx, num_matches, num_per_file, min_spacing, screen_kernel_env):
     import strugatzki_amd as S
     L, ts, nf, frames = 96, 17, 13, 900
     db = synth_db(nf, frames, make_plants(5, L, nf, frames, ts))
@@ -52,7 +52,7 @@ def test_multi_context_search_equals_the_oracle(num_ctx, num_matches, num_per_fi
 
 
 @pytest.mark.parametrize("num_ctx", [1, 2, 4])
-def test_multi_context_search_with_files_shorter_than_the_target(num_ctx):
+def test_multi_context_search_with_files_shorter_than_the_target(num_ctx, screen_kernel_env):
     """Short files see the ring of the single loop over ALL files: their stale frames come from files that live
     in other contexts.  Also a file that starts with a constant stretch (NaN similarities) and an empty file."""
     import strugatzki_amd as S

@@ -46,7 +46,7 @@ def _make_db(tmp_path, nf=8, frames=700, L=64, ts=11, nplants=3):
 
 
 @pytest.mark.parametrize("num_matches,num_per_file,min_spacing", [(5, 1, 0), (6, 2, 30 * STEP)])
-def test_feature_correlation_from_files(ctx, tmp_path, num_matches, num_per_file, min_spacing):
+def test_feature_correlation_from_files(ctx, tmp_path, num_matches, num_per_file, min_spacing, screen_kernel_env):
     L, ts = 64, 11
     db_dir, in_meta, db, tgt, norms, plants = _make_db(tmp_path, L=L, ts=ts)
     cfg = FeatureCorrelation.Config(db_dir, in_meta, FeatureCorrelation.Punch(Span(ts * STEP, (ts + L) * STEP), 0.5),
@@ -63,7 +63,7 @@ def test_feature_correlation_from_files(ctx, tmp_path, num_matches, num_per_file
     assert seen and seen[-1] == 1.0 and seen == sorted(seen)
 
 
-def test_feature_correlation_keeps_the_database_resident_and_runs_on_several_contexts(tmp_path):
+def test_feature_correlation_keeps_the_database_resident_and_runs_on_several_contexts(tmp_path, screen_kernel_env):
     """A second query against the same folder finds the files on the GPU (no per-file progress of a load); touching
     a file loads again.  Two and three contexts (files dealt round robin) return the single-context list."""
     import strugatzki_amd as S
