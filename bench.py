@@ -401,9 +401,10 @@ def main() -> int:
         def spectral_roofline(kms, windows, geom):
             n, hop, blocks = geom
             ach = windows * 64.0 / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
-            # what the kernel is built to move: the blocks' spectra, 20 B of cached statistics per window in,
-            # upper bound and boost (8 B) per window out
-            moved = blocks * 4.0 * NUM_CH * n + windows * (20.0 + 8.0)
+            # what the kernel is built to move: the blocks' spectra, 16 B of cached statistics per window in (20 B in
+            # blocks where some window's boost comes near maxBoost: none in this workload), the upper bound (4 B)
+            # per window out
+            moved = blocks * 4.0 * NUM_CH * n + windows * (16.0 + 4.0)
             return {
                 "bound": "hbm", "kernel": "corr_fft_kernel", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "frac": ach / PEAK_HBM_GBS,

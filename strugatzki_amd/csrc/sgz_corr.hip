@@ -896,7 +896,8 @@ __global__ __launch_bounds__(256) void compact_kernel(const FileDesc *__restrict
                                                       sgz_candidate *__restrict__ out, long long capacity,
                                                       unsigned long long *__restrict__ count,
                                                       const int *__restrict__ hflags, int flagBegin, int flagEnd,
-                                                      unsigned long long *__restrict__ zeroOther)
+                                                      unsigned long long *__restrict__ zeroOther,
+                                                      const float *__restrict__ lnAvgLazy, float lnAvgIn)
 {
     const TileDesc td = tiles[blockIdx.x];
     const FileDesc fd = files[td.file];
@@ -920,7 +921,8 @@ __global__ __launch_bounds__(256) void compact_kernel(const FileDesc *__restrict
                     c.file = td.file;
                     c.offset = (int)o;
                     c.sim = s;
-                    c.boost = boost[fd.win_off + o];
+                    // (boosts the spectral kernel left implicit are evaluated here, as that kernel would have)
+                    c.boost = lnAvgLazy ? screen_boost(lnAvgIn, lnAvgLazy[fd.win_off + o]) : boost[fd.win_off + o];
                     out[slot] = c;
                 }
             }
@@ -1018,7 +1020,8 @@ __global__ __launch_bounds__(256) void compact_bounded_kernel(const FileDesc *__
                                                               unsigned long long *__restrict__ count,
                                                               const int *__restrict__ hflags,
                                                               unsigned long long *__restrict__ zeroOther, int topK,
-                                                              float *__restrict__ topThrOut)
+                                                              float *__restrict__ topThrOut,
+                                                              const float *__restrict__ lnAvgLazy, float lnAvgIn)
 {
     if (zeroOther && blockIdx.x == 0 && threadIdx.x == 0) *zeroOther = 0ull;
     float top = -INFINITY;
@@ -1066,7 +1069,7 @@ __global__ __launch_bounds__(256) void compact_bounded_kernel(const FileDesc *__
                     c.file = cur.file;
                     c.offset = (int)o;
                     c.sim = s[k];
-                    c.boost = boost[cur.winOff + o];
+                    c.boost = lnAvgLazy ? screen_boost(lnAvgIn, lnAvgLazy[cur.winOff + o]) : boost[cur.winOff + o];
                     out[slot] = c;
                 }
             }
@@ -1489,6 +1492,7 @@ int build_layout(sgz_context *ctx)
     if ((rc = ensure(ctx, ctx->d_hflags, ctx->hflags_cap, (size_t)nf))) return rc;
     if (nf) SGZ_HIP(ctx, hipMemsetAsync(ctx->d_hflags, 0, sizeof(int) * nf, ctx->stream));
     ctx->hc_begin = ctx->hc_end = 0;  // no half-precision preparation of this layout yet
+    ctx->boost_lazy.assign((size_t)nf, 0);
     ctx->prefetch_valid = false;
     if (halfOk) {
         if ((rc = ensure(ctx, ctx->d_prefix_h, ctx->prefix_h_cap, (size_t)prefix))) return rc;
@@ -2044,6 +2048,8 @@ static int corr_run_impl(sgz_context *ctx, int file_begin, int file_end, int mod
         ctx->ev_valid = true;
         ctx->ev_runs++;
     }
+    if (!spectral)  // every other kernel writes the boosts of its windows
+        for (int f = file_begin; f < file_end && f < (int)ctx->boost_lazy.size(); f++) ctx->boost_lazy[(size_t)f] = 0;
     if (half) {
         ctx->lo_begin = file_begin;
         ctx->lo_end = file_end;
@@ -2116,6 +2122,10 @@ int sgz_corr_prefetch_dense(sgz_context *ctx, int file_begin, int file_end)
     const long long w0 = ctx->h_files[file_begin].win_off;
     const long long w1 = ctx->h_files[file_end - 1].win_off + ctx->h_files[file_end - 1].num_windows;
     if (!dense_staging(ctx, (size_t)(w1 - w0))) return SGZ_OK;  // too large: the read will copy the plain way
+    {
+        const int brc = boost_materialize(ctx, file_begin, file_end, ctx->stream);
+        if (brc) return brc;
+    }
     bool covered = false;
     for (auto &run : ctx->runs)
         if (run.fb < file_end && run.fe > file_begin) {
@@ -2157,6 +2167,13 @@ int sgz_corr_read_dense_range(sgz_context *ctx, int file_begin, int file_end, fl
         }
     }
     if (!covered) return ctx->fail(SGZ_E_STATE, "sgz_corr_run has not covered these files");
+    if (boost_out && !(ctx->prefetch_valid && ctx->prefetch_fb == file_begin && ctx->prefetch_fe == file_end)) {
+        // boosts the spectral kernel left implicit (the copies below run on another stream)
+        bool filled = false;
+        const int brc = boost_materialize(ctx, file_begin, file_end, ctx->stream, &filled);
+        if (brc) return brc;
+        if (filled) SGZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
     const long long w0 = ctx->h_files[file_begin].win_off;
     const long long w1 = ctx->h_files[file_end - 1].win_off + ctx->h_files[file_end - 1].num_windows;
     const size_t count = (size_t)(w1 - w0), bytes = sizeof(float) * count;
@@ -2230,9 +2247,13 @@ static int compact_device_impl(sgz_context *ctx, int file_begin, int file_end, f
     const int t0 = ctx->tile_begin[file_begin], t1 = ctx->tile_begin[file_end];
     if (launched) *launched = t1 > t0;
     if (t1 > t0) {
+        const float *lnAvgLazy = nullptr;
+        int brc;
+        if ((brc = boost_source(ctx, file_begin, file_end, ctx->stream, &lnAvgLazy))) return brc;
         hipLaunchKernelGGL(compact_kernel, dim3(t1 - t0), dim3(256), 0, ctx->stream, ctx->d_files,
                            ctx->d_tiles + t0, ctx->d_sim, ctx->d_boost, threshold, device_out,
-                           (long long)capacity, device_count, ctx->d_hflags, ctx->hc_begin, ctx->hc_end, zero_other);
+                           (long long)capacity, device_count, ctx->d_hflags, ctx->hc_begin, ctx->hc_end, zero_other,
+                           lnAvgLazy, (float)ctx->cp.lnAvgIn);
         SGZ_HIP(ctx, hipGetLastError());
     }
     return SGZ_OK;
@@ -2282,9 +2303,12 @@ static int compact_bounded_device_impl(sgz_context *ctx, int file_begin, int fil
         int cus = 256;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
         const int grid = std::max(1, std::min((t1 - t0 + 3) / 4, 8 * cus));
+        const float *lnAvgLazy = nullptr;
+        if ((rc = boost_source(ctx, file_begin, file_end, ctx->stream, &lnAvgLazy))) return rc;
         hipLaunchKernelGGL(compact_bounded_kernel, dim3(grid), dim3(256), 0, ctx->stream, ctx->d_files,
                            ctx->d_tiles + t0, t1 - t0, ctx->d_sim, ctx->d_boost, ctx->lokey_cur, ctx->d_thr, head_end,
-                           device_out, (long long)capacity, device_count, ctx->d_hflags, zero_other, top_k, topThr);
+                           device_out, (long long)capacity, device_count, ctx->d_hflags, zero_other, top_k, topThr,
+                           lnAvgLazy, (float)ctx->cp.lnAvgIn);
         SGZ_HIP(ctx, hipGetLastError());
     } else if (top_k > 0) {
         hipLaunchKernelGGL(bound_kth_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->lokey_cur, head_end, top_k, topThr);

@@ -274,16 +274,27 @@ __device__ __forceinline__ void spectral_statics_store(float *base, long long wi
 
 // absT / absS = eta |a'| |x_block| / (aStd n) of the channel group, which times 1 / sd bounds the error of the
 // normalised cross term from the fp32 transforms; relErr covers the fp32 rounding of the target values.
-__device__ __forceinline__ WindowCoeffs window_coeffs_spectral(const CorrParams &cp, float rsdT, float rsdS, float lnAvg,
-                                                               uint2 gu, float relErr, float absT, float absS,
-                                                               float &boostOut)
+// The boost of a window from ln of its average loudness, as the screening kernels evaluate it (fp32, hardware
+// exp2: within 1e-5 of calcBoost, impl/FeatureCorrelationImpl.scala:73-78).
+__device__ __forceinline__ float screen_boost(float lnAvgIn, float lnAvg)
+{
+    const float kLog2e = 1.4426950408889634f;
+    return __builtin_amdgcn_exp2f((lnAvgIn - lnAvg) * (kLog2e / 0.6f));
+}
+// What the boost gate does to a window's bounds: 0 gated (similarity 0 exactly), 1 open, 2 within 1e-5 of maxBoost
+// (the exact path may gate it: the bounds then include 0).
+__device__ __forceinline__ int screen_gate(float boost, float maxBoost)
+{
+    if (!(boost <= maxBoost * 1.00001f)) return 0;
+    return boost > maxBoost * 0.99999f ? 2 : 1;
+}
+
+__device__ __forceinline__ WindowCoeffs window_coeffs_spectral(const CorrParams &cp, float rsdT, float rsdS, uint2 gu,
+                                                               float relErr, float absT, float absS, int gate)
 {
     const float nT = (float)cp.L, nS = (float)cp.L * (float)(cp.numCh - 1);
-    const float kLog2e = 1.4426950408889634f;
-    const float boost = __builtin_amdgcn_exp2f(((float)cp.lnAvgIn - lnAvg) * (kLog2e / 0.6f));
-    boostOut = boost;
     WindowCoeffs wc = {0.0f, 0.0f, 0.0f, 0.0f};  // a gated window: sim = 0 exactly
-    if (boost <= cp.maxBoost * 1.00001f) {
+    if (gate) {
         float errT = 0.0f, errS = 0.0f;
         if (cp.w > 0.0f) {
             const float g = half_from_bits(gu.x & 0xffffu), u = half_from_bits(gu.x >> 16);
@@ -298,7 +309,7 @@ __device__ __forceinline__ WindowCoeffs window_coeffs_spectral(const CorrParams 
             errS = eh + (1.0f + eh) * g + fabsf((float)cp.sumAS) / ((float)cp.aStdS * nS) * u * 1.0001f;
         }
         wc.e = errT * cp.w + errS * (1.0f - cp.w) + 1e-5f;
-        if (boost > cp.maxBoost * 0.99999f) wc.e = -wc.e;  // the exact path may gate this window
+        if (gate == 2) wc.e = -wc.e;  // the exact path may gate this window
     }
     return wc;
 }

@@ -198,6 +198,37 @@ __global__ void fft_blknorm_kernel(const float *__restrict__ blksq, int numCh, i
                              sqrtf(sq[0] + 2.0f * s) * 1.0001f);
 }
 
+// Smallest ln(average loudness) over a block's windows -- its largest boost is exp((lnAvgIn - that) / 0.6) -- or
+// -inf when a window has none (average <= 0): where even that boost passes the gate, the kernel needs no window's
+// own value.  One workgroup of 256 threads per block.
+__global__ __launch_bounds__(256) void fft_blklnmin_kernel(const FftBlock *__restrict__ blocks, float *wstat,
+                                                           long long totalWindows, float *__restrict__ blklnmin)
+{
+    __shared__ float part[4];
+    const FftBlock bd = blocks[blockIdx.x];
+    const SpectralStatics st = spectral_statics(wstat, totalWindows);
+    float m = INFINITY;
+    for (int k = threadIdx.x; k < bd.valid; k += 256) {
+        const float v = st.lnAvg[bd.win + k];
+        m = v == v ? fminf(m, v) : -INFINITY;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fminf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) blklnmin[blockIdx.x] = fminf(fminf(part[0], part[1]), fminf(part[2], part[3]));
+}
+
+// Boosts of a run of windows from their statics: what the spectral kernel leaves out of its output (see
+// sgz_context::boost_lazy).
+__global__ __launch_bounds__(256) void boost_fill_kernel(float *wstat, long long totalWindows, long long w0, long long n,
+                                                         float lnAvgIn, float *__restrict__ boost)
+{
+    const SpectralStatics st = spectral_statics(wstat, totalWindows);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        boost[w0 + i] = screen_boost(lnAvgIn, st.lnAvg[w0 + i]);
+}
+
 // corr_fft_kernel: workgroup = one block of N frames, N / 16 threads.
 //   1. per bin j < N / 2: Zt = A_0 X_0, Zs = sum_{c >= 1} A_c X_c (A: conjugated target spectra / N), and the two
 //      Hermitian spectra combined into one, W[j] = Zt + i Zs, W[N - j] = conj(Zt) + i conj(Zs), written to LDS;
@@ -209,6 +240,7 @@ __global__ __launch_bounds__(N / 16) void corr_fft_kernel(const FftBlock *__rest
                                                           const float2 *__restrict__ aspec,
                                                           const float2 *__restrict__ tab,
                                                           const float4 *__restrict__ blknorm,
+                                                          const float *__restrict__ blklnmin,
                                                           float *__restrict__ wstat, long long totalWindows,
                                                           CorrParams cp, FftGeom fg,
                                                           float *__restrict__ simOut, float *__restrict__ boostOut,
@@ -270,6 +302,10 @@ __global__ __launch_bounds__(N / 16) void corr_fft_kernel(const FftBlock *__rest
     float best = -INFINITY;
     int bad = 0;
     const SpectralStatics st = spectral_statics(wstat, totalWindows);
+    // Boosts are written only on request (boostOut), and read only where the block's largest boost does not pass
+    // the gate by itself: 8 of 28 bytes per window that most launches do not move.
+    const bool allOpen = screen_gate(screen_boost((float)cp.lnAvgIn, blklnmin[blockIdx.x]) * 1.00002f, cp.maxBoost) == 1;
+    const bool needLn = boostOut != nullptr || !allOpen;
     for (int m0 = 0; m0 < 16 && m0 * T < bd.valid; m0 += 4) {
         float rsdT[4], rsdS[4], lnAvg[4];
         uint2 gu[4];
@@ -279,7 +315,7 @@ __global__ __launch_bounds__(N / 16) void corr_fft_kernel(const FftBlock *__rest
             const long long w = bd.win + (k < bd.valid ? k : 0);
             rsdT[u] = st.rsdT[w];
             rsdS[u] = st.rsdS[w];
-            lnAvg[u] = st.lnAvg[w];
+            lnAvg[u] = needLn ? st.lnAvg[w] : 0.0f;
             gu[u] = st.gu[w];
         }
 #pragma unroll
@@ -287,11 +323,15 @@ __global__ __launch_bounds__(N / 16) void corr_fft_kernel(const FftBlock *__rest
             const int k = tid + (m0 + u) * T;
             if (k < bd.valid) {
                 const float2 y = buf[fft_phys(k)];
-                float sim, lo, boost;
-                const WindowCoeffs wc =
-                    window_coeffs_spectral(cpf, rsdT[u], rsdS[u], lnAvg[u], gu[u], fg.relErr, absT, absS, boost);
+                float sim, lo;
+                int gate = 1;
+                if (needLn) {
+                    const float boost = screen_boost((float)cp.lnAvgIn, lnAvg[u]);
+                    gate = screen_gate(boost, cp.maxBoost);
+                    if (boostOut) boostOut[bd.win + k] = boost;
+                }
+                const WindowCoeffs wc = window_coeffs_spectral(cpf, rsdT[u], rsdS[u], gu[u], fg.relErr, absT, absS, gate);
                 window_bounds(wc, y.x, y.y * rbeta, sim, lo);
-                boostOut[bd.win + k] = boost;
                 simOut[bd.win + k] = sim;
                 best = fmaxf(best, lo);
                 bad |= (lo != lo) || (sim != sim);
@@ -395,7 +435,7 @@ namespace sgz {
 
 void fft_screen_free(sgz_context *ctx)
 {
-    void *bufs[] = {ctx->d_fblocks, ctx->d_spec, ctx->d_aspec, ctx->d_fft_tab, ctx->d_blksq, ctx->d_blknorm};
+    void *bufs[] = {ctx->d_fblocks, ctx->d_spec, ctx->d_aspec, ctx->d_fft_tab, ctx->d_blksq, ctx->d_blknorm, ctx->d_blklnmin};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
 }
@@ -468,6 +508,7 @@ int fft_screen_layout(sgz_context *ctx)
     if ((rc = ensure(ctx, ctx->d_spec, ctx->spec_cap, (size_t)specOff))) return rc;
     if ((rc = ensure(ctx, ctx->d_blksq, ctx->blksq_cap, nb * (size_t)numCh))) return rc;
     if ((rc = ensure(ctx, ctx->d_blknorm, ctx->blknorm_cap, nb))) return rc;
+    if ((rc = ensure(ctx, ctx->d_blklnmin, ctx->blklnmin_cap, nb))) return rc;
     SGZ_HIP(ctx, hipMemcpyAsync(ctx->d_fblocks, ctx->h_fblocks.data(), sizeof(FftBlock) * nb, hipMemcpyHostToDevice,
                                 ctx->stream));
     ctx->fg = fg;
@@ -500,9 +541,55 @@ int fft_screen_prepare(sgz_context *ctx, int file_begin, int file_end, hipStream
     hipLaunchKernelGGL(fft_blknorm_kernel, dim3((b1 - b0 + 255) / 256), dim3(256), 0, stream,
                        ctx->d_blksq + (size_t)b0 * numCh, numCh, b1 - b0, ctx->d_blknorm + b0);
     SGZ_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(fft_blklnmin_kernel, dim3(b1 - b0), dim3(256), 0, stream, ctx->d_fblocks + b0, ctx->d_wstat_h,
+                       ctx->total_windows, ctx->d_blklnmin + b0);
+    SGZ_HIP(ctx, hipGetLastError());
     ctx->fc_begin = file_begin;
     ctx->fc_end = file_end;
     return SGZ_OK;
+}
+
+int boost_materialize(sgz_context *ctx, int file_begin, int file_end, hipStream_t stream, bool *launched)
+{
+    if (launched) *launched = false;
+    const int nf = (int)std::min(ctx->boost_lazy.size(), ctx->h_files.size());
+    for (int f = std::max(file_begin, 0); f < std::min(file_end, nf);) {
+        if (!ctx->boost_lazy[(size_t)f]) {
+            f++;
+            continue;
+        }
+        int e = f;
+        while (e < std::min(file_end, nf) && ctx->boost_lazy[(size_t)e]) ctx->boost_lazy[(size_t)e++] = 0;
+        const long long w0 = ctx->h_files[(size_t)f].win_off;
+        const long long w1 = ctx->h_files[(size_t)e - 1].win_off + ctx->h_files[(size_t)e - 1].num_windows;
+        if (w1 > w0) {
+            const int grid = (int)std::min<long long>((w1 - w0 + 255) / 256, 2048);
+            hipLaunchKernelGGL(boost_fill_kernel, dim3(grid), dim3(256), 0, stream, ctx->d_wstat_h, ctx->total_windows, w0,
+                               w1 - w0, (float)ctx->boost_lazy_ln, ctx->d_boost);
+            SGZ_HIP(ctx, hipGetLastError());
+            if (launched) *launched = true;
+        }
+        f = e;
+    }
+    return SGZ_OK;
+}
+
+int boost_source(sgz_context *ctx, int file_begin, int file_end, hipStream_t stream, const float **lnAvg)
+{
+    *lnAvg = nullptr;
+    const int nf = (int)ctx->boost_lazy.size();
+    int lazy = 0, total = 0;
+    for (int f = std::max(file_begin, 0); f < std::min(file_end, nf); f++) {
+        if (ctx->h_files[(size_t)f].num_windows <= 0) continue;  // (no window reads anything)
+        total++;
+        lazy += ctx->boost_lazy[(size_t)f] ? 1 : 0;
+    }
+    if (lazy == 0) return SGZ_OK;
+    if (lazy == total && ctx->fg.N > 0 && ctx->boost_lazy_ln == ctx->cp.lnAvgIn) {
+        *lnAvg = ctx->d_wstat_h + 2 * spectral_statics_stride(ctx->total_windows);
+        return SGZ_OK;
+    }
+    return boost_materialize(ctx, file_begin, file_end, stream);
 }
 
 int fft_screen_launch(sgz_context *ctx, int file_begin, int file_end, hipStream_t stream, hipEvent_t start,
@@ -512,6 +599,14 @@ int fft_screen_launch(sgz_context *ctx, int file_begin, int file_end, hipStream_
     if (N <= 0) return ctx->fail(SGZ_E_STATE, "spectral screening is not set up for this layout");
     int rc;
     if (ctx->aspec_dirty && (rc = fft_target(ctx, stream))) return rc;
+    // this run's boosts stay implicit; files that still owe theirs to a run with another target get them now
+    if (ctx->boost_lazy.size() != ctx->files.size()) ctx->boost_lazy.assign(ctx->files.size(), 0);
+    if (ctx->boost_lazy_ln != ctx->cp.lnAvgIn) {
+        if ((rc = boost_materialize(ctx, 0, file_begin, stream))) return rc;
+        if ((rc = boost_materialize(ctx, file_end, (int)ctx->files.size(), stream))) return rc;
+        ctx->boost_lazy_ln = ctx->cp.lnAvgIn;
+    }
+    for (int f = file_begin; f < file_end; f++) ctx->boost_lazy[(size_t)f] = 1;
     const FftGeom &fg = ctx->fg;
     const int b0 = ctx->fblock_begin[(size_t)file_begin], b1 = ctx->fblock_begin[(size_t)file_end];
     // per-file bounds: two alternating arrays, as in the matrix-core launch (half_screen_launch)
@@ -531,13 +626,13 @@ int fft_screen_launch(sgz_context *ctx, int file_begin, int file_end, hipStream_
         if ((rc = set_lds(ctx, kern, lds))) return rc;
         if (start || stop)
             hipExtLaunchKernelGGL(kern, dim3(b1 - b0), dim3(N / 16), lds, stream, start, stop, 0, ctx->d_fblocks + b0,
-                                  ctx->d_spec, ctx->d_aspec, ctx->d_fft_tab, ctx->d_blknorm + b0,
-                                  ctx->d_wstat_h, ctx->total_windows, ctx->cp, fg, ctx->d_sim, ctx->d_boost,
+                                  ctx->d_spec, ctx->d_aspec, ctx->d_fft_tab, ctx->d_blknorm + b0, ctx->d_blklnmin + b0,
+                                  ctx->d_wstat_h, ctx->total_windows, ctx->cp, fg, ctx->d_sim, (float *)nullptr,
                                   lokey, lokeyNext, ctx->d_hflags);
         else
             hipLaunchKernelGGL(kern, dim3(b1 - b0), dim3(N / 16), lds, stream, ctx->d_fblocks + b0, ctx->d_spec,
-                               ctx->d_aspec, ctx->d_fft_tab, ctx->d_blknorm + b0,
-                               ctx->d_wstat_h, ctx->total_windows, ctx->cp, fg, ctx->d_sim, ctx->d_boost,
+                               ctx->d_aspec, ctx->d_fft_tab, ctx->d_blknorm + b0, ctx->d_blklnmin + b0,
+                               ctx->d_wstat_h, ctx->total_windows, ctx->cp, fg, ctx->d_sim, (float *)nullptr,
                                lokey, lokeyNext, ctx->d_hflags);
         SGZ_HIP(ctx, hipGetLastError());
         return SGZ_OK;

@@ -226,6 +226,14 @@ struct sgz_context {
     size_t blknorm_cap = 0;
     bool aspec_dirty = true;
     int fc_begin = 0, fc_end = 0;            // files whose spectra are current
+    float *d_blklnmin = nullptr;             // per block: smallest ln(average loudness) of its windows
+    size_t blklnmin_cap = 0;
+    // The spectral kernel does not write the boosts of its windows (4 of the bytes it would move per window; a
+    // search needs the boost of the few windows it re-scores only).  boost_lazy[f] != 0: d_boost of file f is not
+    // filled in; whoever reads it (dense reads, compaction over a mix of files) has boost_materialize fill it first
+    // from the statics with the target value the run used (boost_lazy_ln).
+    std::vector<char> boost_lazy;
+    double boost_lazy_ln = 0.0;
     double tgt_sumT = 0.0, tgt_sumS = 0.0;   // sums and Euclidean norms of the fp32 target values
     double tgt_nrmT = 0.0, tgt_nrmS = 0.0, tgt_nrm1 = 0.0;  // (nrm1: channel 1 alone)
     float *d_thr = nullptr;                  // smallest of the head files' bounds (filter of the tail files)
@@ -317,6 +325,12 @@ int fft_screen_prepare(sgz_context *ctx, int file_begin, int file_end, hipStream
 int fft_screen_launch(sgz_context *ctx, int file_begin, int file_end, hipStream_t stream, hipEvent_t start,
                       hipEvent_t stop);
 void fft_screen_free(sgz_context *ctx);
+// Fills in the boosts the spectral kernel left out for files [file_begin, file_end) (kernels on `stream`);
+// *launched tells whether there was anything to do.
+int boost_materialize(sgz_context *ctx, int file_begin, int file_end, hipStream_t stream, bool *launched = nullptr);
+// The statics array the compaction kernels compute boosts from when every file of the range is of that kind (else
+// null, after filling in what was missing).
+int boost_source(sgz_context *ctx, int file_begin, int file_end, hipStream_t stream, const float **lnAvg);
 
 // sgz_corr.hip: address of the device's scratch array of sgz_corr_rescore_device_noalloc (device must be current)
 int noalloc_scratch_init(sgz_context *ctx);
