@@ -227,6 +227,14 @@ SGZ_API int sgz_corr_screen_f16_available(const sgz_context *ctx);
  * sgz_corr_screen_kernel_in_use: 1 or 2 once a run has built the layout, 0 if neither applies, -1 before. */
 SGZ_API int sgz_corr_set_screen_kernel(sgz_context *ctx, int kernel);
 SGZ_API int sgz_corr_screen_kernel_in_use(const sgz_context *ctx);
+/* What a run of the spectral kernel leaves behind: 0 (default) an upper bound per window, which sgz_corr_read_dense*
+ * and every compaction call can read; 1 only the list of the windows whose upper bound reaches the largest lower
+ * bound of their own block -- all a search with numPerFile = 1 needs (sgz_corr_compact_top*, sgz_corr_compact_bounded*
+ * with head_end covering the run's files, which then filter that list instead of scanning every window), at 4
+ * bytes per window less traffic.  After such a run the other readers fail with SGZ_E_STATE until the files are run
+ * again; runs of the other kernels are not affected.  sgz_corr_search sets and resets it around its own run.  No
+ * counterpart in the reference (impl/FeatureCorrelationImpl.scala:234-239 keeps one running maximum per file). */
+SGZ_API int sgz_corr_set_screen_output(sgz_context *ctx, int lists_only);
 /* Geometry of the spectral kernel for the current layout: transform length N, windows per block (N - L + 1) and
  * the number of blocks over all files; zeros when the spectral kernel is not in use.  Any pointer may be NULL.
  * For reports (a block moves 4 * numCh * N bytes of spectra); no counterpart in the reference. */

@@ -1085,6 +1085,49 @@ __global__ __launch_bounds__(256) void bound_kth_kernel(const int *__restrict__ 
     if (threadIdx.x == 0) out[0] = v;
 }
 
+// The search over bounds from the candidate list of a spectral run (sgz::PreList: the windows whose upper bound
+// reaches their own block's largest lower bound) instead of from dense upper bounds: a record stays when its
+// upper bound reaches its file's bound and, with topK > 0, the topK-th largest of the files' bounds -- what
+// compact_bounded_kernel does for head files, over a few records per block instead of every window.  Files the
+// bounds cannot decide and a list that did not hold every record are reported through the count, as there.  Clears
+// the other counter of the list (the next run's) and of the output.
+__global__ __launch_bounds__(256) void prelist_filter_kernel(const sgz_candidate *__restrict__ pre,
+                                                             const unsigned long long *__restrict__ preCount,
+                                                             long long preCapacity,
+                                                             unsigned long long *__restrict__ preOther,
+                                                             const int *__restrict__ lokey, int headEnd,
+                                                             const int *__restrict__ hflags, int fileBegin, int fileEnd,
+                                                             sgz_candidate *__restrict__ out, long long capacity,
+                                                             unsigned long long *__restrict__ count,
+                                                             unsigned long long *__restrict__ zeroOther, int topK,
+                                                             float *__restrict__ topThrOut)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (zeroOther) *zeroOther = 0ull;
+        *preOther = 0ull;
+    }
+    float top = -INFINITY;
+    if (topK > 0) {
+        top = bound_kth_select(lokey, headEnd, topK);
+        if (blockIdx.x == 0 && threadIdx.x == 0) topThrOut[0] = top;
+    }
+    const unsigned long long listed = *preCount;
+    if (blockIdx.x == 0) {
+        for (int f = fileBegin + threadIdx.x; f < fileEnd; f += 256)
+            if (hflags[f]) atomicAdd(count, (unsigned long long)capacity + 1ull);
+        if (threadIdx.x == 0 && listed > (unsigned long long)preCapacity) atomicAdd(count, (unsigned long long)capacity + 1ull);
+    }
+    const long long n = listed > (unsigned long long)preCapacity ? preCapacity : (long long)listed;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const sgz_candidate c = pre[i];
+        const float t = fmaxf(bound_from_key(lokey[c.file]), top);
+        if (c.sim >= t) {
+            const unsigned long long slot = atomicAdd(count, 1ull);
+            if ((long long)slot < capacity) out[slot] = c;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Exact re-evaluation of listed windows, straight from the raw frames: fp32 normalise with the IEEE divide
 // (MathUtil.normalize, impl/MathUtil.scala:132-152), every sum in fp64.  What MathUtil.stat and
@@ -1493,6 +1536,8 @@ int build_layout(sgz_context *ctx)
     if (nf) SGZ_HIP(ctx, hipMemsetAsync(ctx->d_hflags, 0, sizeof(int) * nf, ctx->stream));
     ctx->hc_begin = ctx->hc_end = 0;  // no half-precision preparation of this layout yet
     ctx->boost_lazy.assign((size_t)nf, 0);
+    ctx->no_dense.assign((size_t)nf, 0);
+    ctx->pre_valid = false;
     ctx->prefetch_valid = false;
     if (halfOk) {
         if ((rc = ensure(ctx, ctx->d_prefix_h, ctx->prefix_h_cap, (size_t)prefix))) return rc;
@@ -2048,8 +2093,11 @@ static int corr_run_impl(sgz_context *ctx, int file_begin, int file_end, int mod
         ctx->ev_valid = true;
         ctx->ev_runs++;
     }
-    if (!spectral)  // every other kernel writes the boosts of its windows
+    if (!spectral) {  // every other kernel writes the boosts and the per-window results of its windows
         for (int f = file_begin; f < file_end && f < (int)ctx->boost_lazy.size(); f++) ctx->boost_lazy[(size_t)f] = 0;
+        for (int f = file_begin; f < file_end && f < (int)ctx->no_dense.size(); f++) ctx->no_dense[(size_t)f] = 0;
+        if (ctx->pre_valid && file_begin < ctx->pre_fe && file_end > ctx->pre_fb) ctx->pre_valid = false;
+    }
     if (half) {
         ctx->lo_begin = file_begin;
         ctx->lo_end = file_end;
@@ -2118,6 +2166,10 @@ int sgz_corr_prefetch_dense(sgz_context *ctx, int file_begin, int file_end)
     if (file_begin < 0 || file_end > nf || file_begin > file_end) return ctx->fail(SGZ_E_ARG, "bad file range");
     ctx->prefetch_valid = false;
     if (file_begin == file_end) return SGZ_OK;
+    {
+        const int drc = require_dense(ctx, file_begin, file_end);
+        if (drc) return drc;
+    }
     SGZ_HIP(ctx, hipSetDevice(ctx->device));
     const long long w0 = ctx->h_files[file_begin].win_off;
     const long long w1 = ctx->h_files[file_end - 1].win_off + ctx->h_files[file_end - 1].num_windows;
@@ -2156,6 +2208,10 @@ int sgz_corr_read_dense_range(sgz_context *ctx, int file_begin, int file_end, fl
     const int nf = (int)ctx->files.size();
     if (file_begin < 0 || file_end > nf || file_begin > file_end) return ctx->fail(SGZ_E_ARG, "bad file range");
     if (file_begin == file_end) return SGZ_OK;
+    {
+        const int drc = require_dense(ctx, file_begin, file_end);
+        if (drc) return drc;
+    }
     SGZ_HIP(ctx, hipSetDevice(ctx->device));
     // wait (on the copy stream only) for the runs that produced these files
     bool covered = false;
@@ -2237,6 +2293,10 @@ static int compact_device_impl(sgz_context *ctx, int file_begin, int file_end, f
     if (file_begin < 0 || file_end > nf || file_begin > file_end) return ctx->fail(SGZ_E_ARG, "bad file range");
     if (!device_count || capacity < 0 || (capacity > 0 && !device_out))
         return ctx->fail(SGZ_E_ARG, "bad output buffers");
+    {
+        const int drc = require_dense(ctx, file_begin, file_end);
+        if (drc) return drc;
+    }
     SGZ_HIP(ctx, hipSetDevice(ctx->device));
     for (auto &run : ctx->runs)
         if (run.fb < file_end && run.fe > file_begin) {
@@ -2297,6 +2357,18 @@ static int compact_bounded_device_impl(sgz_context *ctx, int file_begin, int fil
     float *topThr = top_k > 0 ? reinterpret_cast<float *>(device_count) + 2 : nullptr;
     const int t0 = ctx->tile_begin[file_begin], t1 = ctx->tile_begin[file_end];
     if (launched) *launched = t1 > t0;
+    if (t1 > t0 && ctx->pre_valid && ctx->pre_fb == file_begin && ctx->pre_fe == file_end && head_end >= file_end) {
+        // the run left the list of the windows that can hold their file's maximum instead of dense upper bounds
+        const int pp = ctx->pre_run_parity;
+        hipLaunchKernelGGL(prelist_filter_kernel, dim3(32), dim3(256), 0, ctx->stream, ctx->d_prelist, ctx->d_precount + pp,
+                           ctx->pre_capacity, ctx->d_precount + (1 - pp), ctx->lokey_cur, head_end, ctx->d_hflags,
+                           file_begin, file_end, device_out, (long long)capacity, device_count, zero_other, top_k, topThr);
+        SGZ_HIP(ctx, hipGetLastError());
+        ctx->pre_clean[1 - pp] = true;
+        ctx->pre_parity = 1 - pp;
+        return SGZ_OK;
+    }
+    if ((rc = require_dense(ctx, file_begin, file_end))) return rc;
     if (t1 > t0) {
         // four tiles per workgroup and more: enough workgroups to fill the chip, few enough that the bound
         // selection each of them repeats stays cheap

@@ -245,12 +245,14 @@ __global__ __launch_bounds__(N / 16) void corr_fft_kernel(const FftBlock *__rest
                                                           CorrParams cp, FftGeom fg,
                                                           float *__restrict__ simOut, float *__restrict__ boostOut,
                                                           int *__restrict__ lokey,
-                                                          int *__restrict__ lokeyNext, int *__restrict__ hflags)
+                                                          int *__restrict__ lokeyNext, int *__restrict__ hflags,
+                                                          PreList pre)
 {
     constexpr int T = N / 16, NH = N / 2;
     extern __shared__ __attribute__((aligned(16))) float2 buf[];
     __shared__ float wbest[16];
     __shared__ int wbad[16];
+    __shared__ float blockBest;
     const int tid = threadIdx.x;
     const FftBlock bd = blocks[blockIdx.x];
     const int numCh = NCH ? NCH : cp.numCh;
@@ -306,35 +308,43 @@ __global__ __launch_bounds__(N / 16) void corr_fft_kernel(const FftBlock *__rest
     // the gate by itself: 8 of 28 bytes per window that most launches do not move.
     const bool allOpen = screen_gate(screen_boost((float)cp.lnAvgIn, blklnmin[blockIdx.x]) * 1.00002f, cp.maxBoost) == 1;
     const bool needLn = boostOut != nullptr || !allOpen;
-    for (int m0 = 0; m0 < 16 && m0 * T < bd.valid; m0 += 4) {
-        float rsdT[4], rsdS[4], lnAvg[4];
-        uint2 gu[4];
+    // (the loop is unrolled so that the sixteen upper bounds of a thread stay in registers for the candidate pass)
+    float ups[16];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int k = tid + (m0 + u) * T;
-            const long long w = bd.win + (k < bd.valid ? k : 0);
-            rsdT[u] = st.rsdT[w];
-            rsdS[u] = st.rsdS[w];
-            lnAvg[u] = needLn ? st.lnAvg[w] : 0.0f;
-            gu[u] = st.gu[w];
-        }
+    for (int m0 = 0; m0 < 16; m0 += 4) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int k = tid + (m0 + u) * T;
-            if (k < bd.valid) {
-                const float2 y = buf[fft_phys(k)];
-                float sim, lo;
-                int gate = 1;
-                if (needLn) {
-                    const float boost = screen_boost((float)cp.lnAvgIn, lnAvg[u]);
-                    gate = screen_gate(boost, cp.maxBoost);
-                    if (boostOut) boostOut[bd.win + k] = boost;
+        for (int u = 0; u < 4; u++) ups[m0 + u] = -INFINITY;
+        if (m0 * T < bd.valid) {  // (uniform over the workgroup)
+            float rsdT[4], rsdS[4], lnAvg[4];
+            uint2 gu[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int k = tid + (m0 + u) * T;
+                const long long w = bd.win + (k < bd.valid ? k : 0);
+                rsdT[u] = st.rsdT[w];
+                rsdS[u] = st.rsdS[w];
+                lnAvg[u] = needLn ? st.lnAvg[w] : 0.0f;
+                gu[u] = st.gu[w];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int k = tid + (m0 + u) * T;
+                if (k < bd.valid) {
+                    const float2 y = buf[fft_phys(k)];
+                    float sim, lo;
+                    int gate = 1;
+                    if (needLn) {
+                        const float boost = screen_boost((float)cp.lnAvgIn, lnAvg[u]);
+                        gate = screen_gate(boost, cp.maxBoost);
+                        if (boostOut) boostOut[bd.win + k] = boost;
+                    }
+                    const WindowCoeffs wc = window_coeffs_spectral(cpf, rsdT[u], rsdS[u], gu[u], fg.relErr, absT, absS, gate);
+                    window_bounds(wc, y.x, y.y * rbeta, sim, lo);
+                    if (simOut) simOut[bd.win + k] = sim;
+                    ups[m0 + u] = sim;
+                    best = fmaxf(best, lo);
+                    bad |= (lo != lo) || (sim != sim);
                 }
-                const WindowCoeffs wc = window_coeffs_spectral(cpf, rsdT[u], rsdS[u], gu[u], fg.relErr, absT, absS, gate);
-                window_bounds(wc, y.x, y.y * rbeta, sim, lo);
-                simOut[bd.win + k] = sim;
-                best = fmaxf(best, lo);
-                bad |= (lo != lo) || (sim != sim);
             }
         }
     }
@@ -358,6 +368,28 @@ __global__ __launch_bounds__(N / 16) void corr_fft_kernel(const FftBlock *__rest
         if (bad) atomicOr(&hflags[bd.file], 2);
         // the run after this one folds its bounds into the other array: the file's first block resets its entry
         if (bd.o0 == 0) lokeyNext[bd.file] = bound_key(-INFINITY);
+        blockBest = best;
+    }
+    if (!pre.list) return;
+    // Candidate pass (lists instead of dense upper bounds): a window whose upper bound does not reach the largest
+    // lower bound of its own block cannot hold its file's maximum; the few that do -- a handful per block -- are
+    // listed, and the search filters that list by the per-file and the k-th bound instead of scanning every window.
+    __syncthreads();
+    const float bb = blockBest;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int k = tid + i * T;
+        if (k < bd.valid && ups[i] >= bb) {
+            const unsigned long long slot = atomicAdd(pre.count, 1ull);
+            if ((long long)slot < pre.capacity) {
+                sgz_candidate c;
+                c.file = bd.file;
+                c.offset = bd.o0 + k;
+                c.sim = ups[i];
+                c.boost = screen_boost((float)cp.lnAvgIn, st.lnAvg[bd.win + k]);
+                pre.list[slot] = c;
+            }
+        }
     }
 }
 
@@ -435,7 +467,7 @@ namespace sgz {
 
 void fft_screen_free(sgz_context *ctx)
 {
-    void *bufs[] = {ctx->d_fblocks, ctx->d_spec, ctx->d_aspec, ctx->d_fft_tab, ctx->d_blksq, ctx->d_blknorm, ctx->d_blklnmin};
+    void *bufs[] = {ctx->d_fblocks, ctx->d_spec, ctx->d_aspec, ctx->d_fft_tab, ctx->d_blksq, ctx->d_blknorm, ctx->d_blklnmin, ctx->d_prelist, ctx->d_precount};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
 }
@@ -574,6 +606,16 @@ int boost_materialize(sgz_context *ctx, int file_begin, int file_end, hipStream_
     return SGZ_OK;
 }
 
+int require_dense(sgz_context *ctx, int file_begin, int file_end)
+{
+    const int nf = (int)ctx->no_dense.size();
+    for (int f = std::max(file_begin, 0); f < std::min(file_end, nf); f++)
+        if (ctx->no_dense[(size_t)f])
+            return ctx->fail(SGZ_E_STATE, "the latest screening run over these files kept candidate lists only "
+                                          "(sgz_corr_set_screen_output): no per-window results to read");
+    return SGZ_OK;
+}
+
 int boost_source(sgz_context *ctx, int file_begin, int file_end, hipStream_t stream, const float **lnAvg)
 {
     *lnAvg = nullptr;
@@ -607,6 +649,31 @@ int fft_screen_launch(sgz_context *ctx, int file_begin, int file_end, hipStream_
         ctx->boost_lazy_ln = ctx->cp.lnAvgIn;
     }
     for (int f = file_begin; f < file_end; f++) ctx->boost_lazy[(size_t)f] = 1;
+    // dense upper bounds, or the list of the windows that can hold their file's maximum
+    if (ctx->no_dense.size() != ctx->files.size()) ctx->no_dense.assign(ctx->files.size(), 0);
+    PreList pre{nullptr, nullptr, 0};
+    const bool lists = ctx->screen_output == 1;
+    if (lists) {
+        const size_t cap = std::max<size_t>(8192, 16 * ctx->h_fblocks.size());
+        if ((rc = ensure(ctx, ctx->d_prelist, ctx->prelist_cap, cap))) return rc;
+        const unsigned long long *before = ctx->d_precount;
+        if ((rc = ensure(ctx, ctx->d_precount, ctx->precount_cap, (size_t)2))) return rc;
+        if (ctx->d_precount != before) ctx->pre_clean[0] = ctx->pre_clean[1] = false;
+        const int pp = ctx->pre_parity;
+        if (!ctx->pre_clean[pp])
+            SGZ_HIP(ctx, hipMemsetAsync(ctx->d_precount + pp, 0, sizeof(unsigned long long), stream));
+        ctx->pre_clean[pp] = false;
+        ctx->pre_run_parity = pp;
+        ctx->pre_capacity = (long long)ctx->prelist_cap;
+        pre = PreList{ctx->d_prelist, ctx->d_precount + pp, ctx->pre_capacity};
+        ctx->pre_valid = true;
+        ctx->pre_fb = file_begin;
+        ctx->pre_fe = file_end;
+    } else if (ctx->pre_valid && file_begin < ctx->pre_fe && file_end > ctx->pre_fb) {
+        ctx->pre_valid = false;
+    }
+    for (int f = file_begin; f < file_end; f++) ctx->no_dense[(size_t)f] = lists ? 1 : 0;
+    float *simOut = lists ? nullptr : ctx->d_sim;
     const FftGeom &fg = ctx->fg;
     const int b0 = ctx->fblock_begin[(size_t)file_begin], b1 = ctx->fblock_begin[(size_t)file_end];
     // per-file bounds: two alternating arrays, as in the matrix-core launch (half_screen_launch)
@@ -627,13 +694,13 @@ int fft_screen_launch(sgz_context *ctx, int file_begin, int file_end, hipStream_
         if (start || stop)
             hipExtLaunchKernelGGL(kern, dim3(b1 - b0), dim3(N / 16), lds, stream, start, stop, 0, ctx->d_fblocks + b0,
                                   ctx->d_spec, ctx->d_aspec, ctx->d_fft_tab, ctx->d_blknorm + b0, ctx->d_blklnmin + b0,
-                                  ctx->d_wstat_h, ctx->total_windows, ctx->cp, fg, ctx->d_sim, (float *)nullptr,
-                                  lokey, lokeyNext, ctx->d_hflags);
+                                  ctx->d_wstat_h, ctx->total_windows, ctx->cp, fg, simOut, (float *)nullptr,
+                                  lokey, lokeyNext, ctx->d_hflags, pre);
         else
             hipLaunchKernelGGL(kern, dim3(b1 - b0), dim3(N / 16), lds, stream, ctx->d_fblocks + b0, ctx->d_spec,
                                ctx->d_aspec, ctx->d_fft_tab, ctx->d_blknorm + b0, ctx->d_blklnmin + b0,
-                               ctx->d_wstat_h, ctx->total_windows, ctx->cp, fg, ctx->d_sim, (float *)nullptr,
-                               lokey, lokeyNext, ctx->d_hflags);
+                               ctx->d_wstat_h, ctx->total_windows, ctx->cp, fg, simOut, (float *)nullptr,
+                               lokey, lokeyNext, ctx->d_hflags, pre);
         SGZ_HIP(ctx, hipGetLastError());
         return SGZ_OK;
     };
@@ -656,6 +723,14 @@ int sgz_corr_set_screen_kernel(sgz_context *ctx, int kernel)
     if (kernel < 0 || kernel > 2) return ctx->fail(SGZ_E_ARG, "screen kernel: 0 (auto), 1 (matrix cores) or 2 (spectral)");
     if (kernel != ctx->screen_kernel) ctx->layout_dirty = true;
     ctx->screen_kernel = kernel;
+    return SGZ_OK;
+}
+
+int sgz_corr_set_screen_output(sgz_context *ctx, int lists_only)
+{
+    if (!ctx) return SGZ_E_ARG;
+    if (lists_only != 0 && lists_only != 1) return ctx->fail(SGZ_E_ARG, "screen output: 0 (per-window results) or 1 (candidate lists)");
+    ctx->screen_output = lists_only;
     return SGZ_OK;
 }
 

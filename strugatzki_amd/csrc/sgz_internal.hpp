@@ -110,6 +110,15 @@ struct FftGeom {
     double sumAT, sumAS;   // sums of the fp32 target values
 };
 
+// Where the spectral kernel lists the windows that can hold their file's maximum, when it runs for a search over
+// bounds that needs nothing else (sgz_corr_set_screen_output): records, their count (which may pass the capacity:
+// then the list is incomplete and the search takes another path), the capacity.  list == nullptr: dense output.
+struct PreList {
+    sgz_candidate *list;
+    unsigned long long *count;
+    long long capacity;
+};
+
 // One block of the spectral screening kernel: N frames of one file from frame o0 on, `valid` windows.
 struct FftBlock {
     int file;
@@ -234,6 +243,20 @@ struct sgz_context {
     // from the statics with the target value the run used (boost_lazy_ln).
     std::vector<char> boost_lazy;
     double boost_lazy_ln = 0.0;
+    // sgz_corr_set_screen_output(1): a spectral run writes candidate lists instead of dense upper bounds.
+    // no_dense[f] != 0: the latest run over file f was of that kind (dense reads and threshold compaction refuse);
+    // the list of the latest such run covers files [pre_fb, pre_fe) and sits behind counter pre_parity ^ 1.
+    int screen_output = 0;
+    std::vector<char> no_dense;
+    sgz_candidate *d_prelist = nullptr;
+    size_t prelist_cap = 0;
+    unsigned long long *d_precount = nullptr;  // two counters, used in turn (the consumer of one clears the other)
+    size_t precount_cap = 0;
+    int pre_parity = 0, pre_run_parity = 0;  // counter the next run takes; counter the latest run used
+    bool pre_clean[2] = {false, false};
+    bool pre_valid = false;
+    int pre_fb = 0, pre_fe = 0;
+    long long pre_capacity = 0;
     double tgt_sumT = 0.0, tgt_sumS = 0.0;   // sums and Euclidean norms of the fp32 target values
     double tgt_nrmT = 0.0, tgt_nrmS = 0.0, tgt_nrm1 = 0.0;  // (nrm1: channel 1 alone)
     float *d_thr = nullptr;                  // smallest of the head files' bounds (filter of the tail files)
@@ -331,6 +354,8 @@ int boost_materialize(sgz_context *ctx, int file_begin, int file_end, hipStream_
 // The statics array the compaction kernels compute boosts from when every file of the range is of that kind (else
 // null, after filling in what was missing).
 int boost_source(sgz_context *ctx, int file_begin, int file_end, hipStream_t stream, const float **lnAvg);
+// Fails with SGZ_E_STATE when the latest screening run over one of the files kept candidate lists only.
+int require_dense(sgz_context *ctx, int file_begin, int file_end);
 
 // sgz_corr.hip: address of the device's scratch array of sgz_corr_rescore_device_noalloc (device must be current)
 int noalloc_scratch_init(sgz_context *ctx);

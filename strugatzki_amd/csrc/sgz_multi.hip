@@ -135,7 +135,12 @@ extern "C" int sgz_corr_search_multi(sgz_context *const *ctxs, int num_ctx, cons
             counts[(size_t)c] = 0;
             if (nloc == 0) return SGZ_OK;
             cands[(size_t)c].resize((size_t)capacity);
-            int r = pass == 0 ? sgz_corr_run_screen_f16(ctx, 0, nloc) : SGZ_OK;
+            int r = SGZ_OK;
+            if (pass == 0) {  // (nothing of the run is read but its candidates)
+                sgz_corr_set_screen_output(ctx, 1);
+                r = sgz_corr_run_screen_f16(ctx, 0, nloc);
+                sgz_corr_set_screen_output(ctx, 0);
+            }
             if (r) return r;
             r = pass == 0 ? sgz_corr_compact_top(ctx, 0, nloc, num_matches, cands[(size_t)c].data(), capacity,
                                                  &counts[(size_t)c], &tops[(size_t)c])

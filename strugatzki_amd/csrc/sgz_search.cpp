@@ -39,7 +39,11 @@ extern "C" int sgz_corr_search(sgz_context *ctx, int target_frames, int num_matc
     if (over_bounds && f16 && num_per_file == 1 && num_matches >= 1 && nf > 0) {
         if (cands.size() < (size_t)capacity) cands.resize((size_t)capacity);
         int64_t n = 0;
-        if ((rc = sgz_corr_run_screen_f16(ctx, 0, nf))) return rc;
+        // (this path reads nothing of the run but its candidates: the spectral kernel then lists them itself)
+        sgz_corr_set_screen_output(ctx, 1);
+        rc = sgz_corr_run_screen_f16(ctx, 0, nf);
+        sgz_corr_set_screen_output(ctx, 0);
+        if (rc) return rc;
         // first with the files left out that cannot reach the numMatches-th best of the per-file bounds
         float top = 0.0f;
         rc = sgz_corr_compact_top(ctx, 0, nf, num_matches, cands.data(), capacity, &n, &top);

@@ -173,6 +173,11 @@ class Context:
         matrix cores), "spectral" (fp32 transforms of whole blocks, HBM-bound) or "auto"."""
         self._check(lib.sgz_corr_set_screen_kernel(self._h, self.SCREEN_KERNELS[kernel]))
 
+    def set_screen_output(self, lists_only: bool) -> None:
+        """True: a run of the spectral kernel keeps only the list of the windows that can hold their file's maximum
+        (what corr_compact_top* / corr_compact_bounded* need); dense reads of such a run fail."""
+        self._check(lib.sgz_corr_set_screen_output(self._h, 1 if lists_only else 0))
+
     @property
     def screen_kernel_in_use(self) -> str | None:
         return {1: "matrix", 2: "spectral", 0: "none"}.get(lib.sgz_corr_screen_kernel_in_use(self._h))

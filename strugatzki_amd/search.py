@@ -341,7 +341,12 @@ def _sharded_over_bounds(ctx: Context, p: SearchParams, local_to_global: Sequenc
     for top in (True, False):
         if nloc:
             if top:
-                ctx.corr_run_screen_f16(0, nloc)
+                # (nothing of the run is read but its candidates: the spectral kernel then lists them itself)
+                ctx.set_screen_output(True)
+                try:
+                    ctx.corr_run_screen_f16(0, nloc)
+                finally:
+                    ctx.set_screen_output(False)
                 # row 0 = header (count and bound, written by the library), rows 1.. = records
                 ctx.corr_compact_top_device(0, nloc, p.num_matches, b["rec_ptr"], cap, b["count_ptr"])
             else:

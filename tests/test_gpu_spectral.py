@@ -313,3 +313,47 @@ def test_device_transform_equals_the_host_statement_of_it(ctx):
     open_ = boosts[0] <= 8.0 * (1 - 1e-4)
     d = gs.astype(np.float64) - sims[0]
     assert np.all(d[open_] >= 0) and d[open_].max() <= SLACK
+
+
+def test_candidate_lists_instead_of_dense_bounds(spectral):
+    """sgz_corr_set_screen_output(1): the spectral kernel lists the windows whose upper bound reaches their block's
+    largest lower bound, and the search over bounds filters that list instead of scanning dense upper bounds.  Same
+    records as from a dense run (for the k-th bound filter and for every file), dense readers refuse, a dense run
+    afterwards serves them again, and two list runs in a row (the second list's counter was not cleared by a
+    consumer) are both complete."""
+    import strugatzki_amd as S
+    from strugatzki_amd import _native as N
+    ctx = spectral
+    L, ts, nf, frames, k = 300, 20, 9, 5200, 3
+    db = synth_db(nf, frames, make_plants(3, L, nf, frames, ts))
+    tgt = synth_target(ts, L)
+    norms = norms_default()
+    want, sims, boosts = O.correlation_run(corr_config(ts, L, num_matches=k), tgt, norms, db)
+    _load(ctx, db, norms)
+    ctx.corr_set_target(tgt[ts:ts + L], 0.5, 8.0)
+    ctx.corr_run_screen_f16(0, nf)
+    dense_top, dense_T = ctx.corr_compact_top(0, nf, k, 1 << 16)
+    dense_all = ctx.corr_compact_bounded(0, nf, nf, 1 << 16)
+    key = lambda a: sorted((int(c["file"]), int(c["offset"]), float(c["sim"]), float(c["boost"])) for c in a)
+    try:
+        ctx.set_screen_output(True)
+        for _ in range(2):
+            ctx.corr_run_screen_f16(0, nf)
+        top, T = ctx.corr_compact_top(0, nf, k, 1 << 16)
+        every = ctx.corr_compact_bounded(0, nf, nf, 1 << 16)
+        assert T == dense_T and key(top) == key(dense_top) and key(every) == key(dense_all)
+        with pytest.raises(N.NativeError):
+            ctx.corr_read_dense(0)
+        with pytest.raises(N.NativeError):
+            ctx.corr_compact(0, nf, 0.1, 1 << 16)
+        ctx.corr_run_screen_f16(0, nf)
+        top2, T2 = ctx.corr_compact_top(0, nf, k, 1 << 16)
+        assert T2 == dense_T and key(top2) == key(dense_top)
+    finally:
+        ctx.set_screen_output(False)
+    ctx.corr_run_screen_f16(0, nf)
+    gs, gb = ctx.corr_read_dense(0)
+    assert np.all(gs.astype(np.float64) >= sims[0])
+    np.testing.assert_allclose(gb, boosts[0], rtol=1e-5)
+    got = S.search(ctx, S.SearchParams(k, 1, 0, STEP))
+    assert [(g.sim, g.file, g.start, g.stop) for g in got] == [(w.sim, w.file, w.start, w.stop) for w in want]
