@@ -266,23 +266,35 @@ __global__ __launch_bounds__(N / 16) void corr_fft_kernel(const FftBlock *__rest
     const float absT = (fg.epsT * (fg.a01 * bn.x + fg.aT * bn.z + pT + beta * pS) + fg.epsUT * pT) * 1.0001f * fg.kT;
     const float absS = (fg.epsT * (fg.aP * bn.y + fg.aS * bn.w + pT * rbeta * 1.0001f + pS) + fg.epsUS * pS) * 1.0001f * fg.kS;
 
+    // two neighbouring bins per thread and step: 16-byte loads (1 KB of a channel's spectrum per wave instruction)
+    const float4 *xs4 = reinterpret_cast<const float4 *>(xs), *as4 = reinterpret_cast<const float4 *>(aspec);
 #pragma unroll 2
-    for (int m = 0; m < 8; m++) {
-        const int j = tid + m * T;
-        float2 zt = c_mul(aspec[j], xs[j]);
-        float2 zs = make_float2(0.0f, 0.0f);
+    for (int m = 0; m < 4; m++) {
+        const int h = tid + m * T, j = 2 * h;  // bins j and j + 1
+        const float4 a0 = as4[h], x0 = xs4[h];
+        float2 zt0 = c_mul(make_float2(a0.x, a0.y), make_float2(x0.x, x0.y));
+        float2 zt1 = c_mul(make_float2(a0.z, a0.w), make_float2(x0.z, x0.w));
+        float2 zs0 = make_float2(0.0f, 0.0f), zs1 = make_float2(0.0f, 0.0f);
 #pragma unroll
         for (int c = 1; c < numCh; c++) {
-            const float2 a = aspec[(size_t)c * NH + j], x = xs[(size_t)c * NH + j];
-            zs.x = fmaf(a.x, x.x, zs.x);
-            zs.x = fmaf(-a.y, x.y, zs.x);
-            zs.y = fmaf(a.x, x.y, zs.y);
-            zs.y = fmaf(a.y, x.x, zs.y);
+            const float4 a = as4[(size_t)c * (NH / 2) + h], x = xs4[(size_t)c * (NH / 2) + h];
+            zs0.x = fmaf(a.x, x.x, zs0.x);
+            zs0.x = fmaf(-a.y, x.y, zs0.x);
+            zs0.y = fmaf(a.x, x.y, zs0.y);
+            zs0.y = fmaf(a.y, x.x, zs0.y);
+            zs1.x = fmaf(a.z, x.z, zs1.x);
+            zs1.x = fmaf(-a.w, x.w, zs1.x);
+            zs1.y = fmaf(a.z, x.w, zs1.y);
+            zs1.y = fmaf(a.w, x.z, zs1.y);
         }
-        zs.x *= beta;
-        zs.y *= beta;
-        buf[fft_phys((N - j) & (N - 1))] = make_float2(zt.x + zs.y, zs.x - zt.y);
-        buf[fft_phys(j)] = make_float2(zt.x - zs.y, zt.y + zs.x);
+        zs0.x *= beta;
+        zs0.y *= beta;
+        zs1.x *= beta;
+        zs1.y *= beta;
+        buf[fft_phys((N - j) & (N - 1))] = make_float2(zt0.x + zs0.y, zs0.x - zt0.y);
+        buf[fft_phys(j)] = make_float2(zt0.x - zs0.y, zt0.y + zs0.x);
+        buf[fft_phys(N - j - 1)] = make_float2(zt1.x + zs1.y, zs1.x - zt1.y);
+        buf[fft_phys(j + 1)] = make_float2(zt1.x - zs1.y, zt1.y + zs1.x);
     }
     if (tid == 0) {  // bin 0 holds two real bins, DC and Nyquist: component-wise products
         float2 zt = make_float2(aspec[0].x * xs[0].x, aspec[0].y * xs[0].y);
