@@ -268,7 +268,7 @@ __global__ __launch_bounds__(N / 16) void corr_fft_kernel(const FftBlock *__rest
 
     // two neighbouring bins per thread and step: 16-byte loads (1 KB of a channel's spectrum per wave instruction)
     const float4 *xs4 = reinterpret_cast<const float4 *>(xs), *as4 = reinterpret_cast<const float4 *>(aspec);
-#pragma unroll 2
+#pragma unroll 4
     for (int m = 0; m < 4; m++) {
         const int h = tid + m * T, j = 2 * h;  // bins j and j + 1
         const float4 a0 = as4[h], x0 = xs4[h];
