@@ -573,7 +573,7 @@ __global__ __launch_bounds__(256) void window_static_kernel(const FileDesc *__re
         const long long o = (long long)td.o0 + k * 256 + threadIdx.x;
         if (o < fd.num_windows) {
             const WindowStatic ws = window_static(L, numCh, hp, (unsigned)o, window_records(hp, (unsigned)o, L), (double)fd.cT);
-            if (compactWindows > 0) {  // the layout of the spectral kernel: 20 bytes per window in four arrays
+            if (compactWindows > 0) {  // the layout of the spectral kernel: a 16-byte record and a value of its own per window
                 spectral_statics_store(reinterpret_cast<float *>(wstat), compactWindows, fd.win_off + o, ws);
             } else {
                 wstat[2 * (fd.win_off + o)] = make_float4(ws.rsdT, ws.dmT, ws.gT, ws.lnAvg);

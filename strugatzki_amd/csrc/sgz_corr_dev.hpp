@@ -240,40 +240,37 @@ __device__ __forceinline__ WindowCoeffs window_coeffs(const CorrParams &cp, cons
 }
 
 // The spectral kernel streams the statics of every window of a block (it is bound by memory traffic), so it
-// keeps them in 20 instead of 32 bytes per window, as four arrays over all windows of the layout
-// (`stride` = the window count rounded up to an even number): 1 / sd of the two channel groups, ln of the average
-// loudness, and four half-precision numbers rounded up, g and u = h + |dm| / sd of both groups.  The mean-offset
+// keeps them in 20 instead of 32 bytes per window: a 16-byte record (one load; 1 / sd of the two channel groups and
+// four half-precision numbers rounded up, g and u = h + |dm| / sd of both groups) and, in an array of its own
+// because most launches do not read it, ln of the average loudness.  The mean-offset
 // term of the similarity, (w sum a' / (aStd n)) dm / sd, is not evaluated: a' is centred, so sum a' is what
 // rounding left of zero, and the term's magnitude goes into the error bound instead (it has the same factor as
 // h there); sqrt(1 + (dm / sd)^2) is replaced by its bound 1 + u.
 struct SpectralStatics {
-    const float *rsdT, *rsdS, *lnAvg;
-    const uint2 *gu;  // halves: x = gT | uT << 16, y = gS | uS << 16
+    const float4 *rec;   // per window: 1 / sd of the loudness channel, of the others, g | u of both as halves (2 words)
+    const float *lnAvg;  // per window: ln of the average loudness
 };
-__host__ __device__ inline long long spectral_statics_stride(long long windows) { return (windows + 1) & ~1ll; }
+__host__ __device__ inline long long spectral_statics_stride(long long windows) { return windows; }
 __host__ __device__ inline size_t spectral_statics_floats(long long windows) { return 5 * (size_t)spectral_statics_stride(windows); }
+// (floats from the base of the buffer to the ln array)
+__host__ __device__ inline long long spectral_statics_ln_offset(long long windows) { return 4 * spectral_statics_stride(windows); }
 __device__ __forceinline__ SpectralStatics spectral_statics(float *base, long long windows)
 {
-    const long long W = spectral_statics_stride(windows);
-    return SpectralStatics{base, base + W, base + 2 * W, reinterpret_cast<const uint2 *>(base + 3 * W)};
+    return SpectralStatics{reinterpret_cast<const float4 *>(base), base + spectral_statics_ln_offset(windows)};
 }
 __device__ __forceinline__ void spectral_statics_store(float *base, long long windows, long long w, const WindowStatic &ws)
 {
-    const long long W = spectral_statics_stride(windows);
-    base[w] = ws.rsdT;
-    base[W + w] = ws.rsdS;
-    base[2 * W + w] = ws.lnAvg;
     float uT = half_from_bits(ws.hTS & 0xffffu) + fabsf(ws.dmT * ws.rsdT);
     float uS = half_from_bits(ws.hTS >> 16) + fabsf(ws.dmS * ws.rsdS);
     if (!(uT >= 0.0f)) uT = INFINITY;  // NaN (0 * inf: a window without spread): g is +inf there and decides
     if (!(uS >= 0.0f)) uS = INFINITY;
     const float gT = ws.gT >= 0.0f ? ws.gT : INFINITY, gS = ws.gS >= 0.0f ? ws.gS : INFINITY;
-    reinterpret_cast<uint2 *>(base + 3 * W)[w] = make_uint2(half_bits_up(gT) | (half_bits_up(uT * 1.0001f) << 16),
-                                                            half_bits_up(gS) | (half_bits_up(uS * 1.0001f) << 16));
+    reinterpret_cast<float4 *>(base)[w] =
+        make_float4(ws.rsdT, ws.rsdS, __uint_as_float(half_bits_up(gT) | (half_bits_up(uT * 1.0001f) << 16)),
+                    __uint_as_float(half_bits_up(gS) | (half_bits_up(uS * 1.0001f) << 16)));
+    base[spectral_statics_ln_offset(windows) + w] = ws.lnAvg;
 }
 
-// absT / absS = eta |a'| |x_block| / (aStd n) of the channel group, which times 1 / sd bounds the error of the
-// normalised cross term from the fp32 transforms; relErr covers the fp32 rounding of the target values.
 // The boost of a window from ln of its average loudness, as the screening kernels evaluate it (fp32, hardware
 // exp2: within 1e-5 of calcBoost, impl/FeatureCorrelationImpl.scala:73-78).
 __device__ __forceinline__ float screen_boost(float lnAvgIn, float lnAvg)

@@ -333,10 +333,11 @@ __global__ __launch_bounds__(N / 16) void corr_fft_kernel(const FftBlock *__rest
             for (int u = 0; u < 4; u++) {
                 const int k = tid + (m0 + u) * T;
                 const long long w = bd.win + (k < bd.valid ? k : 0);
-                rsdT[u] = st.rsdT[w];
-                rsdS[u] = st.rsdS[w];
+                const float4 r = st.rec[w];
+                rsdT[u] = r.x;
+                rsdS[u] = r.y;
+                gu[u] = make_uint2(__float_as_uint(r.z), __float_as_uint(r.w));
                 lnAvg[u] = needLn ? st.lnAvg[w] : 0.0f;
-                gu[u] = st.gu[w];
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -640,7 +641,7 @@ int boost_source(sgz_context *ctx, int file_begin, int file_end, hipStream_t str
     }
     if (lazy == 0) return SGZ_OK;
     if (lazy == total && ctx->fg.N > 0 && ctx->boost_lazy_ln == ctx->cp.lnAvgIn) {
-        *lnAvg = ctx->d_wstat_h + 2 * spectral_statics_stride(ctx->total_windows);
+        *lnAvg = ctx->d_wstat_h + spectral_statics_ln_offset(ctx->total_windows);
         return SGZ_OK;
     }
     return boost_materialize(ctx, file_begin, file_end, stream);
