@@ -122,10 +122,11 @@ def pmc_traffic_bytes(kernel: str, summary: str = "r02_pmc_summary.csv"):
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # a step is a fifth of a millisecond: the defaults keep the GPU busy for about a second (long enough for the
-    # clocks to settle and for a once-a-second utilisation sampler to see the run) and still finish at once
-    ap.add_argument("--steps", type=int, default=5000)
-    ap.add_argument("--warmup", type=int, default=200)
+    # a step is less than a tenth of a millisecond: the defaults keep the GPU busy for about two seconds (long
+    # enough for the clocks to settle and for a once-a-second utilisation sampler to see the run) and still finish
+    # at once
+    ap.add_argument("--steps", type=int, default=20000)
+    ap.add_argument("--warmup", type=int, default=500)
     ap.add_argument("--files-per-gpu", type=int, default=None,
                     help="database files per GPU (default: 120 at N=1, 1500 at N>1)")
     ap.add_argument("--file-seconds", type=float, default=300.0)
