@@ -357,3 +357,39 @@ def test_candidate_lists_instead_of_dense_bounds(spectral):
     np.testing.assert_allclose(gb, boosts[0], rtol=1e-5)
     got = S.search(ctx, S.SearchParams(k, 1, 0, STEP))
     assert [(g.sim, g.file, g.start, g.stop) for g in got] == [(w.sim, w.file, w.start, w.stop) for w in want]
+
+
+def test_candidate_list_overflow_falls_back(spectral):
+    """Files whose frames repeat with period 2: every second window of a file has the file's largest similarity
+    (to the last bit or within the bound), so the list of windows that reach their block's bound holds thousands
+    of records per block and overflows.  The search then takes its other paths and still returns the oracle's
+    matches; so does a database where only one file is like that."""
+    import strugatzki_amd as S
+    ctx = spectral
+    L, ts, frames = 300, 7, 16000
+    norms = norms_default()
+    tgt = synth_target(ts, L)
+    pair = O.synth_file(SEED, 50, 2, NUM_CH)
+    periodic = np.tile(pair, (frames // 2, 1)).astype(np.float32)
+    plain = synth_db(3, frames, make_plants(2, L, 3, frames, ts))
+    for db in ([periodic, periodic.copy() * np.float32(0.9) + np.float32(0.01)], [plain[0], periodic, plain[1], plain[2]]):
+        for k, npf in ((3, 1), (2, 1)):
+            want, _, _ = O.correlation_run(corr_config(ts, L, num_matches=k, num_per_file=npf), tgt, norms, db, dense=False)
+            _load(ctx, db, norms)
+            ctx.corr_set_target(tgt[ts:ts + L], 0.5, 8.0)
+            got = S.search(ctx, S.SearchParams(k, npf, 0, STEP))
+            assert ctx.screen_kernel_in_use == "spectral"
+            assert [(g.file, g.start, g.stop) for g in got] == [(w.file, w.start, w.stop) for w in want]
+            assert all(abs(g.sim - w.sim) <= 1.2e-7 for g, w in zip(got, want))
+    # the list itself: more records than it holds -> the compaction reports an overflow, as for too small a buffer
+    from strugatzki_amd import _native as N
+    _load(ctx, [periodic, periodic], norms)
+    ctx.corr_set_target(tgt[ts:ts + L], 0.5, 8.0)
+    try:
+        ctx.set_screen_output(True)
+        ctx.corr_run_screen_f16(0, 2)
+        with pytest.raises(N.NativeError) as err:
+            ctx.corr_compact_bounded(0, 2, 2, 1 << 16)
+        assert err.value.code == N.SGZ_E_OVERFLOW
+    finally:
+        ctx.set_screen_output(False)
