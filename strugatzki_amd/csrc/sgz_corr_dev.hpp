@@ -286,6 +286,8 @@ __device__ __forceinline__ int screen_gate(float boost, float maxBoost)
     return boost > maxBoost * 0.99999f ? 2 : 1;
 }
 
+// absT / absS: every error of a normalised cross term that scales with 1 / sd of the window (the transforms' share,
+// eta |a'| |x_block| / (aStd n), and the rounding of the normalised values at the size of the file's level).
 __device__ __forceinline__ WindowCoeffs window_coeffs_spectral(const CorrParams &cp, float rsdT, float rsdS, uint2 gu,
                                                                float relErr, float absT, float absS, int gate)
 {

@@ -31,7 +31,10 @@
 //   * so the kernel BALANCES the two parts of the inverse transform: Zs is scaled by beta = |a_T||x_T| / (|a_S||x_S|)
 //     (per block, from the block's norms) before it is packed, and the imaginary output divided by it.  Each cross
 //     term's inverse-transform error is then 2 eps of its own norm product, whatever the other group's energy.
-// Plus the roundings outside the transforms (operands, products, channel sums, the scaling).  At N = 16384, L = 2584
+// Plus the roundings outside the transforms (operands, products, channel sums, the scaling), and one that does not
+// scale with the block's norm: a normalised value is rounded at the size of the value itself, (x - min) / range, before
+// the file's centring constant is taken off, so a file whose level is far from zero carries 2^-24 of that level as
+// noise on every centred value -- against a window's cross term at most 2^-23 |level| / sd (FftGeom::levelErr).  At N = 16384, L = 2584
 // the bound comes to about 1e-4 of the similarity where half-precision products give 1e-3.
 #include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
@@ -235,7 +238,8 @@ __global__ __launch_bounds__(256) void boost_fill_kernel(float *wstat, long long
 //   2. inverse transform in LDS: w[k] = crossT[k] + i crossS[k];
 //   3. per window the bounds from its cached statics (sgz::SpectralStatics, 20 bytes per window).
 template <int N, int NCH>
-__global__ __launch_bounds__(N / 16) void corr_fft_kernel(const FftBlock *__restrict__ blocks,
+__global__ __launch_bounds__(N / 16) void corr_fft_kernel(const FileDesc *__restrict__ files,
+                                                          const FftBlock *__restrict__ blocks,
                                                           const float2 *__restrict__ spec,
                                                           const float2 *__restrict__ aspec,
                                                           const float2 *__restrict__ tab,
@@ -263,8 +267,11 @@ __global__ __launch_bounds__(N / 16) void corr_fft_kernel(const FftBlock *__rest
     float beta = pT / pS;
     if (!(beta >= 2.4414062e-4f && beta <= 4096.0f)) beta = beta > 4096.0f ? 4096.0f : (beta < 2.4414062e-4f ? 2.4414062e-4f : 1.0f);
     const float rbeta = 1.0f / beta;
-    const float absT = (fg.epsT * (fg.a01 * bn.x + fg.aT * bn.z + pT + beta * pS) + fg.epsUT * pT) * 1.0001f * fg.kT;
-    const float absS = (fg.epsT * (fg.aP * bn.y + fg.aS * bn.w + pT * rbeta * 1.0001f + pS) + fg.epsUS * pS) * 1.0001f * fg.kS;
+    const FileDesc fd = files[bd.file];
+    const float absT = (fg.epsT * (fg.a01 * bn.x + fg.aT * bn.z + pT + beta * pS) + fg.epsUT * pT) * 1.0001f * fg.kT +
+                       fg.levelErr * fabsf(fd.cT);
+    const float absS = (fg.epsT * (fg.aP * bn.y + fg.aS * bn.w + pT * rbeta * 1.0001f + pS) + fg.epsUS * pS) * 1.0001f * fg.kS +
+                       fg.levelErr * fabsf(fd.cS);
 
     // two neighbouring bins per thread and step: 16-byte loads (1 KB of a channel's spectrum per wave instruction)
     const float4 *xs4 = reinterpret_cast<const float4 *>(xs), *as4 = reinterpret_cast<const float4 *>(aspec);
@@ -469,6 +476,7 @@ int fft_target(sgz_context *ctx, hipStream_t stream)
     fg.aP = (float)(std::sqrt(ctx->tgt_nrmT * ctx->tgt_nrmT + 2.0 * ctx->tgt_nrmS * ctx->tgt_nrmS) * up);
     fg.kT = (float)(up / (ctx->cp.aStdT * nT));
     fg.kS = numCh > 1 ? (float)(up / (ctx->cp.aStdS * nS)) : 0.0f;
+    fg.levelErr = ctx->norm.enabled ? (float)std::ldexp(1.0, -23) : 0.0f;
     fg.relErr = (float)std::ldexp(1.0, -22);
     ctx->aspec_dirty = false;
     return SGZ_OK;
@@ -705,12 +713,12 @@ int fft_screen_launch(sgz_context *ctx, int file_begin, int file_end, hipStream_
     auto launch = [&](auto kern) -> int {
         if ((rc = set_lds(ctx, kern, lds))) return rc;
         if (start || stop)
-            hipExtLaunchKernelGGL(kern, dim3(b1 - b0), dim3(N / 16), lds, stream, start, stop, 0, ctx->d_fblocks + b0,
+            hipExtLaunchKernelGGL(kern, dim3(b1 - b0), dim3(N / 16), lds, stream, start, stop, 0, ctx->d_files, ctx->d_fblocks + b0,
                                   ctx->d_spec, ctx->d_aspec, ctx->d_fft_tab, ctx->d_blknorm + b0, ctx->d_blklnmin + b0,
                                   ctx->d_wstat_h, ctx->total_windows, ctx->cp, fg, simOut, (float *)nullptr,
                                   lokey, lokeyNext, ctx->d_hflags, pre);
         else
-            hipLaunchKernelGGL(kern, dim3(b1 - b0), dim3(N / 16), lds, stream, ctx->d_fblocks + b0, ctx->d_spec,
+            hipLaunchKernelGGL(kern, dim3(b1 - b0), dim3(N / 16), lds, stream, ctx->d_files, ctx->d_fblocks + b0, ctx->d_spec,
                                ctx->d_aspec, ctx->d_fft_tab, ctx->d_blknorm + b0, ctx->d_blklnmin + b0,
                                ctx->d_wstat_h, ctx->total_windows, ctx->cp, fg, simOut, (float *)nullptr,
                                lokey, lokeyNext, ctx->d_hflags, pre);

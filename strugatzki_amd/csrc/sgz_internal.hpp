@@ -104,6 +104,10 @@ struct FftGeom {
     // other channels, channels 0 and 1 together (they share a packed transform), sqrt(|a_T|^2 + 2 |a_S|^2) (an upper
     // bound of the norm over all packed pairs an other channel sits in) -- each rounded up; kT / kS = 1 / (aStd n).
     float epsT, epsUT, epsUS;
+    // normalised values are formed as (x - min) * (1 / range) in fp32, rounded once at the size of the value itself,
+    // which for a file far from zero is its level, not its spread: levelErr * |centring constant| / sd per window
+    // (0 without normalisation, where the centred value is one exact-or-correctly-rounded subtraction)
+    float levelErr;
     float aT, aS, a01, aP;
     float kT, kS;
     float relErr;          // fp32 rounding of the target values, relative to |a'| |x_window|
