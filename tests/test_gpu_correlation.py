@@ -382,7 +382,7 @@ def test_other_channel_counts(ctx, num_ch):
         assert abs(g.sim - w.sim) <= 1.2e-7
 
 
-@pytest.mark.parametrize("case", ["flat_stretches", "large_values", "offset_channels", "steps"])
+@pytest.mark.parametrize("case", ["flat_stretches", "large_values", "offset_channels", "steps", "far_level"])
 def test_bounds_hold_on_awkward_data(ctx, case):
     """The half-precision bounds on data built to stress them: stretches with almost no spread (the variance
     term of the bound), normalised values in the hundreds (half-precision range, large prefix sums in the fp32
@@ -408,6 +408,11 @@ def test_bounds_hold_on_awkward_data(ctx, case):
             x[frames // 3:] += np.float32(2.0)
             x[2 * frames // 3:] -= np.float32(3.5)
             x[:, 0] = np.abs(x[:, 0]) + np.float32(0.05)
+        elif case == "far_level" and f >= 2:
+            # normalised values near 300 with a spread of 0.05: the fp32 normalisation itself rounds at a thousandth
+            # of the spread
+            r = (rng.standard_normal((frames, x.shape[1])) * 0.05).astype(np.float32)
+            db[f] = (np.float32(300.0) + r) * (norms[:, 1] - norms[:, 0]) + norms[:, 0]
     tgt = synth_target(ts, L)
     cfg = corr_config(ts, L, num_matches=4, num_per_file=1)
     want, sims, boosts = O.correlation_run(cfg, tgt, norms, db)

@@ -152,12 +152,13 @@ def test_without_normalisation(spectral):
     assert [(g.sim, g.file, g.start, g.stop) for g in got] == [(w.sim, w.file, w.start, w.stop) for w in want]
 
 
-@pytest.mark.parametrize("case", ["flat_stretches", "large_values", "offset_channels", "steps", "ripple"])
+@pytest.mark.parametrize("case", ["flat_stretches", "large_values", "offset_channels", "steps", "ripple", "far_level"])
 def test_bounds_hold_on_awkward_data(spectral, case):
     """Data built to stress the bound: stretches with almost no spread (a window's 1 / sd is large against the
     block's norm, which the error term is proportional to), values in the hundreds, channel levels far from the
     target's, level steps inside a block (the block norm is dominated by frames outside the window), and files
-    that sit at one level with a ripple of 1e-3 (cross terms are sums of many small products of both signs)."""
+    that sit at one level with a ripple of 1e-3 (cross terms are sums of many small products of both signs), and
+    files whose level is thousands of times their spread (the normalisation's own rounding shows)."""
     import strugatzki_amd as S
     from strugatzki_amd.engine import match_tuple
     ctx = spectral
@@ -182,6 +183,11 @@ def test_bounds_hold_on_awkward_data(spectral, case):
         elif case == "ripple" and f >= 3:
             r = (rng.standard_normal((frames, NUM_CH)) * 1e-3).astype(np.float32)
             db[f] = (np.float32(0.4) + r) * (norms[:, 1] - norms[:, 0]) + norms[:, 0]
+        elif case == "far_level" and f >= 2:
+            # normalised values near 300 with a spread of 0.05: the fp32 normalisation rounds at 3e-5, a thousandth
+            # of the spread, and differently in the kernel (multiplication by a reciprocal) than in the exact path
+            r = (rng.standard_normal((frames, NUM_CH)) * 0.05).astype(np.float32)
+            db[f] = (np.float32(300.0) + r) * (norms[:, 1] - norms[:, 0]) + norms[:, 0]
     tgt = synth_target(ts, L)
     cfg = corr_config(ts, L, num_matches=4, num_per_file=1)
     want, sims, boosts = O.correlation_run(cfg, tgt, norms, db)
