@@ -273,6 +273,11 @@ __global__ __launch_bounds__(N / 16) void corr_fft_kernel(const FileDesc *__rest
     const float absS = (fg.epsT * (fg.aP * bn.y + fg.aS * bn.w + pT * rbeta * 1.0001f + pS) + fg.epsUS * pS) * 1.0001f * fg.kS +
                        fg.levelErr * fabsf(fd.cS);
 
+    // SGZ_PROBE (timing builds of tools/spectral_phase_probe.sh only; results are wrong): 1 leaves out the spectra
+    // phase, 2 the transform, 3 everything after the transform
+#if defined(SGZ_PROBE) && SGZ_PROBE == 1
+    for (int m = 0; m < 16; m++) buf[fft_phys(tid + m * T)] = make_float2(0.001f * tid, 0.002f * m);
+#else
     // two neighbouring bins per thread and step: 16-byte loads (1 KB of a channel's spectrum per wave instruction)
     const float4 *xs4 = reinterpret_cast<const float4 *>(xs), *as4 = reinterpret_cast<const float4 *>(aspec);
 #pragma unroll 4
@@ -314,8 +319,15 @@ __global__ __launch_bounds__(N / 16) void corr_fft_kernel(const FileDesc *__rest
         buf[fft_phys(0)] = make_float2(zt.x, zs.x * beta);
         buf[fft_phys(NH)] = make_float2(zt.y, zs.y * beta);
     }
+#endif
     __syncthreads();
+#if !defined(SGZ_PROBE) || SGZ_PROBE != 2
     fft_lds<N, 1>(buf, tab, tid);
+#endif
+#if defined(SGZ_PROBE) && SGZ_PROBE == 3
+    if (tid == 0 && simOut) simOut[bd.win] = buf[5].x;
+    return;
+#endif
 
     CorrParams cpf = cp;  // the statistics of the fp32 target values
     cpf.sumAT = fg.sumAT;
