@@ -132,7 +132,7 @@ def main() -> int:
     ap.add_argument("--file-seconds", type=float, default=300.0)
     ap.add_argument("--target-seconds", type=float, default=None,
                     help="target length (default: 30 at N=1, 60 at N>1)")
-    ap.add_argument("--exact-steps", type=int, default=30,
+    ap.add_argument("--exact-steps", type=int, default=100,
                     help="steps of the reference-precision search (fp64 kernel, every window) timed after the main "
                          "loop at N=1 for roofline.exact; 0 disables")
     ap.add_argument("--num-matches", type=int, default=10)
@@ -155,7 +155,7 @@ def main() -> int:
     ap.add_argument("--screen-kernel", choices=["auto", "matrix", "spectral"], default="auto",
                     help="kernel behind the certified bounds: fp32 block transforms (spectral, HBM-bound), "
                          "half-precision products on the matrix cores (matrix), or the library's choice")
-    ap.add_argument("--other-steps", type=int, default=400,
+    ap.add_argument("--other-steps", type=int, default=2000,
                     help="steps of the same search with the screening kernel the library did not pick, timed after "
                          "the main loop at N=1 (roofline.matrix_cores / roofline.spectral); 0 disables")
     args = ap.parse_args()
