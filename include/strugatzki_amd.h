@@ -524,6 +524,25 @@ SGZ_API int sgz_extract(sgz_context *ctx, const float *pcm, int64_t num_frames, 
                         int channels_behavior, float *features_out, int64_t capacity_frames,
                         int64_t *num_out);
 
+/* The same from samples as audio files hold them (AudioFile.openRead of FeatureExtractionImpl decodes them on the
+ * JVM, impl/FeatureExtractionImpl.scala:34; here the device does): 16-, 24- or 32-bit integers -- v / 2^(bits-1) --
+ * or 32-bit floats, in the host's (little endian) or in big-endian byte order, interleaved, tightly packed.  Half
+ * the bytes of float samples cross the bus for 16-bit audio, and no host loop touches a sample.
+ * sgz_extract(...) == sgz_extract_pcm(..., SGZ_PCM_F32, ...). */
+enum {
+    SGZ_PCM_F32 = 0,
+    SGZ_PCM_F32_BE = 1,
+    SGZ_PCM_S16 = 2,
+    SGZ_PCM_S16_BE = 3,
+    SGZ_PCM_S24 = 4,
+    SGZ_PCM_S24_BE = 5,
+    SGZ_PCM_S32 = 6,
+    SGZ_PCM_S32_BE = 7
+};
+SGZ_API int sgz_extract_pcm(sgz_context *ctx, const void *samples, int sample_format, int64_t num_frames,
+                            int num_channels, double sample_rate, int fft_size, int fft_overlap, int num_coeffs,
+                            int channels_behavior, float *features_out, int64_t capacity_frames, int64_t *num_out);
+
 /* ---- whole processors from their XML configs (host side) ------------------ */
 
 /* Progress observer: called with a value in [0, 1] between GPU launches; a

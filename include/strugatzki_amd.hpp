@@ -218,6 +218,19 @@ struct AudioData {
 };
 // Reads AIFF / AIFF-C (16/24/32-bit PCM, fl32, fl64) and RIFF-WAVE (PCM, float).
 AudioData readAudioFile(const std::string &path);
+// The same files with the samples left as the file holds them where sgz_extract_pcm decodes that layout (16-, 24-
+// and 32-bit integers, 32-bit floats, either byte order): `sampleFormat` is one of SGZ_PCM_*, the interleaved
+// samples start at bytes[offset].  Any other layout (8-bit, 64-bit floats) comes back decoded, as SGZ_PCM_F32.
+struct PcmData {
+    int numChannels = 0;
+    double sampleRate = 0;
+    int64_t numFrames = 0;
+    int sampleFormat = SGZ_PCM_F32;
+    std::vector<unsigned char> bytes;
+    size_t offset = 0;
+    const void *samples() const { return bytes.data() + offset; }
+};
+PcmData readAudioFilePcm(const std::string &path);
 // Writes a 32-bit float AIFF-C ("fl32", big endian), the format the reference
 // produces for feature files (impl/NonRealtimeProcessor.scala:164-165).
 void writeFloatAiff(const std::string &path, const AudioData &data);

@@ -156,6 +156,11 @@ SIGNATURES = {
         [_vp, _vp, C.c_int64, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int64,
          C.POINTER(C.c_int64)],
     ),
+    "sgz_extract_pcm": (
+        C.c_int,
+        [_vp, _vp, C.c_int, C.c_int64, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int64,
+         C.POINTER(C.c_int64)],
+    ),
     "sgz_run_extraction_xml": (C.c_int, [_vp, C.c_char_p, _vp, _vp]),
     "sgz_run_crosssimilarity_xml": (C.c_int, [_vp, C.c_char_p, _vp, _vp]),
     "sgz_run_correlation_xml": (C.c_int, [_vp, C.c_char_p, _vp, _vp, C.POINTER(_vp)]),

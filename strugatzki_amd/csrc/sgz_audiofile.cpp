@@ -128,7 +128,36 @@ void decode(const unsigned char *src, size_t count, int bits, Fmt fmt, bool bigE
     }
 }
 
-AudioData readAiff(Reader &r)
+// The layout sgz_extract_pcm decodes on the device, or -1.
+int deviceFormat(int bits, Fmt fmt, bool bigEndian)
+{
+    if (fmt == Fmt::Float32) return bigEndian ? SGZ_PCM_F32_BE : SGZ_PCM_F32;
+    if (fmt != Fmt::Int) return -1;
+    switch (bits) {
+        case 16: return bigEndian ? SGZ_PCM_S16_BE : SGZ_PCM_S16;
+        case 24: return bigEndian ? SGZ_PCM_S24_BE : SGZ_PCM_S24;
+        case 32: return bigEndian ? SGZ_PCM_S32_BE : SGZ_PCM_S32;
+        default: return -1;
+    }
+}
+
+// The sample data of a parsed file: decoded into a.frames, or -- when `raw` is given and the device decodes the
+// layout -- handed over as the file's own bytes (the reader's buffer moves into raw->bytes).
+void takeSamples(Reader &r, AudioData &a, size_t start, size_t count, int bits, Fmt fmt, bool bigEndian,
+                 bool wavUnsigned8, PcmData *raw)
+{
+    const int df = raw ? deviceFormat(bits, fmt, bigEndian) : -1;
+    if (df >= 0) {
+        raw->sampleFormat = df;
+        raw->offset = start;
+        raw->bytes = std::move(r.d);
+        return;
+    }
+    a.frames.resize(count);
+    if (count) decode(&r.d[start], count, bits, fmt, bigEndian, wavUnsigned8, a.frames.data());
+}
+
+AudioData readAiff(Reader &r, PcmData *raw)
 {
     r.p = 8;
     const std::string form = r.tag();
@@ -180,13 +209,12 @@ AudioData readAiff(Reader &r)
     if (count) {
         if (!ssnd || ssndBytes < count * (size_t)(bits / 8) || ssnd + count * (size_t)(bits / 8) > r.d.size())
             throw Error(SGZ_E_IO, "AIFF sound data truncated: " + r.path);
-        a.frames.resize(count);
-        decode(&r.d[ssnd], count, bits, fmt, big, false, a.frames.data());
+        takeSamples(r, a, ssnd, count, bits, fmt, big, false, raw);
     }
     return a;
 }
 
-AudioData readWav(Reader &r)
+AudioData readWav(Reader &r, PcmData *raw)
 {
     r.p = 8;
     if (r.tag() != "WAVE") throw Error(SGZ_E_IO, "not a WAVE file: " + r.path);
@@ -222,14 +250,14 @@ AudioData readWav(Reader &r)
     const size_t fb = (size_t)a.numChannels * (bits / 8);
     a.numFrames = (int64_t)(dataBytes / fb);
     const size_t count = (size_t)a.numFrames * a.numChannels;
-    a.frames.resize(count);
     const Fmt fmt = format == 3 ? (bits == 64 ? Fmt::Float64 : Fmt::Float32) : Fmt::Int;
-    if (count) decode(&r.d[data], count, bits, fmt, false, bits == 8, a.frames.data());
+    if (format == 3 && bits != 32 && bits != 64) throw Error(SGZ_E_IO, "unsupported WAVE format in " + r.path);
+    if (count) takeSamples(r, a, data, count, bits, fmt, false, bits == 8, raw);
     return a;
 }
 
 // NeXT / Sun ".snd": big-endian header (magic, data offset, data size, encoding, rate, channels), then samples
-AudioData readNext(Reader &r)
+AudioData readNext(Reader &r, PcmData *raw)
 {
     r.p = 4;
     const uint32_t offset = r.be32(), size = r.be32(), enc = r.be32(), rate = r.be32(), ch = r.be32();
@@ -253,8 +281,7 @@ AudioData readNext(Reader &r)
     const size_t fb = (size_t)a.numChannels * (bits / 8);
     a.numFrames = (int64_t)(bytes / fb);
     const size_t count = (size_t)a.numFrames * a.numChannels;
-    a.frames.resize(count);
-    if (count) decode(&r.d[offset], count, bits, fmt, true, false, a.frames.data());
+    if (count) takeSamples(r, a, offset, count, bits, fmt, true, false, raw);
     return a;
 }
 
@@ -274,15 +301,37 @@ void writeAll(const std::string &path, const std::vector<unsigned char> &o)
 
 }  // namespace
 
-AudioData readAudioFile(const std::string &path)
+namespace {
+
+AudioData readAny(const std::string &path, PcmData *raw)
 {
     Reader r(path);
     if (r.d.size() < 12) throw Error(SGZ_E_IO, "file too short: " + path);
     const std::string magic(reinterpret_cast<const char *>(r.d.data()), 4);
-    if (magic == "FORM") return readAiff(r);
-    if (magic == "RIFF") return readWav(r);
-    if (magic == ".snd" && r.d.size() >= 24) return readNext(r);
+    if (magic == "FORM") return readAiff(r, raw);
+    if (magic == "RIFF") return readWav(r, raw);
+    if (magic == ".snd" && r.d.size() >= 24) return readNext(r, raw);
     throw Error(SGZ_E_IO, "unknown audio file format: " + path);
+}
+
+}  // namespace
+
+AudioData readAudioFile(const std::string &path) { return readAny(path, nullptr); }
+
+PcmData readAudioFilePcm(const std::string &path)
+{
+    PcmData p;
+    AudioData a = readAny(path, &p);
+    p.numChannels = a.numChannels;
+    p.sampleRate = a.sampleRate;
+    p.numFrames = a.numFrames;
+    if (p.bytes.empty()) {  // a layout the device does not decode (or no samples): the decoded floats
+        p.sampleFormat = SGZ_PCM_F32;
+        p.offset = 0;
+        p.bytes.resize(a.frames.size() * sizeof(float));
+        if (!a.frames.empty()) std::memcpy(p.bytes.data(), a.frames.data(), p.bytes.size());
+    }
+    return p;
 }
 
 // RIFF-WAVE, IEEE float (format tag 3), with the fact chunk non-PCM formats carry

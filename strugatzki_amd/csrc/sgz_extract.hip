@@ -481,6 +481,66 @@ struct DevBuf {
 
 }  // namespace
 
+namespace {
+
+// Sample decoding on the device: audio files hold 16-, 24- or 32-bit integers or floats of either byte order;
+// uploading them as they are halves (16 bit) the transfer that bounds the call and spares the host a pass over
+// every sample.  An integer v of b bits becomes v / 2^(b-1), rounded once to float where it does not fit (32 bit),
+// as the host-side reader decodes it.
+__global__ __launch_bounds__(256) void pcm16_decode_kernel(const uint4 *__restrict__ raw, long long count, int bigEndian,
+                                                           float *__restrict__ out)
+{
+    // eight samples per thread: one 16-byte load, two 16-byte stores; the last, partial group sample by sample
+    const long long groups = count >> 3;
+    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < groups; g += (long long)gridDim.x * 256) {
+        const uint4 q = raw[g];
+        const unsigned int w[4] = {q.x, q.y, q.z, q.w};
+        float f[8];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            unsigned int lo = w[k] & 0xffffu, hi = w[k] >> 16;
+            if (bigEndian) {
+                lo = ((lo & 0xffu) << 8) | (lo >> 8);
+                hi = ((hi & 0xffu) << 8) | (hi >> 8);
+            }
+            f[2 * k] = (float)(short)lo * (1.0f / 32768.0f);
+            f[2 * k + 1] = (float)(short)hi * (1.0f / 32768.0f);
+        }
+        float4 *dst = reinterpret_cast<float4 *>(out + 8 * g);
+        dst[0] = make_float4(f[0], f[1], f[2], f[3]);
+        dst[1] = make_float4(f[4], f[5], f[6], f[7]);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (count & 7)) {
+        const long long i = 8 * groups + threadIdx.x;
+        const unsigned char *b = reinterpret_cast<const unsigned char *>(raw) + 2 * i;
+        const unsigned int v = bigEndian ? ((unsigned int)b[0] << 8) | b[1] : ((unsigned int)b[1] << 8) | b[0];
+        out[i] = (float)(short)v * (1.0f / 32768.0f);
+    }
+}
+
+// The other layouts byte by byte: bytes = 3 or 4 per sample, integer or (4 bytes only) IEEE float.
+__global__ __launch_bounds__(256) void pcm_decode_kernel(const unsigned char *__restrict__ raw, long long count, int bytes,
+                                                         int bigEndian, int isFloat, float *__restrict__ out)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long long)gridDim.x * 256) {
+        const unsigned char *b = raw + i * bytes;
+        unsigned int u = 0;  // the sample's bytes, most significant first
+        for (int k = 0; k < bytes; k++) u = (u << 8) | b[bigEndian ? k : bytes - 1 - k];
+        float f;
+        if (isFloat) {
+            f = __uint_as_float(u);
+        } else if (bytes == 3) {
+            const int v = (int)(u << 8) >> 8;  // sign extension of 24 bits
+            f = (float)v * (1.0f / 8388608.0f);
+        } else {
+            f = (float)((double)(int)u * (1.0 / 2147483648.0));
+        }
+        out[i] = f;
+    }
+}
+
+}  // namespace
+
 extern "C" {
 
 int64_t sgz_extract_num_frames(int64_t num_frames, int fft_size, int fft_overlap)
@@ -495,9 +555,29 @@ int sgz_extract(sgz_context *ctx, const float *pcm, int64_t num_frames, int num_
                 int fft_size, int fft_overlap, int num_coeffs, int channels_behavior, float *features_out,
                 int64_t capacity_frames, int64_t *num_out)
 {
+    return sgz_extract_pcm(ctx, pcm, SGZ_PCM_F32, num_frames, num_channels, sample_rate, fft_size, fft_overlap,
+                           num_coeffs, channels_behavior, features_out, capacity_frames, num_out);
+}
+
+int sgz_extract_pcm(sgz_context *ctx, const void *pcm, int sample_format, int64_t num_frames, int num_channels,
+                    double sample_rate, int fft_size, int fft_overlap, int num_coeffs, int channels_behavior,
+                    float *features_out, int64_t capacity_frames, int64_t *num_out)
+{
     if (!ctx) return SGZ_E_ARG;
     if (num_frames < 0 || (num_frames > 0 && !pcm) || num_channels < 1 || !(sample_rate > 0))
         return ctx->fail(SGZ_E_ARG, "bad audio input");
+    int sampleBytes = 4, bigEndian = 0, isFloat = 0;
+    switch (sample_format) {
+        case SGZ_PCM_F32: isFloat = 1; break;
+        case SGZ_PCM_F32_BE: isFloat = 1; bigEndian = 1; break;
+        case SGZ_PCM_S16: sampleBytes = 2; break;
+        case SGZ_PCM_S16_BE: sampleBytes = 2; bigEndian = 1; break;
+        case SGZ_PCM_S24: sampleBytes = 3; break;
+        case SGZ_PCM_S24_BE: sampleBytes = 3; bigEndian = 1; break;
+        case SGZ_PCM_S32: break;
+        case SGZ_PCM_S32_BE: bigEndian = 1; break;
+        default: return ctx->fail(SGZ_E_ARG, "unknown sample format");
+    }
     if (fft_size < 16 || fft_size > kMaxFft || (fft_size & (fft_size - 1)) || fft_overlap < 1 || fft_size % fft_overlap)
         return ctx->fail(SGZ_E_ARG, "fftSize must be a power of two in [16, 8192] and a multiple of fftOverlap");
     if (num_coeffs < 1 || num_coeffs > kBands) return ctx->fail(SGZ_E_ARG, "numCoeffs must be in [1, 42]");
@@ -618,8 +698,10 @@ int sgz_extract(sgz_context *ctx, const float *pcm, int64_t num_frames, int num_
         }
     }
 
-    DevBuf dPcm, dTw, dHann, dDct, dOut, dBandW;
+    DevBuf dPcm, dRaw, dTw, dHann, dDct, dOut, dBandW;
     const size_t pcmBytes = sizeof(float) * (size_t)num_frames * num_channels;
+    const size_t rawBytes = (size_t)sampleBytes * (size_t)num_frames * num_channels;
+    const bool native = sample_format == SGZ_PCM_F32;
     const size_t outBytes = sizeof(float) * (size_t)nOut * (num_coeffs + 1);
     SGZ_HIP(ctx, hipMalloc(&dPcm.p, pcmBytes));
     SGZ_HIP(ctx, hipMalloc(&dTw.p, sizeof(float2) * tw.size()));
@@ -629,9 +711,22 @@ int sgz_extract(sgz_context *ctx, const float *pcm, int64_t num_frames, int num_
     SGZ_HIP(ctx, hipMalloc(&dBandW.p, sizeof(float) * bandW.size()));
     SGZ_HIP(ctx, hipMemcpyAsync(dBandW.p, bandW.data(), sizeof(float) * bandW.size(), hipMemcpyHostToDevice, ctx->stream));
     // (a single pageable copy runs at 27 GB/s; long inputs go through the context's parallel pinned staging)
-    {
+    if (native) {
         const int crc = sgz::copy_large(ctx, dPcm.p, pcm, pcmBytes, false);
         if (crc) return crc;
+    } else {  // the samples as the file holds them, decoded on the device
+        SGZ_HIP(ctx, hipMalloc(&dRaw.p, rawBytes + 16));
+        const int crc = sgz::copy_large(ctx, dRaw.p, pcm, rawBytes, false);
+        if (crc) return crc;
+        const long long count = (long long)num_frames * num_channels;
+        const int grid = (int)std::min<long long>((count / (sampleBytes == 2 ? 8 : 1) + 255) / 256 + 1, 8192);
+        if (sampleBytes == 2)
+            hipLaunchKernelGGL(pcm16_decode_kernel, dim3(grid), dim3(256), 0, ctx->stream, (const uint4 *)dRaw.p, count,
+                               bigEndian, (float *)dPcm.p);
+        else
+            hipLaunchKernelGGL(pcm_decode_kernel, dim3(grid), dim3(256), 0, ctx->stream, (const unsigned char *)dRaw.p,
+                               count, sampleBytes, bigEndian, isFloat, (float *)dPcm.p);
+        SGZ_HIP(ctx, hipGetLastError());
     }
     SGZ_HIP(ctx, hipMemcpyAsync(dTw.p, tw.data(), sizeof(float2) * tw.size(), hipMemcpyHostToDevice, ctx->stream));
     SGZ_HIP(ctx, hipMemcpyAsync(dHann.p, hann.data(), sizeof(float) * hann.size(), hipMemcpyHostToDevice, ctx->stream));

@@ -485,7 +485,8 @@ void runFeatureExtraction(sgz_context *ctx, const FeatureExtractionConfig &cfg, 
     if (!ctx) throw Error(SGZ_E_ARG, "null context");
     if (cfg.featureOutput.empty()) throw Error(SGZ_E_ARG, "featureOutput is not set");
     if (cfg.fftOverlap < 1 || cfg.fftSize < cfg.fftOverlap) throw Error(SGZ_E_ARG, "bad fftSize / fftOverlap");
-    const AudioData in = readAudioFile(cfg.audioInput);  // :34
+    // (:34; the samples stay as the file holds them where the device decodes that layout)
+    const PcmData in = readAudioFilePcm(cfg.audioInput);
     checkAborted(obs, 0.0);
     const int stepSize = cfg.fftSize / cfg.fftOverlap;
     const int numFeatures = cfg.numCoeffs + 1;
@@ -497,8 +498,9 @@ void runFeatureExtraction(sgz_context *ctx, const FeatureExtractionConfig &cfg, 
     out.numFrames = n;
     out.frames.resize((size_t)n * numFeatures);
     int64_t got = 0;
-    check(ctx, sgz_extract(ctx, in.frames.data(), in.numFrames, in.numChannels, in.sampleRate, cfg.fftSize,
-                           cfg.fftOverlap, cfg.numCoeffs, (int)cfg.channelsBehavior, out.frames.data(), n, &got));
+    check(ctx, sgz_extract_pcm(ctx, in.samples(), in.sampleFormat, in.numFrames, in.numChannels, in.sampleRate,
+                               cfg.fftSize, cfg.fftOverlap, cfg.numCoeffs, (int)cfg.channelsBehavior,
+                               out.frames.data(), n, &got));
     checkAborted(obs, 0.8);
     // fixNaNs, impl/NonRealtimeProcessor.scala:178-190: NaN -> previous value of the channel, the memory
     // starting at 0 in every 1024-frame chunk (the first chunk holds 1023 frames, :107-108)

@@ -6,6 +6,7 @@ pointers and raises on error codes.
 from __future__ import annotations
 
 import ctypes as C
+import sys
 from typing import Iterable, Sequence
 
 import numpy as np
@@ -348,17 +349,48 @@ class Context:
 
 
     # ---- extraction -----------------------------------------------------------
+    # sample layouts of sgz_extract_pcm (SGZ_PCM_*): (bytes per sample, little-endian code); big endian = code + 1
+    PCM_F32, PCM_S16, PCM_S24, PCM_S32 = 0, 2, 4, 6
+
     def extract(self, pcm: np.ndarray, sample_rate: float, fft_size: int = 1024, fft_overlap: int = 2,
                 num_coeffs: int = 13, channels_behavior: int = 0) -> np.ndarray:
-        """pcm: [frames][channels] (or 1-D mono) -> [featureFrames][num_coeffs + 1]."""
-        a = np.ascontiguousarray(pcm, dtype=np.float32)
+        """pcm: [frames][channels] (or 1-D mono) -> [featureFrames][num_coeffs + 1].
+
+        int16 / int32 arrays and float32 arrays of either byte order are uploaded as they are and decoded on the
+        device (an integer of b bits counts as v / 2^(b-1), as audio files hold them); anything else is converted
+        to float32 on the host first."""
+        a = np.asarray(pcm)
+        kind = (a.dtype.kind, a.dtype.itemsize)
+        if kind in (("i", 2), ("i", 4), ("f", 4)):
+            fmt = {("i", 2): self.PCM_S16, ("i", 4): self.PCM_S32, ("f", 4): self.PCM_F32}[kind]
+            fmt += 0 if a.dtype.isnative == (sys.byteorder == "little") else 1
+            a = np.ascontiguousarray(a)
+        else:
+            fmt = self.PCM_F32
+            a = np.ascontiguousarray(a, dtype=np.float32)
         if a.ndim == 1:
             a = a[:, None]
-        n = max(0, lib.sgz_extract_num_frames(a.shape[0], fft_size, fft_overlap))
+        return self._extract(a, fmt, a.shape[0], a.shape[1], sample_rate, fft_size, fft_overlap, num_coeffs,
+                             channels_behavior)
+
+    def extract_pcm(self, samples, sample_format: int, num_frames: int, num_channels: int, sample_rate: float,
+                    fft_size: int = 1024, fft_overlap: int = 2, num_coeffs: int = 13,
+                    channels_behavior: int = 0) -> np.ndarray:
+        """The samples as an audio file holds them (bytes or a uint8 array, interleaved, layout SGZ_PCM_*)."""
+        raw = np.frombuffer(samples, dtype=np.uint8) if not isinstance(samples, np.ndarray) else samples
+        raw = np.ascontiguousarray(raw).view(np.uint8).reshape(-1)
+        width = {0: 4, 1: 4, 2: 2, 3: 2, 4: 3, 5: 3, 6: 4, 7: 4}.get(sample_format, 0)  # (unknown: the library says so)
+        if raw.size < width * num_frames * num_channels:
+            raise ValueError("fewer bytes than num_frames * num_channels samples")
+        return self._extract(raw, sample_format, num_frames, num_channels, sample_rate, fft_size, fft_overlap,
+                             num_coeffs, channels_behavior)
+
+    def _extract(self, a, fmt, frames, channels, sample_rate, fft_size, fft_overlap, num_coeffs, channels_behavior):
+        n = max(0, lib.sgz_extract_num_frames(frames, fft_size, fft_overlap))
         out = np.empty((max(n, 1), num_coeffs + 1), dtype=np.float32)
         cnt = C.c_int64(0)
-        self._check(lib.sgz_extract(self._h, N.ptr(a), a.shape[0], a.shape[1], sample_rate, fft_size, fft_overlap,
-                                    num_coeffs, channels_behavior, N.ptr(out), out.shape[0], C.byref(cnt)))
+        self._check(lib.sgz_extract_pcm(self._h, N.ptr(a), fmt, frames, channels, sample_rate, fft_size, fft_overlap,
+                                        num_coeffs, channels_behavior, N.ptr(out), out.shape[0], C.byref(cnt)))
         return out[: cnt.value]
 
 

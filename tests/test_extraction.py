@@ -127,3 +127,102 @@ def test_feature_extraction_processor_writes_feature_file_and_meta(ctx, tmp_path
     br = FeatureSegmentation.run(ctx, FeatureSegmentation.Config(str(tmp_path / "db"), meta, normalize=False,
                                                                  corrLen=4096, numBreaks=2))
     assert len(br) == 2
+
+
+# ------------------------------------------------------------------ samples as audio files hold them
+def _layouts(x):
+    """float samples in [-1, 1) -> {SGZ_PCM_* code: (bytes, the float32 values those bytes stand for)}."""
+    out = {}
+    out[0] = (x.astype("<f4").tobytes(), x)
+    out[1] = (x.astype(">f4").tobytes(), x)
+    i16 = np.clip(np.round(x * 32768), -32768, 32767).astype(np.int16)
+    out[2] = (i16.astype("<i2").tobytes(), i16.astype(np.float32) / np.float32(32768))
+    out[3] = (i16.astype(">i2").tobytes(), out[2][1])
+    i24 = np.clip(np.round(x.astype(np.float64) * 8388608), -8388608, 8388607).astype(np.int32)
+    le = i24.astype("<i4").view(np.uint8).reshape(-1, 4)[:, :3]
+    out[4] = (le.tobytes(), i24.astype(np.float32) / np.float32(8388608))
+    out[5] = (le[:, ::-1].tobytes(), out[4][1])
+    i32 = np.clip(np.round(x.astype(np.float64) * 2147483648), -2147483648, 2147483647).astype(np.int64).astype(np.int32)
+    out[6] = (i32.astype("<i4").tobytes(), (i32.astype(np.float64) / 2147483648.0).astype(np.float32))
+    out[7] = (i32.astype(">i4").tobytes(), out[6][1])
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,channels", [(30011, 1), (20005, 2), (8, 1), (0, 1)])
+def test_gpu_sample_layouts_decode_on_the_device(ctx, n, channels):
+    """16-, 24-, 32-bit integers and floats of either byte order, uploaded as they are: the features are those of
+    the same values handed over as float32, bit for bit (an integer of b bits counts as v / 2^(b-1), the reading of
+    the reference's audio file layer); lengths that are no multiple of the 8 samples a thread decodes."""
+    x = _signal(max(n, 1), seed=n + 1, channels=channels)[:n]
+    x[:4] = np.array([[-1.0, 0.999999, -0.5, 0.25][: channels]] * 4, np.float32)[: min(4, n)]
+    for code, (raw, vals) in _layouts(x).items():
+        want = ctx.extract(np.ascontiguousarray(vals, np.float32), SR)
+        got = ctx.extract_pcm(raw, code, n, channels, SR)
+        assert got.shape == want.shape, code
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), code
+    import strugatzki_amd as S
+    with pytest.raises(S.NativeError):
+        ctx.extract_pcm(np.zeros(64, np.uint8), 8, 4, 1, SR)  # no such layout
+
+
+@pytest.mark.gpu
+def test_gpu_integer_arrays_go_up_as_they_are(ctx):
+    x = _signal(25000, seed=12, channels=2)
+    i16 = np.round(x * 32767).astype(np.int16)
+    want = ctx.extract(i16.astype(np.float32) / np.float32(32768), SR)
+    for a in (i16, i16.astype(">i2"), i16[:, ::-1][:, ::-1]):
+        got = ctx.extract(a, SR)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    i32 = (i16.astype(np.int32) << 16) + 12345
+    want = ctx.extract((i32.astype(np.float64) / 2147483648.0).astype(np.float32), SR)
+    assert np.array_equal(ctx.extract(i32, SR).view(np.uint32), want.view(np.uint32))
+    np.testing.assert_allclose(want, O.extract((i32.astype(np.float64) / 2147483648.0).astype(np.float32), SR),
+                               rtol=0, atol=TOL)
+
+
+def _write_next(path, payload, encoding, channels):
+    import struct
+    with open(path, "wb") as f:
+        f.write(b".snd" + struct.pack(">5I", 24, len(payload), encoding, 44100, channels) + payload)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["wav16", "wav24", "wav32", "aiff16", "aiff24", "aiff32", "next_f32", "next_f64",
+                                  "wav8"])
+def test_feature_extraction_reads_every_file_layout(ctx, tmp_path, kind):
+    """FeatureExtraction over files of each sample layout: those the device decodes go up as the file's bytes, the
+    others (8 bit, 64-bit floats) decoded by the reader -- the same features as from the decoded values."""
+    import aifc
+    import wave
+    from strugatzki_amd import processors as P
+    from strugatzki_amd.processors import FeatureExtraction
+    x = _signal(30001, seed=21, channels=2)
+    lay = _layouts(x)
+    path = str(tmp_path / ("in." + kind))
+    if kind.startswith("wav") and kind != "wav8":
+        bits = int(kind[3:])
+        raw, vals = lay[{16: 2, 24: 4, 32: 6}[bits]]
+        with wave.open(path, "wb") as w:
+            w.setnchannels(2); w.setsampwidth(bits // 8); w.setframerate(44100); w.writeframes(raw)
+    elif kind == "wav8":
+        u8 = np.clip(np.round(x * 128) + 128, 0, 255).astype(np.uint8)
+        raw, vals = u8.tobytes(), (u8.astype(np.float32) - 128) / np.float32(128)
+        with wave.open(path, "wb") as w:
+            w.setnchannels(2); w.setsampwidth(1); w.setframerate(44100); w.writeframes(raw)
+    elif kind.startswith("aiff"):
+        bits = int(kind[4:])
+        raw, vals = lay[{16: 3, 24: 5, 32: 7}[bits]]
+        with aifc.open(path, "wb") as w:
+            w.setnchannels(2); w.setsampwidth(bits // 8); w.setframerate(44100); w.writeframes(raw)
+    elif kind == "next_f32":
+        raw, vals = lay[1]
+        _write_next(path, raw, 6, 2)
+    else:
+        raw, vals = x.astype(">f8").tobytes(), x
+        _write_next(path, raw, 7, 2)
+    feat = str(tmp_path / "out_feat.aif")
+    FeatureExtraction.run(ctx, FeatureExtraction.Config(path, feat, None))
+    got, _ = P.read_audio_file(feat)
+    want = ctx.extract(np.ascontiguousarray(vals, np.float32), SR)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))

@@ -16,3 +16,11 @@ for it in range(3):
     k = N.lib.sgz_last_kernel_ms(ctx._h)
     print(f"frames {f.shape[0]}  wall {dt*1e3:.1f} ms (incl. H2D of {x.nbytes/1e6:.0f} MB)  kernel {k:.3f} ms "
           f"= {n/44100.0/(k*1e-3):.3e} x realtime, {(x.nbytes + f.nbytes)/k/1e6:.1f} GB/s algorithmic")
+# the same hour as 16-bit samples, decoded on the device (what a 16-bit audio file goes up as)
+x16 = np.round(x * 32767).astype(np.int16)
+for it in range(3):
+    t0 = time.perf_counter()
+    f = ctx.extract(x16, 44100.0)
+    dt = time.perf_counter() - t0
+    k = N.lib.sgz_last_kernel_ms(ctx._h)
+    print(f"int16: frames {f.shape[0]}  wall {dt*1e3:.1f} ms (incl. H2D of {x16.nbytes/1e6:.0f} MB)  kernel {k:.3f} ms")
