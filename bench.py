@@ -405,7 +405,10 @@ def main() -> int:
             # what the kernel is built to move: the blocks' spectra and 16 B of cached statistics per window in (20 B in
             # blocks where some window's boost comes near maxBoost: none in this workload); out only the list of the
             # few windows that can hold their file's maximum and one bound per file
-            moved = blocks * 4.0 * NUM_CH * n + windows * 16.0
+            q16 = ctx.spectra_format_in_use == "q16"
+            # (16-bit spectra: 4 bytes per complex bin and a 4-byte scale per band of 64 bins; every workgroup also
+            # reads the target's spectra, which the caches serve)
+            moved = blocks * (2.0 * NUM_CH * n + NUM_CH * n / 32.0 if q16 else 4.0 * NUM_CH * n) + windows * 16.0
             return {
                 "bound": "hbm", "kernel": "corr_fft_kernel", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "frac": ach / PEAK_HBM_GBS,
@@ -413,10 +416,12 @@ def main() -> int:
                 "bytes_by_design": moved,
                 "gbs_by_design": moved / (kms * 1e-3) / 1e9 if kms > 0 else 0.0,
                 "transform_length": n, "windows_per_block": hop, "blocks": blocks,
+                "spectra": "16-bit integers, one scale per 64 bins" if q16 else "fp32",
                 "note": "one launch over all files, one workgroup per block of N frames: the cross terms of a block's "
-                        "N - L + 1 windows are one circular correlation, evaluated from fp32 spectra of the blocks kept "
-                        "in HBM with the database (product with the target's spectra, channels summed in the frequency "
-                        "domain, one inverse transform in LDS); achieved = 64 algorithmic bytes per window (one new "
+                        "N - L + 1 windows are one circular correlation, evaluated from spectra of the blocks kept "
+                        "in HBM with the database (16-bit integers with a scale per band, whose measured distance to "
+                        "the fp32 spectra is part of the certified error; product with the target's spectra, channels "
+                        "summed in the frequency domain, one fp32 inverse transform in LDS); achieved = 64 algorithmic bytes per window (one new "
                         "frame in, similarity and boost out) over the kernel's duration, against 8 TB/s; "
                         "bytes_by_design is what this formulation has to move (overlapping blocks, cached window "
                         "statistics; the search reads candidate lists, not an upper bound per window).  It yields certified bounds, and every "

@@ -237,8 +237,17 @@ SGZ_API int sgz_corr_screen_kernel_in_use(const sgz_context *ctx);
 SGZ_API int sgz_corr_set_screen_output(sgz_context *ctx, int lists_only);
 /* Geometry of the spectral kernel for the current layout: transform length N, windows per block (N - L + 1) and
  * the number of blocks over all files; zeros when the spectral kernel is not in use.  Any pointer may be NULL.
- * For reports (a block moves 4 * numCh * N bytes of spectra); no counterpart in the reference. */
+ * For reports (a block moves 4 * numCh * N bytes of fp32 spectra, 2 * numCh * N + numCh * N / 32 of 16-bit ones);
+ * no counterpart in the reference. */
 SGZ_API int sgz_corr_screen_geometry(const sgz_context *ctx, int *n_out, int *hop_out, long long *blocks_out);
+/* How the spectral kernel keeps the database's spectra: 1 fp32; 2 signed 16-bit integers with one scale per band of
+ * 64 bins -- half the bytes the kernel streams, and the distance of every stored block to its fp32 spectrum is
+ * measured when it is built and added to the block's certified error, so the bounds stay bounds (they widen by
+ * about half); 0 (default) leaves the choice to the library (16-bit).  Takes effect with the next run (the spectra
+ * are rebuilt).  sgz_corr_spectra_format_in_use: 1 or 2 once a run has built the layout with the spectral kernel, 0
+ * if it is not in use, -1 before.  No counterpart in the reference (which holds no spectra). */
+SGZ_API int sgz_corr_set_spectra_format(sgz_context *ctx, int format);
+SGZ_API int sgz_corr_spectra_format_in_use(const sgz_context *ctx);
 /* The N-point complex fp32 transform of the spectral kernel (N = 4096, 8192, 16384; forward or inverse without the
  * 1 / N factor; interleaved re, im), run thread by thread on the host with the kernels' own index arithmetic and
  * operations: test support, no GPU needed, no counterpart in the reference. */

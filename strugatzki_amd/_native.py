@@ -105,6 +105,8 @@ SIGNATURES = {
     "sgz_corr_set_screen_kernel": (C.c_int, [_vp, C.c_int]),
     "sgz_corr_screen_kernel_in_use": (C.c_int, [_vp]),
     "sgz_corr_screen_geometry": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "sgz_corr_set_spectra_format": (C.c_int, [_vp, C.c_int]),
+    "sgz_corr_spectra_format_in_use": (C.c_int, [_vp]),
     "sgz_corr_set_screen_output": (C.c_int, [_vp, C.c_int]),
     "sgz_fft_reference_host": (C.c_int, [C.c_int, C.c_int, _vp, _vp]),
     "sgz_corr_read_dense": (C.c_int, [_vp, C.c_int, _vp, _vp]),

@@ -76,15 +76,54 @@ __device__ __forceinline__ void untangle(float2 zj, float2 zm, float2 &xa, float
     xb = make_float2(0.5f * (zj.y + zm.y), 0.5f * (zm.x - zj.x));
 }
 
+// 16-bit spectra: a complex bin is two signed 16-bit integers (real part in the low half) times the scale of its
+// band of 64 bins.  The product is one fp32 rounding; the builder measures what the stored value is off the fp32
+// spectrum with the very same expression the reader decodes with.
+__device__ __forceinline__ float2 q16_decode(unsigned int q, float scale)
+{
+    return make_float2((float)(short)(q & 0xffffu) * scale, (float)((int)q >> 16) * scale);
+}
+
+// Rounds one band (the 64 bins of a wave, one per lane) to 16 bits: the band's scale is its largest component / 32767
+// (NaN when a component is not finite, so that the block's results come out as NaN like those of fp32 spectra; 0 when
+// the band is all but empty).  Returns the packed bin, adds the squared distance to `dq`.
+__device__ __forceinline__ unsigned int q16_encode_band(float2 v, float &scaleOut, float &dq)
+{
+    float mx = fmaxf(fabsf(v.x), fabsf(v.y));
+    int bad = !(mx <= 3.0e38f);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+        bad |= __shfl_xor(bad, off, 64);
+    }
+    float scale = 0.0f, inv = 0.0f;
+    if (mx >= 1.0e-30f) {
+        scale = mx * (1.0f / 32767.0f);
+        inv = 32767.0f / mx;
+    }
+    if (bad) scale = __builtin_nanf("");
+    const float qx = fminf(fmaxf(rintf(v.x * inv), -32767.0f), 32767.0f);
+    const float qy = fminf(fmaxf(rintf(v.y * inv), -32767.0f), 32767.0f);
+    const unsigned int q = ((unsigned int)(int)qx & 0xffffu) | ((unsigned int)(int)qy << 16);
+    const float2 d = q16_decode(q, scale);
+    const float ex = d.x - v.x, ey = d.y - v.y;
+    if (!bad) dq = fmaf(ex, ex, fmaf(ey, ey, dq));
+    scaleOut = scale;
+    return q;
+}
+
 // fft_spectra_kernel: workgroup = (block, channel pair).  The block's frames of two channels, normalised and
 // centred exactly as the half-precision preparation does it (the window statistics of the bounds are sums of
 // these very values), one forward transform, the two spectra to HBM; per channel the sum of squares.
-template <int N>
+// Q16: the spectra go out as 16-bit integers (q16_encode_band), with the scales and, per channel, the squared
+// distance of what was stored to what was computed.
+template <int N, bool Q16>
 __global__ __launch_bounds__(N / 16) void fft_spectra_kernel(const FileDesc *__restrict__ files,
                                                              const FftBlock *__restrict__ blocks, int numPairs,
                                                              int numUnits, NormParams nrm, int numCh,
                                                              const float2 *__restrict__ tab, float2 *__restrict__ spec,
-                                                             float *__restrict__ blksq)
+                                                             float *__restrict__ blksq, float *__restrict__ specscale,
+                                                             float *__restrict__ blkdq)
 {
     constexpr int T = N / 16, NH = N / 2;
     extern __shared__ __attribute__((aligned(16))) float2 buf[];
@@ -129,6 +168,10 @@ __global__ __launch_bounds__(N / 16) void fft_spectra_kernel(const FileDesc *__r
     fft_lds<N, -1>(buf, tab, tid);
     float2 *out0 = spec + bd.spec + (long long)c0 * NH;
     float2 *out1 = spec + bd.spec + (long long)c1 * NH;
+    unsigned int *q0 = reinterpret_cast<unsigned int *>(spec) + bd.spec + (long long)c0 * NH;
+    unsigned int *q1 = reinterpret_cast<unsigned int *>(spec) + bd.spec + (long long)c1 * NH;
+    float *sc0 = specscale + ((size_t)blk * numCh + c0) * (NH / 64), *sc1 = specscale + ((size_t)blk * numCh + c1) * (NH / 64);
+    float dq0 = 0.0f, dq1 = 0.0f;
 #pragma unroll 4
     for (int m = 0; m < 8; m++) {
         const int j = tid + m * T;
@@ -140,19 +183,41 @@ __global__ __launch_bounds__(N / 16) void fft_spectra_kernel(const FileDesc *__r
             xa = make_float2(zj.x, zn.x);
             xb = make_float2(zj.y, zn.y);
         }
-        out0[j] = xa;
-        if (two) out1[j] = xb;
+        if constexpr (Q16) {  // (a wave's 64 lanes hold one band)
+            float sa, sb;
+            q0[j] = q16_encode_band(xa, sa, dq0);
+            if ((tid & 63) == 0) sc0[j >> 6] = sa;
+            if (two) {
+                q1[j] = q16_encode_band(xb, sb, dq1);
+                if ((tid & 63) == 0) sc1[j >> 6] = sb;
+            }
+        } else {
+            out0[j] = xa;
+            if (two) out1[j] = xb;
+        }
+    }
+    if constexpr (Q16) {
+        const float e0 = block_sum<T>(dq0, red);
+        const float e1 = block_sum<T>(dq1, red);
+        if (tid == 0) {
+            blkdq[(size_t)blk * numCh + c0] = e0;
+            if (two) blkdq[(size_t)blk * numCh + c1] = e1;
+        }
     }
 }
 
 // fft_target_kernel: workgroup = channel pair of the target; the conjugated spectra divided by N (the inverse
 // transform's factor), packed like the database spectra.
-template <int N>
+// Q16: as 16-bit integers like the database's (q16_encode_band), with the scales and per channel the squared
+// distance of what was stored to what was computed.
+template <int N, bool Q16>
 __global__ __launch_bounds__(N / 16) void fft_target_kernel(const float *__restrict__ aprime, int Lpad, int L, int numCh,
-                                                            const float2 *__restrict__ tab, float2 *__restrict__ aspec)
+                                                            const float2 *__restrict__ tab, float2 *__restrict__ aspec,
+                                                            float *__restrict__ ascale, float *__restrict__ tgtdq)
 {
     constexpr int T = N / 16, NH = N / 2;
     extern __shared__ __attribute__((aligned(16))) float2 buf[];
+    __shared__ float red[16];
     const int tid = threadIdx.x;
     const int c0 = 2 * blockIdx.x, c1 = c0 + 1;
     const bool two = c1 < numCh;
@@ -169,6 +234,7 @@ __global__ __launch_bounds__(N / 16) void fft_target_kernel(const float *__restr
     __syncthreads();
     fft_lds<N, -1>(buf, tab, tid);
     constexpr float rN = 1.0f / (float)N;
+    float dq0 = 0.0f, dq1 = 0.0f;
 #pragma unroll 4
     for (int m = 0; m < 8; m++) {
         const int j = tid + m * T;
@@ -182,14 +248,39 @@ __global__ __launch_bounds__(N / 16) void fft_target_kernel(const float *__restr
             xa = make_float2(zj.x * rN, zn.x * rN);
             xb = make_float2(zj.y * rN, zn.y * rN);
         }
-        aspec[(size_t)c0 * NH + j] = xa;
-        if (two) aspec[(size_t)c1 * NH + j] = xb;
+        if constexpr (Q16) {
+            unsigned int *aq = reinterpret_cast<unsigned int *>(aspec);
+            float sa, sb;
+            aq[(size_t)c0 * NH + j] = q16_encode_band(xa, sa, dq0);
+            if ((tid & 63) == 0) ascale[(size_t)c0 * (NH / 64) + (j >> 6)] = sa;
+            if (two) {
+                aq[(size_t)c1 * NH + j] = q16_encode_band(xb, sb, dq1);
+                if ((tid & 63) == 0) ascale[(size_t)c1 * (NH / 64) + (j >> 6)] = sb;
+            }
+        } else {
+            aspec[(size_t)c0 * NH + j] = xa;
+            if (two) aspec[(size_t)c1 * NH + j] = xb;
+        }
+    }
+    if constexpr (Q16) {
+        const float e0 = block_sum<T>(dq0, red);
+        const float e1 = block_sum<T>(dq1, red);
+        if (tid == 0) {
+            tgtdq[c0] = e0;
+            if (two) tgtdq[c1] = e1;
+        }
     }
 }
 
 // Euclidean norms of a block, rounded up: loudness channel, the other channels, channels 0 and 1 together,
 // sqrt(|x_T|^2 + 2 |x_S|^2).
-__global__ void fft_blknorm_kernel(const float *__restrict__ blksq, int numCh, int nblocks, float4 *__restrict__ blknorm)
+// With 16-bit spectra (blkdq given) also what the rounding to 16 bits amounts to, as norms of time-domain values:
+// a spectrum off by d (half spectrum, Euclidean norm) moves a cross term by at most |a'| sqrt(2 / N) |d| (Cauchy-Schwarz
+// over the bins, Parseval for the target, every bin of the half spectrum standing for at most two of the whole one);
+// qscale = sqrt(2 / N).  The block's norms are raised by the same amounts: what the kernel multiplies is the
+// stored spectrum.
+__global__ void fft_blknorm_kernel(const float *__restrict__ blksq, int numCh, int nblocks, float4 *__restrict__ blknorm,
+                                   const float *__restrict__ blkdq, float qscale, float2 *__restrict__ blkq)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nblocks) return;
@@ -197,8 +288,20 @@ __global__ void fft_blknorm_kernel(const float *__restrict__ blksq, int numCh, i
     float s = 0.0f;
     for (int c = 1; c < numCh; c++) s += sq[c];
     const float s1 = numCh > 1 ? sq[1] : 0.0f;
-    blknorm[b] = make_float4(sqrtf(sq[0]) * 1.0001f, sqrtf(s) * 1.0001f, sqrtf(sq[0] + s1) * 1.0001f,
-                             sqrtf(sq[0] + 2.0f * s) * 1.0001f);
+    float4 bn = make_float4(sqrtf(sq[0]) * 1.0001f, sqrtf(s) * 1.0001f, sqrtf(sq[0] + s1) * 1.0001f,
+                            sqrtf(sq[0] + 2.0f * s) * 1.0001f);
+    if (blkdq) {
+        const float *dq = blkdq + (size_t)b * numCh;
+        float ds = 0.0f;
+        for (int c = 1; c < numCh; c++) ds += dq[c];
+        const float dT = sqrtf(dq[0]) * qscale * 1.001f, dS = sqrtf(ds) * qscale * 1.001f;
+        blkq[b] = make_float2(dT, dS);
+        bn.x += dT;
+        bn.y += dS;
+        bn.z += dT + dS;
+        bn.w += dT + 1.5f * dS;
+    }
+    blknorm[b] = bn;
 }
 
 // Smallest ln(average loudness) over a block's windows -- its largest boost is exp((lnAvgIn - that) / 0.6) -- or
@@ -237,13 +340,19 @@ __global__ __launch_bounds__(256) void boost_fill_kernel(float *wstat, long long
 //      Hermitian spectra combined into one, W[j] = Zt + i Zs, W[N - j] = conj(Zt) + i conj(Zs), written to LDS;
 //   2. inverse transform in LDS: w[k] = crossT[k] + i crossS[k];
 //   3. per window the bounds from its cached statics (sgz::SpectralStatics, 20 bytes per window).
-template <int N, int NCH>
+// Q16: the spectra are 16-bit integers with band scales (four bins per 16-byte load); `blkq` holds the block's
+// rounding terms.
+template <int N, int NCH, bool Q16>
 __global__ __launch_bounds__(N / 16) void corr_fft_kernel(const FileDesc *__restrict__ files,
                                                           const FftBlock *__restrict__ blocks,
                                                           const float2 *__restrict__ spec,
                                                           const float2 *__restrict__ aspec,
                                                           const float2 *__restrict__ tab,
                                                           const float4 *__restrict__ blknorm,
+                                                          const float *__restrict__ specscale,
+                                                          const float2 *__restrict__ blkq,
+                                                          const float *__restrict__ ascale,
+                                                          const float *__restrict__ tgtdq,
                                                           const float *__restrict__ blklnmin,
                                                           float *__restrict__ wstat, long long totalWindows,
                                                           CorrParams cp, FftGeom fg,
@@ -268,56 +377,127 @@ __global__ __launch_bounds__(N / 16) void corr_fft_kernel(const FileDesc *__rest
     if (!(beta >= 2.4414062e-4f && beta <= 4096.0f)) beta = beta > 4096.0f ? 4096.0f : (beta < 2.4414062e-4f ? 2.4414062e-4f : 1.0f);
     const float rbeta = 1.0f / beta;
     const FileDesc fd = files[bd.file];
-    const float absT = (fg.epsT * (fg.a01 * bn.x + fg.aT * bn.z + pT + beta * pS) + fg.epsUT * pT) * 1.0001f * fg.kT +
-                       fg.levelErr * fabsf(fd.cT);
-    const float absS = (fg.epsT * (fg.aP * bn.y + fg.aS * bn.w + pT * rbeta * 1.0001f + pS) + fg.epsUS * pS) * 1.0001f * fg.kS +
-                       fg.levelErr * fabsf(fd.cS);
+    float absT = (fg.epsT * (fg.a01 * bn.x + fg.aT * bn.z + pT + beta * pS) + fg.epsUT * pT) * 1.0001f * fg.kT +
+                 fg.levelErr * fabsf(fd.cT);
+    float absS = (fg.epsT * (fg.aP * bn.y + fg.aS * bn.w + pT * rbeta * 1.0001f + pS) + fg.epsUS * pS) * 1.0001f * fg.kS +
+                 fg.levelErr * fabsf(fd.cS);
+    if constexpr (Q16) {
+        // the stored spectra against the computed ones: the block's (blkq, already as norms of time-domain values)
+        // and the target's -- a target spectrum off by d (half spectrum) moves a cross term by at most
+        // sqrt(2) |d| |X| = sqrt(2 N) |d| |x_block|
+        const float2 bq = blkq[blockIdx.x];
+        float tqS = 0.0f;
+        for (int c = 1; c < numCh; c++) tqS += tgtdq[c];
+        const float tscale = __builtin_amdgcn_sqrtf(2.0f * (float)N) * 1.001f;
+        const float tqT = __builtin_amdgcn_sqrtf(tgtdq[0]) * tscale;
+        tqS = __builtin_amdgcn_sqrtf(tqS) * tscale;
+        absT += (fg.aT * bq.x + tqT * bn.x) * 1.0001f * fg.kT;
+        absS += (fg.aS * bq.y + tqS * bn.y) * 1.0001f * fg.kS;
+    }
 
     // SGZ_PROBE (timing builds of tools/spectral_phase_probe.sh only; results are wrong): 1 leaves out the spectra
     // phase, 2 the transform, 3 everything after the transform
 #if defined(SGZ_PROBE) && SGZ_PROBE == 1
     for (int m = 0; m < 16; m++) buf[fft_phys(tid + m * T)] = make_float2(0.001f * tid, 0.002f * m);
 #else
-    // two neighbouring bins per thread and step: 16-byte loads (1 KB of a channel's spectrum per wave instruction)
-    const float4 *xs4 = reinterpret_cast<const float4 *>(xs), *as4 = reinterpret_cast<const float4 *>(aspec);
-#pragma unroll 4
-    for (int m = 0; m < 4; m++) {
-        const int h = tid + m * T, j = 2 * h;  // bins j and j + 1
-        const float4 a0 = as4[h], x0 = xs4[h];
-        float2 zt0 = c_mul(make_float2(a0.x, a0.y), make_float2(x0.x, x0.y));
-        float2 zt1 = c_mul(make_float2(a0.z, a0.w), make_float2(x0.z, x0.w));
-        float2 zs0 = make_float2(0.0f, 0.0f), zs1 = make_float2(0.0f, 0.0f);
+    if constexpr (Q16) {
+        // four neighbouring bins per thread and step: one 16-byte load each of the block's spectrum and of the
+        // target's, and the two scales of the band (a band is the bins of 16 neighbouring threads).  The scales are
+        // multiplied first and applied to one side only: the target's integers go into the products as they are.
+        const unsigned int *xq = reinterpret_cast<const unsigned int *>(spec) + bd.spec;
+        const unsigned int *aq = reinterpret_cast<const unsigned int *>(aspec);
+        const uint4 *xq4 = reinterpret_cast<const uint4 *>(xq), *aq4 = reinterpret_cast<const uint4 *>(aq);
+        const float *sc = specscale + (size_t)blockIdx.x * numCh * (NH / 64);
+        auto mac = [&](int c, const uint4 q, float scale, const uint4 qa, float2 (&zt)[4], float2 (&zs)[4]) {
+            const float2 a[4] = {q16_decode(qa.x, 1.0f), q16_decode(qa.y, 1.0f), q16_decode(qa.z, 1.0f), q16_decode(qa.w, 1.0f)};
+            const float2 x[4] = {q16_decode(q.x, scale), q16_decode(q.y, scale), q16_decode(q.z, scale),
+                                 q16_decode(q.w, scale)};
 #pragma unroll
-        for (int c = 1; c < numCh; c++) {
-            const float4 a = as4[(size_t)c * (NH / 2) + h], x = xs4[(size_t)c * (NH / 2) + h];
-            zs0.x = fmaf(a.x, x.x, zs0.x);
-            zs0.x = fmaf(-a.y, x.y, zs0.x);
-            zs0.y = fmaf(a.x, x.y, zs0.y);
-            zs0.y = fmaf(a.y, x.x, zs0.y);
-            zs1.x = fmaf(a.z, x.z, zs1.x);
-            zs1.x = fmaf(-a.w, x.w, zs1.x);
-            zs1.y = fmaf(a.z, x.w, zs1.y);
-            zs1.y = fmaf(a.w, x.z, zs1.y);
+            for (int i = 0; i < 4; i++) {
+                if (c == 0) {
+                    zt[i] = c_mul(a[i], x[i]);
+                    zs[i] = make_float2(0.0f, 0.0f);
+                } else {
+                    zs[i].x = fmaf(a[i].x, x[i].x, zs[i].x);
+                    zs[i].x = fmaf(-a[i].y, x[i].y, zs[i].x);
+                    zs[i].y = fmaf(a[i].x, x[i].y, zs[i].y);
+                    zs[i].y = fmaf(a[i].y, x[i].x, zs[i].y);
+                }
+            }
+        };
+        auto scatter = [&](int j, const float2 (&zt)[4], const float2 (&zs)[4]) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float sx = zs[i].x * beta, sy = zs[i].y * beta;
+                buf[fft_phys((N - j - i) & (N - 1))] = make_float2(zt[i].x + sy, sx - zt[i].y);
+                buf[fft_phys(j + i)] = make_float2(zt[i].x - sy, zt[i].y + sx);
+            }
+        };
+#pragma unroll 2
+        for (int m = 0; m < 2; m++) {
+            const int h = tid + m * T;  // bins 4 h .. 4 h + 3
+            float2 zt[4], zs[4];
+#pragma unroll
+            for (int c = 0; c < numCh; c++)
+                mac(c, xq4[(size_t)c * (NH / 4) + h], sc[c * (NH / 64) + (h >> 4)] * ascale[c * (NH / 64) + (h >> 4)],
+                    aq4[(size_t)c * (NH / 4) + h], zt, zs);
+            scatter(4 * h, zt, zs);
         }
-        zs0.x *= beta;
-        zs0.y *= beta;
-        zs1.x *= beta;
-        zs1.y *= beta;
-        buf[fft_phys((N - j) & (N - 1))] = make_float2(zt0.x + zs0.y, zs0.x - zt0.y);
-        buf[fft_phys(j)] = make_float2(zt0.x - zs0.y, zt0.y + zs0.x);
-        buf[fft_phys(N - j - 1)] = make_float2(zt1.x + zs1.y, zs1.x - zt1.y);
-        buf[fft_phys(j + 1)] = make_float2(zt1.x - zs1.y, zt1.y + zs1.x);
-    }
-    if (tid == 0) {  // bin 0 holds two real bins, DC and Nyquist: component-wise products
-        float2 zt = make_float2(aspec[0].x * xs[0].x, aspec[0].y * xs[0].y);
-        float2 zs = make_float2(0.0f, 0.0f);
-        for (int c = 1; c < numCh; c++) {
-            const float2 a = aspec[(size_t)c * NH], x = xs[(size_t)c * NH];
-            zs.x = fmaf(a.x, x.x, zs.x);
-            zs.y = fmaf(a.y, x.y, zs.y);
+        if (tid == 0) {  // bin 0 holds two real bins, DC and Nyquist: component-wise products
+            const float2 x0 = q16_decode(xq[0], sc[0] * ascale[0]), a0 = q16_decode(aq[0], 1.0f);
+            float2 zt = make_float2(a0.x * x0.x, a0.y * x0.y);
+            float2 zs = make_float2(0.0f, 0.0f);
+            for (int c = 1; c < numCh; c++) {
+                const float2 a = q16_decode(aq[(size_t)c * NH], 1.0f);
+                const float2 x = q16_decode(xq[(size_t)c * NH], sc[c * (NH / 64)] * ascale[c * (NH / 64)]);
+                zs.x = fmaf(a.x, x.x, zs.x);
+                zs.y = fmaf(a.y, x.y, zs.y);
+            }
+            buf[fft_phys(0)] = make_float2(zt.x, zs.x * beta);
+            buf[fft_phys(NH)] = make_float2(zt.y, zs.y * beta);
         }
-        buf[fft_phys(0)] = make_float2(zt.x, zs.x * beta);
-        buf[fft_phys(NH)] = make_float2(zt.y, zs.y * beta);
+    } else {
+        // two neighbouring bins per thread and step: 16-byte loads (1 KB of a channel's spectrum per wave instruction)
+        const float4 *xs4 = reinterpret_cast<const float4 *>(xs), *as4 = reinterpret_cast<const float4 *>(aspec);
+#pragma unroll 4
+        for (int m = 0; m < 4; m++) {
+            const int h = tid + m * T, j = 2 * h;  // bins j and j + 1
+            const float4 a0 = as4[h], x0 = xs4[h];
+            float2 zt0 = c_mul(make_float2(a0.x, a0.y), make_float2(x0.x, x0.y));
+            float2 zt1 = c_mul(make_float2(a0.z, a0.w), make_float2(x0.z, x0.w));
+            float2 zs0 = make_float2(0.0f, 0.0f), zs1 = make_float2(0.0f, 0.0f);
+#pragma unroll
+            for (int c = 1; c < numCh; c++) {
+                const float4 a = as4[(size_t)c * (NH / 2) + h], x = xs4[(size_t)c * (NH / 2) + h];
+                zs0.x = fmaf(a.x, x.x, zs0.x);
+                zs0.x = fmaf(-a.y, x.y, zs0.x);
+                zs0.y = fmaf(a.x, x.y, zs0.y);
+                zs0.y = fmaf(a.y, x.x, zs0.y);
+                zs1.x = fmaf(a.z, x.z, zs1.x);
+                zs1.x = fmaf(-a.w, x.w, zs1.x);
+                zs1.y = fmaf(a.z, x.w, zs1.y);
+                zs1.y = fmaf(a.w, x.z, zs1.y);
+            }
+            zs0.x *= beta;
+            zs0.y *= beta;
+            zs1.x *= beta;
+            zs1.y *= beta;
+            buf[fft_phys((N - j) & (N - 1))] = make_float2(zt0.x + zs0.y, zs0.x - zt0.y);
+            buf[fft_phys(j)] = make_float2(zt0.x - zs0.y, zt0.y + zs0.x);
+            buf[fft_phys(N - j - 1)] = make_float2(zt1.x + zs1.y, zs1.x - zt1.y);
+            buf[fft_phys(j + 1)] = make_float2(zt1.x - zs1.y, zt1.y + zs1.x);
+        }
+        if (tid == 0) {  // bin 0 holds two real bins, DC and Nyquist: component-wise products
+            float2 zt = make_float2(aspec[0].x * xs[0].x, aspec[0].y * xs[0].y);
+            float2 zs = make_float2(0.0f, 0.0f);
+            for (int c = 1; c < numCh; c++) {
+                const float2 a = aspec[(size_t)c * NH], x = xs[(size_t)c * NH];
+                zs.x = fmaf(a.x, x.x, zs.x);
+                zs.y = fmaf(a.y, x.y, zs.y);
+            }
+            buf[fft_phys(0)] = make_float2(zt.x, zs.x * beta);
+            buf[fft_phys(NH)] = make_float2(zt.y, zs.y * beta);
+        }
     }
 #endif
     __syncthreads();
@@ -461,27 +641,37 @@ int fft_target(sgz_context *ctx, hipStream_t stream)
     const int numPairs = (numCh + 1) / 2;
     int rc;
     if ((rc = ensure(ctx, ctx->d_aspec, ctx->aspec_cap, (size_t)numCh * (N / 2)))) return rc;
+    const bool q16 = fg.q16 != 0;
+    if (q16) {
+        if ((rc = ensure(ctx, ctx->d_aspecscale, ctx->aspecscale_cap, (size_t)numCh * (N / 128)))) return rc;
+        if ((rc = ensure(ctx, ctx->d_tgtdq, ctx->tgtdq_cap, (size_t)numCh))) return rc;
+    }
     const size_t lds = sizeof(float2) * fft_lds_elems(N);
     const int Lpad = ctx->cp.S * kR;
     auto launch = [&](auto kern) -> int {
         if ((rc = set_lds(ctx, kern, lds))) return rc;
         hipLaunchKernelGGL(kern, dim3(numPairs), dim3(N / 16), lds, stream, ctx->d_aprime_f, Lpad, L, numCh, ctx->d_fft_tab,
-                           ctx->d_aspec);
+                           ctx->d_aspec, q16 ? ctx->d_aspecscale : nullptr, q16 ? ctx->d_tgtdq : nullptr);
         SGZ_HIP(ctx, hipGetLastError());
         return SGZ_OK;
     };
-    if (N == 4096) rc = launch(fft_target_kernel<4096>);
-    else if (N == 8192) rc = launch(fft_target_kernel<8192>);
-    else rc = launch(fft_target_kernel<16384>);
+    if (N == 4096) rc = q16 ? launch(fft_target_kernel<4096, true>) : launch(fft_target_kernel<4096, false>);
+    else if (N == 8192) rc = q16 ? launch(fft_target_kernel<8192, true>) : launch(fft_target_kernel<8192, false>);
+    else rc = q16 ? launch(fft_target_kernel<16384, true>) : launch(fft_target_kernel<16384, false>);
     if (rc) return rc;
     const double nT = (double)L, nS = (double)L * (numCh - 1);
     fg.sumAT = ctx->tgt_sumT;
     fg.sumAS = ctx->tgt_sumS;
     // (a target without spread gives inf / NaN factors, like its similarities)
-    const double u = std::ldexp(1.0, -24), up = 1.0001;
+    // (16-bit spectra: the kernel multiplies the stored target spectrum, whose norm is within sqrt(128) / 65534 of the
+    // computed one's -- every component is off by at most half a step of its band, 1 / 65534 of the band's largest,
+    // and a band has 128 of them; two more roundings per operand, the product of the two scales and its product
+    // with the integer)
+    const double u = std::ldexp(1.0, -24), up = q16 ? 1.0003 : 1.0001;
+    const int extra = q16 ? 2 : 0;
     fg.epsT = (float)(fft_eps(N) * up);
-    fg.epsUT = (float)((1 + 8) * 3.0 * u * up);            // operand roundings, products, the untangling
-    fg.epsUS = (float)((numCh - 1 + 10) * 3.0 * u * up);   // the same, the channel sums and the scaling by beta
+    fg.epsUT = (float)((1 + 8 + extra) * 3.0 * u * up);            // operand roundings, products, the untangling
+    fg.epsUS = (float)((numCh - 1 + 10 + extra) * 3.0 * u * up);   // the same, the channel sums and the scaling by beta
     fg.aT = (float)(ctx->tgt_nrmT * up);
     fg.aS = (float)(ctx->tgt_nrmS * up);
     fg.a01 = (float)(std::sqrt(ctx->tgt_nrmT * ctx->tgt_nrmT + ctx->tgt_nrm1 * ctx->tgt_nrm1) * up);
@@ -500,7 +690,8 @@ namespace sgz {
 
 void fft_screen_free(sgz_context *ctx)
 {
-    void *bufs[] = {ctx->d_fblocks, ctx->d_spec, ctx->d_aspec, ctx->d_fft_tab, ctx->d_blksq, ctx->d_blknorm, ctx->d_blklnmin, ctx->d_prelist, ctx->d_precount};
+    void *bufs[] = {ctx->d_fblocks, ctx->d_spec, ctx->d_aspec, ctx->d_fft_tab, ctx->d_blksq, ctx->d_blknorm, ctx->d_blklnmin, ctx->d_prelist, ctx->d_precount,
+                    ctx->d_specscale, ctx->d_blkdq, ctx->d_blkq, ctx->d_aspecscale, ctx->d_tgtdq};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
 }
@@ -548,6 +739,13 @@ int fft_screen_layout(sgz_context *ctx)
     FftGeom fg{};
     fg.N = bestN;
     fg.hop = bestN - L + 1;
+    // 16-bit spectra unless the caller (or the environment, for tests) asks for fp32 ones
+    int fmt = ctx->spectra_format;
+    if (const char *e = std::getenv("SGZ_SPECTRA")) {
+        if (!std::strcmp(e, "f32")) fmt = 1;
+        if (!std::strcmp(e, "q16")) fmt = 2;
+    }
+    fg.q16 = fmt != 1;
     long long specOff = 0;
     for (int f = 0; f < nf; f++) {
         const FileDesc &fd = ctx->h_files[(size_t)f];
@@ -570,7 +768,12 @@ int fft_screen_layout(sgz_context *ctx)
     int rc;
     if ((rc = ensure_tab(ctx))) return rc;
     if ((rc = ensure(ctx, ctx->d_fblocks, ctx->d_fblocks_cap, nb))) return rc;
-    if ((rc = ensure(ctx, ctx->d_spec, ctx->spec_cap, (size_t)specOff))) return rc;
+    if ((rc = ensure(ctx, ctx->d_spec, ctx->spec_cap, fg.q16 ? ((size_t)specOff + 1) / 2 : (size_t)specOff))) return rc;
+    if (fg.q16) {
+        if ((rc = ensure(ctx, ctx->d_specscale, ctx->specscale_cap, nb * (size_t)numCh * (bestN / 128)))) return rc;
+        if ((rc = ensure(ctx, ctx->d_blkdq, ctx->blkdq_cap, nb * (size_t)numCh))) return rc;
+        if ((rc = ensure(ctx, ctx->d_blkq, ctx->blkq_cap, nb))) return rc;
+    }
     if ((rc = ensure(ctx, ctx->d_blksq, ctx->blksq_cap, nb * (size_t)numCh))) return rc;
     if ((rc = ensure(ctx, ctx->d_blknorm, ctx->blknorm_cap, nb))) return rc;
     if ((rc = ensure(ctx, ctx->d_blklnmin, ctx->blklnmin_cap, nb))) return rc;
@@ -585,6 +788,7 @@ int fft_screen_layout(sgz_context *ctx)
 int fft_screen_prepare(sgz_context *ctx, int file_begin, int file_end, hipStream_t stream)
 {
     const int N = ctx->fg.N, numCh = ctx->cp.numCh;
+    const bool q16 = ctx->fg.q16 != 0;
     const int b0 = ctx->fblock_begin[(size_t)file_begin], b1 = ctx->fblock_begin[(size_t)file_end];
     if (b1 == b0) return SGZ_OK;
     const int numPairs = (numCh + 1) / 2;
@@ -595,16 +799,20 @@ int fft_screen_prepare(sgz_context *ctx, int file_begin, int file_end, hipStream
         const int units = (b1 - b0) * numPairs;
         hipLaunchKernelGGL(kern, dim3((unsigned)((units + 7) & ~7)), dim3(N / 16), lds, stream, ctx->d_files,
                            ctx->d_fblocks + b0, numPairs, units, ctx->norm, numCh, ctx->d_fft_tab, ctx->d_spec,
-                           ctx->d_blksq + (size_t)b0 * numCh);
+                           ctx->d_blksq + (size_t)b0 * numCh,
+                           q16 ? ctx->d_specscale + (size_t)b0 * numCh * (N / 128) : nullptr,
+                           q16 ? ctx->d_blkdq + (size_t)b0 * numCh : nullptr);
         SGZ_HIP(ctx, hipGetLastError());
         return SGZ_OK;
     };
-    if (N == 4096) rc = launch(fft_spectra_kernel<4096>);
-    else if (N == 8192) rc = launch(fft_spectra_kernel<8192>);
-    else rc = launch(fft_spectra_kernel<16384>);
+    if (N == 4096) rc = q16 ? launch(fft_spectra_kernel<4096, true>) : launch(fft_spectra_kernel<4096, false>);
+    else if (N == 8192) rc = q16 ? launch(fft_spectra_kernel<8192, true>) : launch(fft_spectra_kernel<8192, false>);
+    else rc = q16 ? launch(fft_spectra_kernel<16384, true>) : launch(fft_spectra_kernel<16384, false>);
     if (rc) return rc;
     hipLaunchKernelGGL(fft_blknorm_kernel, dim3((b1 - b0 + 255) / 256), dim3(256), 0, stream,
-                       ctx->d_blksq + (size_t)b0 * numCh, numCh, b1 - b0, ctx->d_blknorm + b0);
+                       ctx->d_blksq + (size_t)b0 * numCh, numCh, b1 - b0, ctx->d_blknorm + b0,
+                       q16 ? ctx->d_blkdq + (size_t)b0 * numCh : nullptr, (float)(std::sqrt(2.0 / N) * 1.0001),
+                       q16 ? ctx->d_blkq + b0 : nullptr);
     SGZ_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(fft_blklnmin_kernel, dim3(b1 - b0), dim3(256), 0, stream, ctx->d_fblocks + b0, ctx->d_wstat_h,
                        ctx->total_windows, ctx->d_blklnmin + b0);
@@ -722,25 +930,33 @@ int fft_screen_launch(sgz_context *ctx, int file_begin, int file_end, hipStream_
     ctx->lokey_parity = 1 - par;
     if (b1 == b0) return SGZ_OK;
     const size_t lds = sizeof(float2) * fft_lds_elems(N);
+    const bool q16 = fg.q16 != 0;
+    const float *scales = q16 ? ctx->d_specscale + (size_t)b0 * ctx->cp.numCh * (N / 128) : nullptr;
+    const float2 *blkq = q16 ? ctx->d_blkq + b0 : nullptr;
     auto launch = [&](auto kern) -> int {
         if ((rc = set_lds(ctx, kern, lds))) return rc;
         if (start || stop)
             hipExtLaunchKernelGGL(kern, dim3(b1 - b0), dim3(N / 16), lds, stream, start, stop, 0, ctx->d_files, ctx->d_fblocks + b0,
-                                  ctx->d_spec, ctx->d_aspec, ctx->d_fft_tab, ctx->d_blknorm + b0, ctx->d_blklnmin + b0,
+                                  ctx->d_spec, ctx->d_aspec, ctx->d_fft_tab, ctx->d_blknorm + b0, scales, blkq, ctx->d_aspecscale, ctx->d_tgtdq, ctx->d_blklnmin + b0,
                                   ctx->d_wstat_h, ctx->total_windows, ctx->cp, fg, simOut, (float *)nullptr,
                                   lokey, lokeyNext, ctx->d_hflags, pre);
         else
             hipLaunchKernelGGL(kern, dim3(b1 - b0), dim3(N / 16), lds, stream, ctx->d_files, ctx->d_fblocks + b0, ctx->d_spec,
-                               ctx->d_aspec, ctx->d_fft_tab, ctx->d_blknorm + b0, ctx->d_blklnmin + b0,
+                               ctx->d_aspec, ctx->d_fft_tab, ctx->d_blknorm + b0, scales, blkq, ctx->d_aspecscale, ctx->d_tgtdq, ctx->d_blklnmin + b0,
                                ctx->d_wstat_h, ctx->total_windows, ctx->cp, fg, simOut, (float *)nullptr,
                                lokey, lokeyNext, ctx->d_hflags, pre);
         SGZ_HIP(ctx, hipGetLastError());
         return SGZ_OK;
     };
     const bool std14 = ctx->cp.numCh == 14;
-    if (N == 4096) return std14 ? launch(corr_fft_kernel<4096, 14>) : launch(corr_fft_kernel<4096, 0>);
-    if (N == 8192) return std14 ? launch(corr_fft_kernel<8192, 14>) : launch(corr_fft_kernel<8192, 0>);
-    return std14 ? launch(corr_fft_kernel<16384, 14>) : launch(corr_fft_kernel<16384, 0>);
+    if (q16) {
+        if (N == 4096) return std14 ? launch(corr_fft_kernel<4096, 14, true>) : launch(corr_fft_kernel<4096, 0, true>);
+        if (N == 8192) return std14 ? launch(corr_fft_kernel<8192, 14, true>) : launch(corr_fft_kernel<8192, 0, true>);
+        return std14 ? launch(corr_fft_kernel<16384, 14, true>) : launch(corr_fft_kernel<16384, 0, true>);
+    }
+    if (N == 4096) return std14 ? launch(corr_fft_kernel<4096, 14, false>) : launch(corr_fft_kernel<4096, 0, false>);
+    if (N == 8192) return std14 ? launch(corr_fft_kernel<8192, 14, false>) : launch(corr_fft_kernel<8192, 0, false>);
+    return std14 ? launch(corr_fft_kernel<16384, 14, false>) : launch(corr_fft_kernel<16384, 0, false>);
 }
 
 }  // namespace sgz
@@ -757,6 +973,22 @@ int sgz_corr_set_screen_kernel(sgz_context *ctx, int kernel)
     if (kernel != ctx->screen_kernel) ctx->layout_dirty = true;
     ctx->screen_kernel = kernel;
     return SGZ_OK;
+}
+
+int sgz_corr_set_spectra_format(sgz_context *ctx, int format)
+{
+    if (!ctx) return SGZ_E_ARG;
+    if (format < 0 || format > 2) return ctx->fail(SGZ_E_ARG, "spectra format: 0 (auto), 1 (fp32) or 2 (16-bit integers)");
+    if (format != ctx->spectra_format) ctx->layout_dirty = true;
+    ctx->spectra_format = format;
+    return SGZ_OK;
+}
+
+int sgz_corr_spectra_format_in_use(const sgz_context *ctx)
+{
+    if (!ctx || !ctx->have_target || ctx->layout_dirty) return -1;
+    if (ctx->fg.N <= 0) return 0;
+    return ctx->fg.q16 ? 2 : 1;
 }
 
 int sgz_corr_set_screen_output(sgz_context *ctx, int lists_only)

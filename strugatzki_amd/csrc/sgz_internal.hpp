@@ -98,6 +98,7 @@ struct HalfGeom {
 struct FftGeom {
     int N;      // transform length (0: spectral screening is not in use for this layout)
     int hop;    // windows per block: N - L + 1
+    int q16;    // the database spectra are kept as 16-bit integers with one scale per 64 bins (else fp32)
     // What the kernel needs to bound the error of a block's cross terms (it combines them with the block's norms):
     // epsT: norm-wise relative error of one transform (forward or inverse); epsUT / epsUS: the roundings outside the
     // transforms (operands, products, channel sums); Euclidean norms of the fp32 target values -- loudness channel,
@@ -129,7 +130,7 @@ struct FftBlock {
     int o0;
     int valid;
     int pad;
-    long long spec;  // offset (complex values) of the block's spectra [numCh][N / 2]
+    long long spec;  // offset (complex values: 8 bytes as fp32, 4 as 16-bit integers) of the block's spectra [numCh][N / 2]
     long long win;   // index of the block's first window in the dense per-window arrays
 };
 
@@ -237,6 +238,17 @@ struct sgz_context {
     float4 *d_blknorm = nullptr;             // per block, Euclidean norms: loudness channel, the others, channels 0 and 1,
                                              // sqrt(|x_T|^2 + 2 |x_S|^2)
     size_t blknorm_cap = 0;
+    int spectra_format = 0;                  // sgz_corr_set_spectra_format: 0 auto, 1 fp32, 2 16-bit integers
+    float *d_specscale = nullptr;            // 16-bit spectra: [block][numCh][N / 128] the value of one integer step
+    size_t specscale_cap = 0;
+    float *d_blkdq = nullptr;                // 16-bit spectra: [block][numCh] sum of squares of the rounding to 16 bits
+    size_t blkdq_cap = 0;
+    float *d_aspecscale = nullptr;           // 16-bit spectra: the target's scales [numCh][N / 128]
+    size_t aspecscale_cap = 0;
+    float *d_tgtdq = nullptr;                // 16-bit spectra: [numCh] sum of squares of the target spectra's rounding
+    size_t tgtdq_cap = 0;
+    float2 *d_blkq = nullptr;                // per block: that rounding as a norm of time-domain values, loudness / others
+    size_t blkq_cap = 0;
     bool aspec_dirty = true;
     int fc_begin = 0, fc_end = 0;            // files whose spectra are current
     float *d_blklnmin = nullptr;             // per block: smallest ln(average loudness) of its windows

@@ -190,6 +190,14 @@ class Context:
         self._check(lib.sgz_corr_screen_geometry(self._h, C.byref(n), C.byref(hop), C.byref(blocks)))
         return n.value, hop.value, blocks.value
 
+    def set_spectra_format(self, fmt: str) -> None:
+        """'auto', 'f32' or 'q16': how the spectral kernel keeps the database's spectra."""
+        self._check(lib.sgz_corr_set_spectra_format(self._h, {"auto": 0, "f32": 1, "q16": 2}[fmt]))
+
+    @property
+    def spectra_format_in_use(self) -> str | None:
+        return {1: "f32", 2: "q16", 0: "none"}.get(lib.sgz_corr_spectra_format_in_use(self._h))
+
     def corr_read_dense(self, file: int) -> tuple[np.ndarray, np.ndarray]:
         n = max(0, self.corr_num_windows(file))
         sim = np.empty(n, dtype=np.float32)

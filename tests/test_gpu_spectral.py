@@ -16,14 +16,19 @@ pytestmark = pytest.mark.gpu
 SLACK = 2e-3
 
 
-@pytest.fixture
-def spectral(ctx, monkeypatch):
-    """The shared context with the spectral kernel forced; back to the library's own choice afterwards."""
+@pytest.fixture(params=["q16", "f32"])
+def spectral(ctx, monkeypatch, request):
+    """The shared context with the spectral kernel forced, once with the database's and the target's spectra kept as
+    16-bit integers and once as fp32; back to the library's own choices afterwards."""
     monkeypatch.delenv("SGZ_SCREEN_KERNEL", raising=False)
     monkeypatch.delenv("SGZ_FFT_N", raising=False)
+    monkeypatch.delenv("SGZ_SPECTRA", raising=False)
     ctx.set_screen_kernel("spectral")
+    ctx.set_spectra_format(request.param)
+    ctx.spectra_format_wanted = request.param
     yield ctx
     ctx.set_screen_kernel("auto")
+    ctx.set_spectra_format("auto")
 
 
 def _load(ctx, db, norms):
@@ -80,6 +85,7 @@ def test_bounds_enclose_the_oracle(spectral, monkeypatch, L, n, extra):
     ctx.corr_set_target(tgt[ts:ts + L], 0.5, 8.0)
     ctx.corr_run_screen_f16(0, nf)
     assert ctx.screen_kernel_in_use == "spectral"
+    assert ctx.spectra_format_in_use == ctx.spectra_format_wanted
     gn, ghop, gblocks = ctx.screen_geometry
     assert (gn, ghop) == (n, hop)
     assert gblocks == sum(-(-len(s) // hop) for s in sims)
@@ -399,3 +405,33 @@ def test_candidate_list_overflow_falls_back(spectral):
         assert err.value.code == N.SGZ_E_OVERFLOW
     finally:
         ctx.set_screen_output(False)
+
+
+def test_sixteen_bit_spectra_widen_the_bounds_only_slightly(ctx, monkeypatch):
+    """The same run with fp32 and with 16-bit spectra: both enclose the oracle (checked above), the 16-bit ones
+    carry what the rounding to 16 bits was measured to be -- about half as much again; and the format can be
+    queried and is rebuilt on change."""
+    for v in ("SGZ_SCREEN_KERNEL", "SGZ_FFT_N", "SGZ_SPECTRA"):
+        monkeypatch.delenv(v, raising=False)
+    L, ts, nf, frames = 1500, 30, 3, 16000
+    db = synth_db(nf, frames, make_plants(2, L, nf, frames, ts))
+    tgt = synth_target(ts, L)
+    norms = norms_default()
+    _, sims, boosts = O.correlation_run(corr_config(ts, L, num_matches=2), tgt, norms, db)
+    ctx.set_screen_kernel("spectral")
+    try:
+        _load(ctx, db, norms)
+        ctx.corr_set_target(tgt[ts:ts + L], 0.5, 8.0)
+        width = {}
+        for fmt in ("f32", "q16", "auto"):
+            ctx.set_spectra_format(fmt)
+            ctx.corr_run_screen_f16(0, nf)
+            assert ctx.spectra_format_in_use == ("q16" if fmt == "auto" else fmt)
+            width[fmt] = _check_upper(ctx, sims, boosts)
+        assert width["f32"] <= width["q16"] <= 3.0 * width["f32"] + 1e-5
+        assert width["auto"] == width["q16"]
+        with pytest.raises(Exception):
+            ctx.set_spectra_format("f16")
+    finally:
+        ctx.set_screen_kernel("auto")
+        ctx.set_spectra_format("auto")

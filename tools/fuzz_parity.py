@@ -34,6 +34,7 @@ def run(cases: int, seed: int, ctx=None, verbose=True, kernels=None) -> int:
             if v is not None:
                 os.environ[k] = v
         ctx.set_screen_kernel("auto")
+        ctx.set_spectra_format("auto")
     if own:
         ctx.close()
     return bad
@@ -82,6 +83,7 @@ def _one_case(ctx, rng, case, verbose, draw_kernel=False) -> bool:
         if kern == "spectral" and fft_n > L:
             os.environ["SGZ_FFT_N"] = str(fft_n)
         ctx.set_screen_kernel(kern)
+        ctx.set_spectra_format(str(rng.choice(["auto", "q16", "f32"])))
     windows = sum(max(f - L + 1, 1) for f in frames)
     dense = draw_kernel and windows * L * num_ch < 3e8
     want, sims, boosts = O.correlation_run(cfg, tgt, norms, db, dense=dense)
@@ -100,7 +102,7 @@ def _one_case(ctx, rng, case, verbose, draw_kernel=False) -> bool:
             if d.size and not np.all(d >= 0.0):
                 if verbose:
                     print(f"BOUND BELOW ORACLE case {case}: file {f} by {d.min():.3e} kern={kern} n={fft_n} "
-                          f"in use {ctx.screen_kernel_in_use} {ctx.screen_geometry} ch={num_ch} L={L} frames={frames} "
+                          f"in use {ctx.screen_kernel_in_use} {ctx.spectra_format_in_use} {ctx.screen_geometry} ch={num_ch} L={L} frames={frames} "
                           f"w={weight} norm={normalize}", flush=True)
                 return False
     p = S.SearchParams(num_matches, num_per_file, min_spacing, STEP, screen=mode != "none",

@@ -11,7 +11,7 @@ if [ "$1" = build ]; then
   mkdir -p $OUT
   make -C $ROOT/strugatzki_amd/csrc -j8 > /dev/null
   cd $ROOT/strugatzki_amd/csrc
-  for v in 0 1 2 3; do
+  for v in ${PROBES:-0 1 2 3}; do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden -I$ROOT/include \
       -DSGZ_PROBE=$v -c sgz_corr_fft.hip -o /tmp/sgz_probe_$v.o
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/lib_probe$v.so \
@@ -19,7 +19,7 @@ if [ "$1" = build ]; then
   done
 else
   cd $ROOT
-  for v in 0 1 2 3; do
+  for v in ${PROBES:-0 1 2 3}; do
     SGZ_LIB_PATH=$OUT/lib_probe$v.so timeout -k 10 100 python3 tools/spectral_probe_timing.py || exit 1
     SGZ_LIB_PATH=$OUT/lib_probe$v.so PROBE_L=5168 PROBE_NF=1500 timeout -k 10 100 python3 tools/spectral_probe_timing.py || exit 1
   done
