@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256) void boost_fill_kernel(float *wstat, long long
 // Q16: the spectra are 16-bit integers with band scales (four bins per 16-byte load); `blkq` holds the block's
 // rounding terms.
 template <int N, int NCH, bool Q16>
-__global__ __launch_bounds__(N / 16) void corr_fft_kernel(const FileDesc *__restrict__ files,
+__global__ __launch_bounds__(N / 16, 4) void corr_fft_kernel(const FileDesc *__restrict__ files,
                                                           const FftBlock *__restrict__ blocks,
                                                           const float2 *__restrict__ spec,
                                                           const float2 *__restrict__ aspec,
