@@ -90,7 +90,7 @@ __device__ __forceinline__ float2 q16_decode(unsigned int q, float scale)
 __device__ __forceinline__ unsigned int q16_encode_band(float2 v, float &scaleOut, float &dq)
 {
     float mx = fmaxf(fabsf(v.x), fabsf(v.y));
-    int bad = !(mx <= 3.0e38f);
+    int bad = !(fabsf(v.x) <= 3.0e38f) || !(fabsf(v.y) <= 3.0e38f);  // (fmaxf drops a NaN next to a number)
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
         mx = fmaxf(mx, __shfl_xor(mx, off, 64));

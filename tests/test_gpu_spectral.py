@@ -435,3 +435,30 @@ def test_sixteen_bit_spectra_widen_the_bounds_only_slightly(ctx, monkeypatch):
     finally:
         ctx.set_screen_kernel("auto")
         ctx.set_spectra_format("auto")
+
+
+@pytest.mark.parametrize("value", [np.nan, np.inf, -np.inf])
+@pytest.mark.parametrize("num_per_file", [1, 2])
+def test_values_that_are_not_numbers(spectral, value, num_per_file):
+    """A NaN or an infinity among a file's frames.  Feature files do not hold such values (the extraction replaces
+    them, impl/NonRealtimeProcessor.scala:178-190), so this is about the library agreeing with itself: the
+    screened search must return what its exact search (every window in fp64, no screening) returns, whatever form
+    the spectra are kept in -- a band of 16-bit spectra with such a component gets a NaN scale, the block's bounds
+    come out as NaN and the file goes to the exact path."""
+    import strugatzki_amd as S
+    ctx = spectral
+    L, ts, nf, frames = 300, 12, 4, 5000
+    db = synth_db(nf, frames, make_plants(3, L, nf, frames, ts))
+    db[1][2000, 3] = np.float32(value)
+    db[2][10, 0] = np.float32(value)
+    db[2][4990, 7] = np.float32(value)
+    tgt = synth_target(ts, L)
+    _load(ctx, db, norms_default())
+    ctx.corr_set_target(tgt[ts:ts + L], 0.5, 8.0)
+    got = S.search(ctx, S.SearchParams(4, num_per_file, 0, STEP))
+    assert ctx.screen_kernel_in_use == "spectral"
+    want = S.search(ctx, S.SearchParams(4, num_per_file, 0, STEP, screen=False))
+    assert len(want) == 4
+    assert [(g.file, g.start, g.stop) for g in got] == [(w.file, w.start, w.stop) for w in want]
+    for g, w in zip(got, want):
+        assert abs(g.sim - w.sim) <= 1.2e-7 or (np.isnan(g.sim) and np.isnan(w.sim))
