@@ -531,19 +531,21 @@ __global__ __launch_bounds__(N / 16, 4) void corr_fft_kernel(const FileDesc *__r
         const float mT = fabsf((float)cpf.sumAT) / ((float)cp.aStdT * nT) * 1.0001f;
         const float mS = fabsf((float)cpf.sumAS) / ((float)cp.aStdS * nS) * 1.0001f;
         const float wT = cp.w, wS = 1.0f - cp.w, relErr = fg.relErr;
+        // (the records of G windows per thread are on their way at a time; 8 instead of 4 changes nothing measurable)
+        constexpr int G = 4;
 #pragma unroll
-        for (int m0 = 0; m0 < 16; m0 += 4) {
+        for (int m0 = 0; m0 < 16; m0 += G) {
 #pragma unroll
-            for (int u = 0; u < 4; u++) ups[m0 + u] = -INFINITY;
+            for (int u = 0; u < G; u++) ups[m0 + u] = -INFINITY;
             if (m0 * T < bd.valid) {  // (uniform over the workgroup)
-                float4 rec[4];
+                float4 rec[G];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < G; u++) {
                     const int k = tid + (m0 + u) * T;
                     rec[u] = st.rec[bd.win + (k < bd.valid ? k : 0)];
                 }
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < G; u++) {
                     const int k = tid + (m0 + u) * T;
                     const bool live = k < bd.valid;
                     const float2 y = buf[fft_phys(live ? k : 0)];
