@@ -292,8 +292,8 @@ SGZ_API int sgz_corr_rescore_device(sgz_context *ctx, sgz_candidate *device_cand
  * tight serving loops, harnesses that forbid hipMalloc): same inputs, same results, but the partial sums of
  * the re-scoring live in a fixed 4 MiB array that is part of the library's device code instead of a buffer
  * allocated on demand, and the call makes no hipMalloc / hipFree.  No counterpart in the reference.
- * Limit: capacity * slices * 48 bytes <= 4 MiB with slices = ceil(L * numCh / 4096) (at most 64) for the
- * current target of L frames -- 9 709 records for a 30 s target of 14 channels; beyond it SGZ_E_ARG, nothing
+ * Limit: capacity * slices * 56 bytes <= 4 MiB with slices = ceil(L * numCh / 4096) (at most 64) for the
+ * current target of L frames -- 8 322 records for a 30 s target of 14 channels; beyond it SGZ_E_ARG, nothing
  * is launched.  All calls on one GPU (of any context) share that GPU's array: calls that overlap in time on
  * one GPU race; calls queued on one stream do not.  Needs a layout (an sgz_corr_run* since the last change
  * of database, norms or target length), as sgz_corr_rescore_device does. */

@@ -1150,7 +1150,8 @@ __global__ __launch_bounds__(256) void prelist_filter_kernel(const sgz_candidate
 // values, and a thread's channel constants stay in registers.
 // ---------------------------------------------------------------------------
 constexpr int kRsThreads = 256;
-constexpr int kRsParts = 6;  // sumT, sumS, sqT, sqS, crossT, crossS
+constexpr int kRsParts = 7;  // sumT, sumS, sqT, sqS, crossT, crossS; the window's loudness shift m0T (the same in every slice)
+constexpr int kRsSums = 6;
 
 // Records of a candidate list that may be read.  A count beyond the capacity comes from two sources: more
 // candidates than slots (then every slot is written), or a compaction kernel that reports a file it cannot
@@ -1261,6 +1262,7 @@ __global__ __launch_bounds__(kRsThreads) void rescore_pass_kernel(
             out[3] = qS;
             out[4] = xT;
             out[5] = xS;
+            out[6] = m0T;  // (the final kernel then needs neither the file table nor the frames)
         }
     }
 }
@@ -1315,13 +1317,12 @@ __global__ __launch_bounds__(256) void rescore_final_kernel(const FileDesc *__re
     const double nT = (double)cp.L, nS = (double)cp.L * (double)(cp.numCh - 1);
     for (long long ci = (long long)blockIdx.x * blockDim.x + threadIdx.x; ci < n;
          ci += (long long)gridDim.x * blockDim.x) {
-        double t[kRsParts] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        double t[kRsSums] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         for (int k = 0; k < rg.slices; k++)
 #pragma unroll
-            for (int j = 0; j < kRsParts; j++) t[j] += part[(ci * rg.slices + k) * kRsParts + j];
+            for (int j = 0; j < kRsSums; j++) t[j] += part[(ci * rg.slices + k) * kRsParts + j];
         sgz_candidate c = cands[ci];
-        double m0T, m0S;
-        window_shift(files[c.file].raw + (long long)c.offset * cp.numCh, normTab, normEnabled, m0T, m0S);
+        const double m0T = part[ci * rg.slices * kRsParts + 6];
         const double dT = t[0] / nT, dS = t[1] / nS;  // mean - m0
         const float avgF = (float)(m0T + dT);
         const double lnAvgB = log((double)avgF);
