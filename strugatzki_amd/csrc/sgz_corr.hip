@@ -1165,16 +1165,6 @@ __device__ __forceinline__ long long listed_records(unsigned long long count, lo
     return (long long)count;
 }
 
-__device__ __forceinline__ double block_sum_256(double v, double *scratch /* 4 doubles */)
-{
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    __syncthreads();  // scratch may still be read from the previous call
-    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
-}
-
 struct RescoreGeom {
     int slices;       // per window
     int sliceFrames;  // frames per slice (the last one may be shorter)
@@ -1201,7 +1191,7 @@ __global__ __launch_bounds__(kRsThreads) void rescore_pass_kernel(
     int truncatedOk, double *__restrict__ part /* [window][slice][kRsParts] */)
 {
     constexpr int U = 16;  // loads in flight per thread
-    __shared__ double scratch[4];
+    __shared__ double scratch6[kRsSums][4];
     const long long n = listed_records(*count, capacity, truncatedOk);
     const long long work = n * rg.slices;
     if ((long long)blockIdx.x >= work) return;
@@ -1249,19 +1239,20 @@ __global__ __launch_bounds__(kRsThreads) void rescore_pass_kernel(
             }
         }
         double *out = part + w * kRsParts;
-        const double sT = block_sum_256(isT ? s : 0.0, scratch);
-        const double sS = block_sum_256(isT ? 0.0 : s, scratch);
-        const double qT = block_sum_256(isT ? q : 0.0, scratch);
-        const double qS = block_sum_256(isT ? 0.0 : q, scratch);
-        const double xT = block_sum_256(isT ? x : 0.0, scratch);
-        const double xS = block_sum_256(isT ? 0.0 : x, scratch);
+        // the six sums over the workgroup at once: wave sums by shuffles, the four waves' results through LDS
+        double v6[kRsSums] = {isT ? s : 0.0, isT ? 0.0 : s, isT ? q : 0.0, isT ? 0.0 : q, isT ? x : 0.0, isT ? 0.0 : x};
+#pragma unroll
+        for (int j = 0; j < kRsSums; j++)
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) v6[j] += __shfl_xor(v6[j], off, 64);
+        __syncthreads();  // scratch may still be read from the window before
+        if ((tid & 63) == 0)
+#pragma unroll
+            for (int j = 0; j < kRsSums; j++) scratch6[j][tid >> 6] = v6[j];
+        __syncthreads();
         if (tid == 0) {
-            out[0] = sT;
-            out[1] = sS;
-            out[2] = qT;
-            out[3] = qS;
-            out[4] = xT;
-            out[5] = xS;
+#pragma unroll
+            for (int j = 0; j < kRsSums; j++) out[j] = (scratch6[j][0] + scratch6[j][1]) + (scratch6[j][2] + scratch6[j][3]);
             out[6] = m0T;  // (the final kernel then needs neither the file table nor the frames)
         }
     }
