@@ -19,7 +19,6 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
-#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1802,15 +1801,39 @@ int sgz_corr_set_target(sgz_context *ctx, const float *frames, int num_frames, f
     if (!frames || num_frames < 1) return ctx->fail(SGZ_E_ARG, "target needs at least one frame");
     SGZ_HIP(ctx, hipSetDevice(ctx->device));
     const int numCh = ctx->numCh, L = num_frames;
+    // Everything the device gets of a target is written into one pinned buffer and copied asynchronously on the
+    // context's stream (a query service sets a new target per search: four blocking copies out of pageable memory
+    // were most of this call).  The stream is drained first: kernels of the search before may still read the old
+    // target, and its copies this buffer.
+    int S = (L + kR - 1) / kR;
+    S = (S + 1) & ~1;
+    const size_t Lpad = (size_t)S * kR;
+    const size_t nTb = (size_t)numCh * L, nAp = (size_t)numCh * Lpad;
+    auto up256 = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t offAp = 0, offTn = up256(offAp + sizeof(double) * nAp), offApf = up256(offTn + sizeof(float) * 2 * nTb);
+    const size_t offImg = up256(offApf + sizeof(float) * nAp);
+    const size_t imgHalfwords = sgz::half_image_halfwords(L, numCh);
+    const size_t stageBytes = up256(offImg + sizeof(uint16_t) * imgHalfwords);
+    SGZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SGZ_HIP(ctx, hipStreamSynchronize(ctx->screen_stream));
+    if (stageBytes > ctx->tgt_stage_cap) {
+        if (ctx->h_tgt_stage) (void)hipHostFree(ctx->h_tgt_stage);
+        ctx->h_tgt_stage = nullptr;
+        ctx->tgt_stage_cap = 0;
+        SGZ_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_tgt_stage), stageBytes, hipHostMallocDefault));
+        ctx->tgt_stage_cap = stageBytes;
+    }
+    double *ap = reinterpret_cast<double *>(ctx->h_tgt_stage + offAp);
+    float *tb = reinterpret_cast<float *>(ctx->h_tgt_stage + offTn), *tfm = tb + nTb;  // channel-major, frame-major
+    float *apf = reinterpret_cast<float *>(ctx->h_tgt_stage + offApf);
     // readInBuffer (impl/FeatureCorrelationImpl.scala:83-98): de-interleave, normalise (fp32)
-    std::vector<float> tb((size_t)numCh * L);
-    for (int c = 0; c < numCh; c++) {
-        for (int i = 0; i < L; i++) {
+    for (int i = 0; i < L; i++)
+        for (int c = 0; c < numCh; c++) {
             float v = frames[(size_t)i * numCh + c];
             if (ctx->norm.enabled) v = (v - ctx->norm.mn[c]) / ctx->norm.d[c];
             tb[(size_t)c * L + i] = v;
+            tfm[(size_t)i * numCh + c] = v;
         }
-    }
     // MathUtil.stat over the loudness row and over the MFCC rows (two passes, fp64)
     auto stat = [&](int c0, int c1, double &mean, double &sd) {
         double sum = 0.0;
@@ -1837,8 +1860,6 @@ int sgz_corr_set_target(sgz_context *ctx, const float *frames, int num_frames, f
     const int oldL = ctx->have_target ? cp.L : -1;
     cp.numCh = numCh;
     cp.L = L;
-    int S = (L + kR - 1) / kR;
-    S = (S + 1) & ~1;
     cp.S = S;
     cp.nb = (S + kSBMax - 1) / kSBMax;
     int SB = (S + cp.nb - 1) / cp.nb;
@@ -1852,57 +1873,65 @@ int sgz_corr_set_target(sgz_context *ctx, const float *frames, int num_frames, f
     cp.w = temporal_weight;
     cp.maxBoost = max_boost;
 
-    const size_t Lpad = (size_t)S * kR;
-    std::vector<double> ap((size_t)numCh * Lpad, 0.0);
+    // centred target in fp64 and rounded to fp32, zero-padded to Lpad per channel; of the fp32 values what the
+    // spectral screening needs: their sums and Euclidean norms per channel group
     double sumT = 0.0, sumS = 0.0;
+    double fs[2] = {0.0, 0.0}, fq[2] = {0.0, 0.0}, fq1 = 0.0;
+    bool finite = true;  // every centred value within the half-precision range
     for (int c = 0; c < numCh; c++) {
         const double mean = c == 0 ? tMean : sMean;
+        double *apc = ap + (size_t)c * Lpad;
+        float *apfc = apf + (size_t)c * Lpad;
         for (int i = 0; i < L; i++) {
             const double v = (double)tb[(size_t)c * L + i] - mean;  // ca(i) + aAdd, MathUtil.scala:190
-            ap[(size_t)c * Lpad + i] = v;
+            apc[i] = v;
             if (c == 0) sumT += v; else sumS += v;
+            finite = finite && std::fabs(v) <= 60000.0;  // (false for NaN as well)
+            const float vf = (float)v;
+            apfc[i] = vf;
+            const double w = (double)vf;
+            fs[c > 0] += w;
+            fq[c > 0] += w * w;
+            if (c == 1) fq1 += w * w;
+        }
+        for (size_t i = (size_t)L; i < Lpad; i++) {
+            apc[i] = 0.0;
+            apfc[i] = 0.0f;
         }
     }
     cp.sumAT = sumT;
     cp.sumAS = sumS;
-    int rc;
-    SGZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    SGZ_HIP(ctx, hipStreamSynchronize(ctx->screen_stream));
-    if ((rc = ensure(ctx, ctx->d_aprime, ctx->aprime_cap, ap.size()))) return rc;
-    SGZ_HIP(ctx, hipMemcpy(ctx->d_aprime, ap.data(), sizeof(double) * ap.size(), hipMemcpyHostToDevice));
-    // normalised target twice: channel-major [numCh][L], then frame-major [L][numCh]
-    std::vector<float> tboth(2 * tb.size());
-    std::memcpy(tboth.data(), tb.data(), sizeof(float) * tb.size());
-    for (int c = 0; c < numCh; c++)
-        for (int i = 0; i < L; i++) tboth[tb.size() + (size_t)i * numCh + c] = tb[(size_t)c * L + i];
-    if ((rc = ensure(ctx, ctx->d_tnorm, ctx->tnorm_cap, tboth.size()))) return rc;
-    SGZ_HIP(ctx, hipMemcpy(ctx->d_tnorm, tboth.data(), sizeof(float) * tboth.size(), hipMemcpyHostToDevice));
+    ctx->tgt_nrm1 = std::sqrt(fq1);
+    ctx->tgt_sumT = fs[0];
+    ctx->tgt_sumS = fs[1];
+    ctx->tgt_nrmT = std::sqrt(fq[0]);
+    ctx->tgt_nrmS = std::sqrt(fq[1]);
+    ctx->aspec_dirty = true;
     ctx->aMeanT = tMean;
     ctx->aMeanS = sMean;
-    std::vector<float> apf(ap.size());
-    for (size_t i = 0; i < ap.size(); i++) apf[i] = (float)ap[i];
-    {  // what the spectral screening needs of the fp32 values: their sums and Euclidean norms per channel group
-        double s[2] = {0.0, 0.0}, q[2] = {0.0, 0.0}, q1 = 0.0;
-        for (int c = 0; c < numCh; c++)
-            for (int i = 0; i < L; i++) {
-                const double v = (double)apf[(size_t)c * Lpad + i];
-                s[c > 0] += v;
-                q[c > 0] += v * v;
-                if (c == 1) q1 += v * v;
-            }
-        ctx->tgt_nrm1 = std::sqrt(q1);
-        ctx->tgt_sumT = s[0];
-        ctx->tgt_sumS = s[1];
-        ctx->tgt_nrmT = std::sqrt(q[0]);
-        ctx->tgt_nrmS = std::sqrt(q[1]);
-        ctx->aspec_dirty = true;
-    }
-    if ((rc = ensure(ctx, ctx->d_aprime_f, ctx->aprime_f_cap, apf.size()))) return rc;
-    SGZ_HIP(ctx, hipMemcpy(ctx->d_aprime_f, apf.data(), sizeof(float) * apf.size(), hipMemcpyHostToDevice));
+    int rc;
+    if ((rc = ensure(ctx, ctx->d_aprime, ctx->aprime_cap, nAp))) return rc;
+    if ((rc = ensure(ctx, ctx->d_tnorm, ctx->tnorm_cap, 2 * nTb))) return rc;
+    if ((rc = ensure(ctx, ctx->d_aprime_f, ctx->aprime_f_cap, nAp))) return rc;
+    SGZ_HIP(ctx, hipMemcpyAsync(ctx->d_aprime, ap, sizeof(double) * nAp, hipMemcpyHostToDevice, ctx->stream));
+    // normalised target twice: channel-major [numCh][L], then frame-major [L][numCh]
+    SGZ_HIP(ctx, hipMemcpyAsync(ctx->d_tnorm, tb, sizeof(float) * 2 * nTb, hipMemcpyHostToDevice, ctx->stream));
+    SGZ_HIP(ctx, hipMemcpyAsync(ctx->d_aprime_f, apf, sizeof(float) * nAp, hipMemcpyHostToDevice, ctx->stream));
     ctx->have_target = true;
     // half-precision target image of the matrix-core screening kernel (none when the geometry does not fit)
     const bool hadHalf = ctx->hg.S2 > 0;
-    if ((rc = half_screen_set_target(ctx, ap, Lpad))) return rc;
+    // (the image itself is built when that kernel first runs with this target: converting 36 000 values to half
+    // precision on the host takes longer than the rest of this call, and searches screened by the spectral kernel
+    // never read it)
+    ctx->half_stage_ap = ap;
+    ctx->half_stage_lpad = Lpad;
+    ctx->half_stage_img = reinterpret_cast<uint16_t *>(ctx->h_tgt_stage + offImg);
+    ctx->half_stage_halfwords = imgHalfwords;
+    if ((rc = half_screen_set_target(ctx, finite))) return rc;
+    // (the fp32 screening runs on the other stream: it waits for the uploads)
+    if (!ctx->tgt_event) SGZ_HIP(ctx, hipEventCreateWithFlags(&ctx->tgt_event, hipEventDisableTiming));
+    SGZ_HIP(ctx, hipEventRecord(ctx->tgt_event, ctx->stream));
+    SGZ_HIP(ctx, hipStreamWaitEvent(ctx->screen_stream, ctx->tgt_event, 0));
     if (oldL != L || hadHalf != (ctx->hg.S2 > 0)) ctx->layout_dirty = true;
     // the NaN marks of half-precision runs belong to the previous target
     // (a pending layout rebuild clears all marks itself, for the files of the new layout)

@@ -376,56 +376,82 @@ int half_screen_pick_tile(sgz_context *ctx, const long long *numWindows, int num
     return SGZ_OK;
 }
 
-// Builds the two shifted half-precision copies of every target channel.
-// Copy k (k = 0, 1), halfword position p holds a'[p - 16 + k].
-int half_screen_set_target(sgz_context *ctx, const std::vector<double> &aprime, size_t Lpad)
+// Halfwords of the target image (two shifted half-precision copies of every channel: copy k = 0, 1 holds a'[p - 16 + k]
+// at halfword position p) at the widest geometry that fits: what sgz_corr_set_target reserves in its staging buffer.
+size_t half_image_halfwords(int L, int numCh)
+{
+    size_t need = 0;
+    for (size_t k = 0; k < sizeof kHalfWidths / sizeof kHalfWidths[0]; k++) {
+        HalfGeom hg{};
+        if (half_geom(L, kHalfWidths[k], hg)) need = std::max(need, (size_t)numCh * 2 * 2 * (size_t)hg.LAd);
+    }
+    return need;
+}
+
+// Geometry of the matrix-core kernel for the new target (none when it does not fit the LDS or the target leaves the
+// half-precision range); the image is left to half_image_build.
+int half_screen_set_target(sgz_context *ctx, bool in_half_range)
 {
     HalfGeom hg{};
     const int L = ctx->cp.L, numCh = ctx->cp.numCh;
     // the width in use stays (the layout is built for it; a new target length rebuilds the layout and picks again)
     bool fits = ctx->hg.S2 > 0 && half_geom(L, ctx->hg.NB, hg);
     for (size_t k = 0; !fits && k < sizeof kHalfWidths / sizeof kHalfWidths[0]; k++) fits = half_geom(L, kHalfWidths[k], hg);
-    if (!fits) {
+    const size_t total = (size_t)numCh * 2 * 2 * (size_t)hg.LAd;
+    if (!fits || !in_half_range || total > ctx->half_stage_halfwords) {
         ctx->hg = HalfGeom{};
+        ctx->half_img_dirty = false;
         return SGZ_OK;
     }
-    for (int c = 0; c < numCh; c++)
-        for (int i = 0; i < L; i++)
-            if (!(std::fabs(aprime[(size_t)c * Lpad + i]) <= 60000.0)) {  // also NaN: no half-precision image
-                ctx->hg = HalfGeom{};
-                return SGZ_OK;
-            }
+    hg.relErrT = half_rel_err(1, hg.S2);
+    hg.relErrS = half_rel_err(numCh - 1, hg.S2);
+    ctx->hg = hg;
+    ctx->half_img_dirty = true;
+    return SGZ_OK;
+}
+
+// The target's half-precision image (every channel at shifts 0 and 1 halfword) and the sums of its values, from the
+// fp64 target staged by sgz_corr_set_target; the copy to the device is queued on `stream`.
+static int half_image_build(sgz_context *ctx, hipStream_t stream)
+{
+    HalfGeom &hg = ctx->hg;
+    const int L = ctx->cp.L, numCh = ctx->cp.numCh;
     const size_t perCopy = (size_t)2 * hg.LAd;  // halfwords
-    std::vector<uint16_t> img((size_t)numCh * 2 * perCopy, 0);
+    const size_t total = (size_t)numCh * 2 * perCopy, Lpad = ctx->half_stage_lpad;
+    uint16_t *stage = ctx->half_stage_img;
+    const double *aprime = ctx->half_stage_ap;
+    if (!stage || !aprime || total > ctx->half_stage_halfwords) return ctx->fail(SGZ_E_STATE, "no staged target");
+    std::memset(stage, 0, total * sizeof(uint16_t));
     double sumT = 0.0, sumS = 0.0;
     for (int c = 0; c < numCh; c++) {
+        uint16_t *c0 = stage + ((size_t)c * 2) * perCopy + 16, *c1 = stage + ((size_t)c * 2 + 1) * perCopy + 15;
         for (int i = 0; i < L; i++) {
             const _Float16 hv = (_Float16)aprime[(size_t)c * Lpad + i];
             uint16_t bits;
             std::memcpy(&bits, &hv, 2);
             if (c == 0) sumT += (double)hv; else sumS += (double)hv;
-            for (int k = 0; k < 2; k++) {
-                const long long p = (long long)i + 16 - k;
-                if (p >= 0 && p < (long long)perCopy) img[((size_t)c * 2 + k) * perCopy + (size_t)p] = bits;
-            }
+            c0[i] = bits;  // the image at shift 0 and, one halfword earlier, at shift 1 (L + 16 <= 2 LAd)
+            c1[i] = bits;
         }
     }
     hg.sumAT = sumT;
     hg.sumAS = sumS;
-    hg.relErrT = half_rel_err(1, hg.S2);
-    hg.relErrS = half_rel_err(numCh - 1, hg.S2);
     int rc;
-    if ((rc = ensure(ctx, ctx->d_aimg_h, ctx->aimg_h_cap, img.size()))) return rc;
-    SGZ_HIP(ctx, hipMemcpy(ctx->d_aimg_h, img.data(), img.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-    ctx->hg = hg;
+    if ((rc = ensure(ctx, ctx->d_aimg_h, ctx->aimg_h_cap, total))) return rc;
+    SGZ_HIP(ctx, hipMemcpyAsync(ctx->d_aimg_h, stage, total * sizeof(uint16_t), hipMemcpyHostToDevice, stream));
+    ctx->half_img_dirty = false;
     return SGZ_OK;
 }
 
 int half_screen_launch(sgz_context *ctx, int tile_begin, int tile_end, hipStream_t stream, hipEvent_t start,
                        hipEvent_t stop)
 {
+    if (ctx->hg.S2 <= 0) return ctx->fail(SGZ_E_STATE, "half-precision screening is not available for this target");
+    if (ctx->half_img_dirty) {
+        const int irc = half_image_build(ctx, stream);
+        if (irc) return irc;
+    }
     const HalfGeom &hg = ctx->hg;
-    if (hg.S2 <= 0) return ctx->fail(SGZ_E_STATE, "half-precision screening is not available for this target");
     const size_t ldsBytes = half_lds_bytes(hg);
     const _Float16 *planarH = reinterpret_cast<const _Float16 *>(ctx->d_planar_h);
     const uint32_t *aimg = reinterpret_cast<const uint32_t *>(ctx->d_aimg_h);

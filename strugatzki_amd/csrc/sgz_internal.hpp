@@ -156,6 +156,15 @@ struct sgz_context {
     // target
     bool have_target = false;
     sgz::CorrParams cp{};
+    // the matrix-core kernel's target image is built from the staged fp64 target when that kernel first needs it
+    const double *half_stage_ap = nullptr;
+    size_t half_stage_lpad = 0;
+    uint16_t *half_stage_img = nullptr;
+    size_t half_stage_halfwords = 0;
+    bool half_img_dirty = false;
+    hipEvent_t tgt_event = nullptr;        // the target's upload on `stream`, for the other stream that reads it
+    unsigned char *h_tgt_stage = nullptr;  // pinned: what sgz_corr_set_target uploads, written in place and copied
+    size_t tgt_stage_cap = 0;              // asynchronously (the stream is idle when the next target overwrites it)
     double *d_aprime = nullptr;  // [numCh][S * kR] centred target, fp64
     size_t aprime_cap = 0;
     float *d_tnorm = nullptr;     // [numCh][L] normalised target, fp32 (exact re-scoring)
@@ -354,7 +363,8 @@ namespace sgz {
 // sgz_corr_mfma.hip
 bool half_screen_fits(const sgz_context *ctx);
 int half_screen_pick_tile(sgz_context *ctx, const long long *numWindows, int numFiles);
-int half_screen_set_target(sgz_context *ctx, const std::vector<double> &aprime, size_t Lpad);
+size_t half_image_halfwords(int L, int numCh);
+int half_screen_set_target(sgz_context *ctx, bool in_half_range);
 int half_screen_launch(sgz_context *ctx, int tile_begin, int tile_end, hipStream_t stream, hipEvent_t start,
                        hipEvent_t stop);
 
