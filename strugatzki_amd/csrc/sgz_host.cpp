@@ -5,11 +5,15 @@
 // processor from its XML config.
 #include <zlib.h>
 
+#include <sys/stat.h>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <filesystem>
 #include <fstream>
+#include <mutex>
+#include <unordered_map>
 
 #include "strugatzki_amd.hpp"
 
@@ -119,6 +123,41 @@ std::vector<Match> runFeatureCorrelation(sgz_context *ctx, const FeatureCorrelat
     return runFeatureCorrelationMulti(std::vector<sgz_context *>{ctx}, cfg, obs);
 }
 
+// Size and modification time of a file from one stat call ("?" where it fails): the label of a resident file.
+std::string fileStamp(const std::string &path)
+{
+    struct stat st;
+    if (::stat(path.c_str(), &st) != 0) return "?:?";
+    return std::to_string((long long)st.st_size) + ":" + std::to_string((long long)st.st_mtim.tv_sec) + "." +
+           std::to_string((long long)st.st_mtim.tv_nsec);
+}
+
+// A database meta file, parsed once per content: a search service reads the same folder for every query, and
+// parsing its meta files was a quarter of a call over a resident database.  Keyed by path, valid while size and
+// modification time stay what they were.
+FeatureExtractionConfig cachedMeta(const std::string &path)
+{
+    struct Entry {
+        std::string stamp;
+        FeatureExtractionConfig cfg;
+    };
+    static std::mutex mu;
+    static std::unordered_map<std::string, Entry> cache;
+    const std::string stamp = fileStamp(path);
+    if (stamp != "?:?") {
+        std::lock_guard<std::mutex> lock(mu);
+        const auto it = cache.find(path);
+        if (it != cache.end() && it->second.stamp == stamp) return it->second.cfg;
+    }
+    FeatureExtractionConfig cfg = FeatureExtractionConfig::fromXMLFile(path);
+    if (stamp != "?:?" && fileStamp(path) == stamp) {  // (not a file that changed while it was read)
+        std::lock_guard<std::mutex> lock(mu);
+        if (cache.size() > 200000) cache.clear();
+        cache[path] = Entry{stamp, cfg};
+    }
+    return cfg;
+}
+
 // The same over several contexts (one per GPU of the node): the compatible database files are dealt round robin,
 // in iteration order, to the contexts; each keeps its share resident.  A context that still holds exactly these
 // files from an earlier call (same paths, sizes and modification times: sgz_db_tag) is not loaded again, so a
@@ -140,13 +179,15 @@ std::vector<Match> runFeatureCorrelationMulti(const std::vector<sgz_context *> &
     std::vector<std::string> metas;
     std::error_code ec;
     const fs::path inMeta = fs::path(cfg.metaInput).lexically_normal();
+    const std::string inMetaName = inMeta.filename().string();
     for (const auto &e : fs::directory_iterator(cfg.databaseFolder, ec)) {
         const std::string name = e.path().filename().string();
         if (name.size() < 9 || name.compare(name.size() - 9, 9, "_feat.xml") != 0) continue;
         const fs::path p = (fs::path(cfg.databaseFolder) / name).lexically_normal();
         if (p == inMeta) continue;
+        // (the same file through another spelling of the folder: only an entry of the input's own name can be it)
         std::error_code ec2;
-        if (fs::exists(inMeta, ec2) && fs::equivalent(p, inMeta, ec2)) continue;
+        if (name == inMetaName && fs::exists(inMeta, ec2) && fs::equivalent(p, inMeta, ec2)) continue;
         metas.push_back(p.string());
     }
     if (ec) throw Error(SGZ_E_IO, "cannot list database folder " + cfg.databaseFolder);
@@ -154,7 +195,7 @@ std::vector<Match> runFeatureCorrelationMulti(const std::vector<sgz_context *> &
     // :50-55 -- same number of coefficients and same step size
     std::vector<FeatureExtractionConfig> extrDBs;
     for (const auto &m : metas) {
-        const FeatureExtractionConfig e = FeatureExtractionConfig::fromXMLFile(m);
+        const FeatureExtractionConfig e = cachedMeta(m);
         if (e.fftOverlap >= 1 && e.numCoeffs == extrIn.numCoeffs && e.fftSize / e.fftOverlap == stepSize) extrDBs.push_back(e);
     }
 
@@ -181,11 +222,7 @@ std::vector<Match> runFeatureCorrelationMulti(const std::vector<sgz_context *> &
         std::string tag = "correlate|" + std::to_string(numCh) + "|" + std::to_string(nctx) + "|" + std::to_string(c);
         for (int32_t g : ids[(size_t)c]) {
             const std::string &path = extrDBs[(size_t)g].featureOutput;
-            std::error_code e1, e2;
-            const auto sz = fs::file_size(path, e1);
-            const auto tm = fs::last_write_time(path, e2);
-            tag += "|" + path + ":" + (e1 ? "?" : std::to_string(sz)) + ":" +
-                   (e2 ? "?" : std::to_string(tm.time_since_epoch().count()));
+            tag += "|" + path + ":" + fileStamp(path);
         }
         const char *have = sgz_db_tag(ctxs[(size_t)c]);
         if (have && tag == have) continue;  // resident already

@@ -101,6 +101,32 @@ def test_feature_correlation_keeps_the_database_resident_and_runs_on_several_con
                     c.close()
 
 
+def test_feature_correlation_reads_a_changed_meta_file_again(tmp_path):
+    """Parsed meta files are kept between calls (a query service scans the same folder for every query); one that
+    changes on disk is parsed again: here the file with the best match drops out of the database because its meta
+    file now names another number of coefficients (impl/FeatureCorrelationImpl.scala:50-55), then comes back."""
+    import strugatzki_amd as S
+    L, ts = 64, 11
+    db_dir, in_meta, db, tgt, norms, plants = _make_db(tmp_path, L=L, ts=ts)
+    cfg = FeatureCorrelation.Config(db_dir, in_meta, FeatureCorrelation.Punch(Span(ts * STEP, (ts + L) * STEP), 0.5),
+                                    None, 22050, 88200, True, 8.0, 3, 1, 0)
+    with S.Context(0) as c0:
+        first = FeatureCorrelation.run(c0, cfg)
+        assert FeatureCorrelation.run(c0, cfg) == first
+        best = os.path.basename(first[0].file)[:-len(".aif")]
+        meta = os.path.join(db_dir, best + "_feat.xml")
+        text = open(meta).read()
+        mc = FeatureExtraction.Config.from_xml(text)
+        other = FeatureExtraction.Config(mc.audioInput, mc.featureOutput, mc.metaOutput, 10, mc.fftSize, mc.fftOverlap,
+                                         mc.channelsBehavior)
+        open(meta, "w").write(other.to_xml())
+        without = FeatureCorrelation.run(c0, cfg)
+        assert all(os.path.basename(m.file) != best + ".aif" for m in without) and without[0] == first[1]
+        open(meta, "w").write(text)
+        os.utime(meta, ns=(2_000_000_000, 2_000_000_000))  # (same size as at first: the time tells)
+        assert FeatureCorrelation.run(c0, cfg) == first
+
+
 @pytest.mark.parametrize("num_matches,num_per_file,min_punch,max_punch", [(4, 1, 20, 60), (6, 2, 5, 200)])
 def test_feature_correlation_punch_out_from_files(ctx, tmp_path, num_matches, num_per_file, min_punch, max_punch):
     """punchIn + punchOut: spans run from the punch-in to the punch-out offset, sim = sqrt(inSim * outSim)."""
