@@ -104,6 +104,10 @@ SGZ_API int sgz_db_reset(sgz_context *ctx, int num_channels);
 /* Copies one feature file (raw, un-normalised) to the GPU and appends it.
  * Replaces AudioFile.openRead + afExtr.read, impl/FeatureCorrelationImpl.scala:169,195. */
 SGZ_API int sgz_db_add_file(sgz_context *ctx, const float *frames, int64_t num_frames);
+/* sgz_db_add_file for frames as an audio file holds them (sample_format: SGZ_PCM_*, e.g. SGZ_PCM_F32_BE for the
+ * big-endian floats of the feature AIFFs the reference writes, impl/NonRealtimeProcessor.scala:164-165): the file's
+ * own bytes are uploaded and decoded on the device, the host makes no pass over the samples. */
+SGZ_API int sgz_db_add_file_pcm(sgz_context *ctx, const void *samples, int sample_format, int64_t num_frames);
 /* Appends a feature file that already sits in device memory (not copied, not
  * freed; must stay valid until the next sgz_db_reset; 16-byte aligned). */
 SGZ_API int sgz_db_add_file_device(sgz_context *ctx, const float *device_frames, int64_t num_frames);

@@ -73,6 +73,7 @@ SIGNATURES = {
     "sgz_synchronize": (C.c_int, [_vp]),
     "sgz_db_reset": (C.c_int, [_vp, C.c_int]),
     "sgz_db_add_file": (C.c_int, [_vp, _vp, C.c_int64]),
+    "sgz_db_add_file_pcm": (C.c_int, [_vp, _vp, C.c_int, C.c_int64]),
     "sgz_db_add_file_device": (C.c_int, [_vp, _vp, C.c_int64]),
     "sgz_db_add_synthetic": (C.c_int, [_vp, C.c_uint64, C.c_int64, C.c_int64, C.POINTER(Plant), C.c_int]),
     "sgz_db_num_files": (C.c_int, [_vp]),

@@ -69,6 +69,7 @@ void sgz_destroy(sgz_context *ctx)
     sgz::fft_screen_free(ctx);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     if (ctx->h_tgt_stage) (void)hipHostFree(ctx->h_tgt_stage);
+    if (ctx->d_pcm_stage) (void)hipFree(ctx->d_pcm_stage);
     if (ctx->tgt_event) (void)hipEventDestroy(ctx->tgt_event);
     if (ctx->h_dense_pin) (void)hipHostFree(ctx->h_dense_pin);
     for (auto &slot : ctx->pin_pool) {

@@ -1642,6 +1642,50 @@ int sgz_db_add_file(sgz_context *ctx, const float *frames, int64_t num_frames)
     return SGZ_OK;
 }
 
+int sgz_db_add_file_pcm(sgz_context *ctx, const void *samples, int sample_format, int64_t num_frames)
+{
+    if (!ctx) return SGZ_E_ARG;
+    if (sample_format == SGZ_PCM_F32) return sgz_db_add_file(ctx, static_cast<const float *>(samples), num_frames);
+    if (ctx->numCh == 0) return ctx->fail(SGZ_E_STATE, "sgz_db_reset has not been called");
+    if (num_frames < 0 || (num_frames > 0 && !samples)) return ctx->fail(SGZ_E_ARG, "bad samples / num_frames");
+    int sampleBytes, bigEndian, isFloat;
+    if (sgz::pcm_format(sample_format, &sampleBytes, &bigEndian, &isFloat)) return ctx->fail(SGZ_E_ARG, "unknown sample format");
+    SGZ_HIP(ctx, hipSetDevice(ctx->device));
+    DbFile f;
+    f.frames = num_frames;
+    f.owned = true;
+    const size_t count = (size_t)num_frames * ctx->numCh, bytes = sizeof(float) * count, rawBytes = (size_t)sampleBytes * count;
+    SGZ_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&f.d_raw), bytes ? bytes : 4));
+    if (count) {
+        // the file's own bytes go up (into a buffer kept on the context) and are decoded there: no pass over the
+        // samples on the host
+        if (rawBytes + 16 > ctx->pcm_stage_cap) {
+            if (ctx->d_pcm_stage) (void)hipFree(ctx->d_pcm_stage);
+            ctx->d_pcm_stage = nullptr;
+            ctx->pcm_stage_cap = 0;
+            const size_t want = rawBytes + rawBytes / 4 + 16;
+            if (hipMalloc(&ctx->d_pcm_stage, want) != hipSuccess) {
+                (void)hipFree(f.d_raw);
+                return ctx->fail(SGZ_E_HIP, "hipMalloc of the sample staging buffer failed");
+            }
+            ctx->pcm_stage_cap = want;
+        }
+        int rc = SGZ_OK;
+        if (hipMemcpy(ctx->d_pcm_stage, samples, rawBytes, hipMemcpyHostToDevice) != hipSuccess) rc = ctx->fail(SGZ_E_HIP, "upload of the samples failed");
+        if (!rc) rc = sgz::pcm_decode_launch(ctx, ctx->d_pcm_stage, (long long)count, sample_format, f.d_raw, ctx->stream);
+        // (the staging buffer is reused by the next file: its decode must have read it)
+        if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = ctx->fail(SGZ_E_HIP, "sample decode failed");
+        if (rc) {
+            (void)hipFree(f.d_raw);
+            return rc;
+        }
+    }
+    ctx->files.push_back(f);
+    ctx->db_tag.clear();
+    ctx->layout_dirty = true;
+    return SGZ_OK;
+}
+
 int sgz_db_add_file_device(sgz_context *ctx, const float *device_frames, int64_t num_frames)
 {
     if (!ctx) return SGZ_E_ARG;

@@ -541,6 +541,47 @@ __global__ __launch_bounds__(256) void pcm_decode_kernel(const unsigned char *__
 
 }  // namespace
 
+namespace sgz {
+
+int pcm_format(int sample_format, int *sample_bytes, int *big_endian, int *is_float)
+{
+    int sampleBytes = 4, bigEndian = 0, isFloat = 0;
+    switch (sample_format) {
+        case SGZ_PCM_F32: isFloat = 1; break;
+        case SGZ_PCM_F32_BE: isFloat = 1; bigEndian = 1; break;
+        case SGZ_PCM_S16: sampleBytes = 2; break;
+        case SGZ_PCM_S16_BE: sampleBytes = 2; bigEndian = 1; break;
+        case SGZ_PCM_S24: sampleBytes = 3; break;
+        case SGZ_PCM_S24_BE: sampleBytes = 3; bigEndian = 1; break;
+        case SGZ_PCM_S32: break;
+        case SGZ_PCM_S32_BE: bigEndian = 1; break;
+        default: return SGZ_E_ARG;
+    }
+    *sample_bytes = sampleBytes;
+    *big_endian = bigEndian;
+    *is_float = isFloat;
+    return SGZ_OK;
+}
+
+// `count` samples of the layout `sample_format` in device memory (16-byte aligned, readable up to the next multiple
+// of 16 bytes) to fp32, on `stream`.
+int pcm_decode_launch(sgz_context *ctx, const void *raw, long long count, int sample_format, float *out, hipStream_t stream)
+{
+    int sampleBytes, bigEndian, isFloat;
+    if (pcm_format(sample_format, &sampleBytes, &bigEndian, &isFloat)) return ctx->fail(SGZ_E_ARG, "unknown sample format");
+    if (count <= 0) return SGZ_OK;
+    const int grid = (int)std::min<long long>((count / (sampleBytes == 2 ? 8 : 1) + 255) / 256 + 1, 8192);
+    if (sampleBytes == 2)
+        hipLaunchKernelGGL(pcm16_decode_kernel, dim3(grid), dim3(256), 0, stream, (const uint4 *)raw, count, bigEndian, out);
+    else
+        hipLaunchKernelGGL(pcm_decode_kernel, dim3(grid), dim3(256), 0, stream, (const unsigned char *)raw, count,
+                           sampleBytes, bigEndian, isFloat, out);
+    SGZ_HIP(ctx, hipGetLastError());
+    return SGZ_OK;
+}
+
+}  // namespace sgz
+
 extern "C" {
 
 int64_t sgz_extract_num_frames(int64_t num_frames, int fft_size, int fft_overlap)
@@ -566,18 +607,8 @@ int sgz_extract_pcm(sgz_context *ctx, const void *pcm, int sample_format, int64_
     if (!ctx) return SGZ_E_ARG;
     if (num_frames < 0 || (num_frames > 0 && !pcm) || num_channels < 1 || !(sample_rate > 0))
         return ctx->fail(SGZ_E_ARG, "bad audio input");
-    int sampleBytes = 4, bigEndian = 0, isFloat = 0;
-    switch (sample_format) {
-        case SGZ_PCM_F32: isFloat = 1; break;
-        case SGZ_PCM_F32_BE: isFloat = 1; bigEndian = 1; break;
-        case SGZ_PCM_S16: sampleBytes = 2; break;
-        case SGZ_PCM_S16_BE: sampleBytes = 2; bigEndian = 1; break;
-        case SGZ_PCM_S24: sampleBytes = 3; break;
-        case SGZ_PCM_S24_BE: sampleBytes = 3; bigEndian = 1; break;
-        case SGZ_PCM_S32: break;
-        case SGZ_PCM_S32_BE: bigEndian = 1; break;
-        default: return ctx->fail(SGZ_E_ARG, "unknown sample format");
-    }
+    int sampleBytes, bigEndian, isFloat;
+    if (sgz::pcm_format(sample_format, &sampleBytes, &bigEndian, &isFloat)) return ctx->fail(SGZ_E_ARG, "unknown sample format");
     if (fft_size < 16 || fft_size > kMaxFft || (fft_size & (fft_size - 1)) || fft_overlap < 1 || fft_size % fft_overlap)
         return ctx->fail(SGZ_E_ARG, "fftSize must be a power of two in [16, 8192] and a multiple of fftOverlap");
     if (num_coeffs < 1 || num_coeffs > kBands) return ctx->fail(SGZ_E_ARG, "numCoeffs must be in [1, 42]");
@@ -718,15 +749,9 @@ int sgz_extract_pcm(sgz_context *ctx, const void *pcm, int sample_format, int64_
         SGZ_HIP(ctx, hipMalloc(&dRaw.p, rawBytes + 16));
         const int crc = sgz::copy_large(ctx, dRaw.p, pcm, rawBytes, false);
         if (crc) return crc;
-        const long long count = (long long)num_frames * num_channels;
-        const int grid = (int)std::min<long long>((count / (sampleBytes == 2 ? 8 : 1) + 255) / 256 + 1, 8192);
-        if (sampleBytes == 2)
-            hipLaunchKernelGGL(pcm16_decode_kernel, dim3(grid), dim3(256), 0, ctx->stream, (const uint4 *)dRaw.p, count,
-                               bigEndian, (float *)dPcm.p);
-        else
-            hipLaunchKernelGGL(pcm_decode_kernel, dim3(grid), dim3(256), 0, ctx->stream, (const unsigned char *)dRaw.p,
-                               count, sampleBytes, bigEndian, isFloat, (float *)dPcm.p);
-        SGZ_HIP(ctx, hipGetLastError());
+        const int drc = sgz::pcm_decode_launch(ctx, dRaw.p, (long long)num_frames * num_channels, sample_format,
+                                               (float *)dPcm.p, ctx->stream);
+        if (drc) return drc;
     }
     SGZ_HIP(ctx, hipMemcpyAsync(dTw.p, tw.data(), sizeof(float2) * tw.size(), hipMemcpyHostToDevice, ctx->stream));
     SGZ_HIP(ctx, hipMemcpyAsync(dHann.p, hann.data(), sizeof(float) * hann.size(), hipMemcpyHostToDevice, ctx->stream));

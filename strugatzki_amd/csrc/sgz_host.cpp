@@ -230,10 +230,11 @@ std::vector<Match> runFeatureCorrelationMulti(const std::vector<sgz_context *> &
         for (size_t k = 0; k < ids[(size_t)c].size(); k++) {
             const int g = ids[(size_t)c][k];
             checkAborted(obs, 0.5 * (double)g / (double)std::max(nf, 1));  // :164
-            const AudioData af = readAudioFile(extrDBs[(size_t)g].featureOutput);  // :169
+            // (:169; the file's bytes as they are -- big-endian floats -- decoded on the device)
+            const PcmData af = readAudioFilePcm(extrDBs[(size_t)g].featureOutput);
             if (af.numChannels != numCh)
                 throw Error(SGZ_E_IO, "feature file " + extrDBs[(size_t)g].featureOutput + " has the wrong number of channels");
-            check(ctxs[(size_t)c], sgz_db_add_file(ctxs[(size_t)c], af.frames.data(), af.numFrames));
+            check(ctxs[(size_t)c], sgz_db_add_file_pcm(ctxs[(size_t)c], af.samples(), af.sampleFormat, af.numFrames));
         }
         check(ctxs[(size_t)c], sgz_db_set_tag(ctxs[(size_t)c], tag.c_str()));
     }

@@ -163,6 +163,8 @@ struct sgz_context {
     size_t half_stage_halfwords = 0;
     bool half_img_dirty = false;
     hipEvent_t tgt_event = nullptr;        // the target's upload on `stream`, for the other stream that reads it
+    void *d_pcm_stage = nullptr;           // device: a file's samples as the file holds them, before sgz_db_add_file_pcm decodes them
+    size_t pcm_stage_cap = 0;
     unsigned char *h_tgt_stage = nullptr;  // pinned: what sgz_corr_set_target uploads, written in place and copied
     size_t tgt_stage_cap = 0;              // asynchronously (the stream is idle when the next target overwrites it)
     double *d_aprime = nullptr;  // [numCh][S * kR] centred target, fp64
@@ -391,6 +393,8 @@ std::vector<sgz_ring_run> ring_runs(const long long *frames, int num_files, int 
 
 // sgz_context.hip: synchronous copy between pageable host memory and the device, staged in parallel when large
 int copy_large(sgz_context *ctx, void *dst, const void *src, size_t bytes, bool to_host);
+int pcm_format(int sample_format, int *sample_bytes, int *big_endian, int *is_float);
+int pcm_decode_launch(sgz_context *ctx, const void *raw, long long count, int sample_format, float *out, hipStream_t stream);
 
 // Grows a device buffer to at least `count` elements (contents are not kept).
 template <typename T>

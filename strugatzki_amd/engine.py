@@ -86,6 +86,15 @@ class Context:
         a = _as_frames(frames, self.num_channels)
         self._check(lib.sgz_db_add_file(self._h, N.ptr(a), a.shape[0]))
 
+    def db_add_file_pcm(self, samples, sample_format: int, num_frames: int) -> None:
+        """Frames as an audio file holds them (bytes or a uint8 array, interleaved, layout SGZ_PCM_*)."""
+        raw = np.frombuffer(samples, dtype=np.uint8) if not isinstance(samples, np.ndarray) else samples
+        raw = np.ascontiguousarray(raw).view(np.uint8).reshape(-1)
+        width = {0: 4, 1: 4, 2: 2, 3: 2, 4: 3, 5: 3, 6: 4, 7: 4}.get(sample_format, 0)
+        if raw.size < width * num_frames * self.num_channels:
+            raise ValueError("fewer bytes than num_frames * num_channels samples")
+        self._check(lib.sgz_db_add_file_pcm(self._h, N.ptr(raw), sample_format, num_frames))
+
     def db_add_file_device(self, device_ptr: int, num_frames: int) -> None:
         self._check(lib.sgz_db_add_file_device(self._h, C.c_void_p(device_ptr), num_frames))
 

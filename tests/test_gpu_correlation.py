@@ -796,3 +796,26 @@ def test_tail_trim_shortens_every_file(ctx):
         ctx.corr_set_tail_trim(-1)
     full_counts, _ = dense(db, 0)
     assert full_counts == [261, 21, 1, 101]
+
+
+def test_database_files_as_audio_files_hold_them(ctx):
+    """sgz_db_add_file_pcm: big-endian floats (what feature AIFFs hold), little-endian ones and integer layouts go up
+    as bytes and are decoded on the device: the resident frames are bit for bit those of the decoded values."""
+    num_ch = NUM_CH
+    rng = np.random.default_rng(5)
+    files = [O.synth_file(SEED, g, n, num_ch) for g, n in enumerate((1500, 1, 777))]
+    ctx.db_reset(num_ch)
+    for x in files:
+        ctx.db_add_file_pcm(x.astype(">f4").tobytes(), 1, x.shape[0])
+    ctx.db_add_file_pcm(files[0].astype("<f4").tobytes(), 0, files[0].shape[0])
+    i16 = rng.integers(-32768, 32767, size=(333, num_ch)).astype(np.int16)
+    ctx.db_add_file_pcm(i16.astype(">i2").tobytes(), 3, 333)
+    ctx.db_add_file_pcm(b"", 1, 0)
+    assert ctx.num_files == 6
+    for f, want in enumerate(files + [files[0], i16.astype(np.float32) / np.float32(32768)]):
+        got = ctx.db_read_file(f)
+        assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert ctx.file_frames(5) == 0
+    import strugatzki_amd as S
+    with pytest.raises(S.NativeError):
+        ctx.db_add_file_pcm(b"\0" * 64, 9, 1)
