@@ -486,7 +486,7 @@ std::vector<std::pair<double, double>> runFeatureStats(sgz_context *ctx, const s
     int numCh = 0;
     for (size_t i = 0; i < featureFiles.size(); i++) {
         checkAborted(obs, 0.8 * (double)i / (double)featureFiles.size());
-        const AudioData af = readAudioFile(featureFiles[i]);
+        const PcmData af = readAudioFilePcm(featureFiles[i]);  // (decoded on the device)
         if (i == 0) {
             numCh = af.numChannels;
             check(ctx, sgz_db_reset(ctx, numCh));
@@ -494,7 +494,7 @@ std::vector<std::pair<double, double>> runFeatureStats(sgz_context *ctx, const s
             throw Error(SGZ_E_IO, "feature file " + featureFiles[i] + " has a different number of channels");
         }
         if (af.numFrames < 1) throw Error(SGZ_E_IO, "feature file " + featureFiles[i] + " is empty");
-        check(ctx, sgz_db_add_file(ctx, af.frames.data(), af.numFrames));
+        check(ctx, sgz_db_add_file_pcm(ctx, af.samples(), af.sampleFormat, af.numFrames));
     }
     std::vector<double> mm((size_t)numCh * 2);
     check(ctx, sgz_feature_stats(ctx, 0, (int)featureFiles.size(), mm.data(), nullptr));
