@@ -11,11 +11,13 @@
 // kernel streams the block's spectra (kept in HBM per database / norms / target length, like the half-precision
 // image of the matrix-core path), multiplies them with the target's spectra, adds the channels of a group in
 // the frequency domain, and inverts ONE complex transform per block whose real part is the loudness cross term
-// and whose imaginary part the cross term of the other channels.  It is HBM-bound: per block 8 N numCh / 2
-// bytes of spectra, per window 20 bytes of cached statistics in and 8 bytes out (upper bound and boost; the
-// largest lower bound of a file is kept per file).
+// and whose imaginary part the cross term of the other channels.  It is bound by memory traffic: per block
+// 2 N numCh bytes of spectra (16-bit integers with one scale per band of 64 bins; 4 N numCh as fp32, on request) and
+// as much again of the target's out of the cache, per window 16 bytes of cached statistics in (20 where a window's
+// boost comes near the gate) and, for a search, nothing out but the few windows that can hold their file's
+// maximum (the largest lower bound of a file is kept per file).
 //
-// Everything is fp32.  The result is a screening value with a certified error like the matrix-core kernel's.
+// All arithmetic is fp32.  The result is a screening value with a certified error like the matrix-core kernel's.
 // A transform of `passes` passes is taken to be accurate to eps = (1 + 40 u)^passes - 1 of its input's norm (per
 // pass: a table-derived twiddle <= 10 ulp, its product, four butterfly levels with their inner factors; every output
 // is an inner product evaluated through a butterfly tree, every path of which carries that factor).  Two things
@@ -36,6 +38,10 @@
 // the file's centring constant is taken off, so a file whose level is far from zero carries 2^-24 of that level as
 // noise on every centred value -- against a window's cross term at most 2^-23 |level| / sd (FftGeom::levelErr).  At N = 16384, L = 2584
 // the bound comes to about 1e-4 of the similarity where half-precision products give 1e-3.
+// Spectra stored as 16-bit integers add one more term, which is not estimated but measured: the kernel that stores
+// a spectrum decodes it again with the reader's own expression and sums the squared distance to what it computed
+// (per block and channel; per channel of the target); a spectrum off by d in the Euclidean norm of the half
+// spectrum moves a cross term by at most |a'| sqrt(2 / N) |d| resp. sqrt(2 N) |d_A| |x_block|.
 #include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 
