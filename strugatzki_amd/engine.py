@@ -81,6 +81,7 @@ class Context:
         # the sharded search keeps every rank's file placement between searches: a new database starts afresh
         # (when the files of one rank change, every rank of the group has to go through db_reset)
         self.__dict__.pop("_rank_maps", None)
+        self.__dict__.pop("_placement", None)
 
     def db_add_file(self, frames: np.ndarray) -> None:
         a = _as_frames(frames, self.num_channels)

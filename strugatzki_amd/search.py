@@ -198,8 +198,13 @@ def _rank_maps(ctx: Context, local_to_global: Sequence[int], group) -> dict:
     import torch
     import torch.distributed as dist
 
-    key = (tuple(local_to_global), id(group))
     cache = ctx.__dict__.setdefault("_rank_maps", {})
+    # (every search asks: the tuple search_sharded keeps per placement is recognised by identity, without hashing
+    # its thousands of entries)
+    last = cache.get("_last")
+    if last is not None and last[0] is local_to_global and last[1] == id(group):
+        return last[2]
+    key = (tuple(local_to_global), id(group))
     if key not in cache:
         world = dist.get_world_size(group)
         on_gpu = dist.get_backend(group) != "gloo"
@@ -231,6 +236,7 @@ def _rank_maps(ctx: Context, local_to_global: Sequence[int], group) -> dict:
                 owner.setdefault(int(g), (r, i))
         cache.clear()
         cache[key] = dict(per_rank=per_rank, flat=flat, offsets=offsets, frames=frames, owner=owner, ring_for=None)
+    cache["_last"] = (local_to_global, id(group), cache[key])
     return cache[key]
 
 
@@ -471,12 +477,20 @@ def search_sharded(ctx: Context, p: SearchParams, head_global: Sequence[int], ta
     search over bounds for numPerFile = 1."""
     nh, nt = len(head_global), len(tail_global)
     assert ctx.num_files == nh + nt
+    # local index -> global id, built once per placement: the two sequences describe the files the context holds, and
+    # a new placement means a new database (Context.db_reset drops this), so the same two objects with the same
+    # lengths are the same placement -- a search must not pay for thousands of list entries each time
+    memo = ctx.__dict__.get("_placement")
+    if memo is None or memo[0] is not head_global or memo[1] is not tail_global or memo[2] != (nh, nt):
+        memo = (head_global, tail_global, (nh, nt), tuple(head_global) + tuple(tail_global))
+        ctx.__dict__["_placement"] = memo
+    l2g = memo[3]
     if num_files_total is not None and num_files_total > 0:
-        _exchange_ring_images(ctx, list(head_global) + list(tail_global), group)
+        _exchange_ring_images(ctx, l2g, group)
     mode = _screen_mode(ctx, p) if p.screen else None
     if (p.screen and p.screen_head and p.num_per_file == 1 and p.num_matches >= 1 and mode == "f16"
             and num_files_total is not None and num_files_total > 0):  # (nothing rank-dependent: a collective follows)
-        out = _sharded_over_bounds(ctx, p, list(head_global) + list(tail_global), num_files_total, group)
+        out = _sharded_over_bounds(ctx, p, l2g, num_files_total, group)
         if out is not None:  # every rank holds the same candidates, so all ranks agree on this
             return out
     if nh == 0 and num_files_total is not None and num_files_total > 0:
@@ -502,7 +516,7 @@ def search_sharded(ctx: Context, p: SearchParams, head_global: Sequence[int], ta
     if p.screen:
         ctx.corr_rescore_device(rec.data_ptr(), cap, cnt.data_ptr())
     ctx.synchronize()
-    _to_global_ids(rec, cnt, cap, list(head_global) + list(tail_global), dev)
+    _to_global_ids(rec, cnt, cap, l2g, dev)
     cands = exchange_candidates(rec, cnt, cap, group)
     if cands is None:
         raise RuntimeError(f"candidate buffer overflow (> {cap}); raise SearchParams.capacity")
