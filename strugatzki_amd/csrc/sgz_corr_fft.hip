@@ -720,10 +720,11 @@ int fft_target(sgz_context *ctx, hipStream_t stream)
     // (a target without spread gives inf / NaN factors, like its similarities)
     // (16-bit spectra: the kernel multiplies the stored target spectrum, whose norm is within sqrt(128) / 65534 of the
     // computed one's -- every component is off by at most half a step of its band, 1 / 65534 of the band's largest,
-    // and a band has 128 of them; two more roundings per operand, the product of the two scales and its product
-    // with the integer)
+    // and a band has 128 of them; four more roundings per product: the product of the two scales, its product with
+    // the block's integer, and -- on either side -- the rounding of integer times scale in the value whose distance to
+    // the computed spectrum was measured, where the kernel's operand is the unrounded product)
     const double u = std::ldexp(1.0, -24), up = q16 ? 1.0003 : 1.0001;
-    const int extra = q16 ? 2 : 0;
+    const int extra = q16 ? 4 : 0;
     fg.epsT = (float)(fft_eps(N) * up);
     fg.epsUT = (float)((1 + 8 + extra) * 3.0 * u * up);            // operand roundings, products, the untangling
     fg.epsUS = (float)((numCh - 1 + 10 + extra) * 3.0 * u * up);   // the same, the channel sums and the scaling by beta
