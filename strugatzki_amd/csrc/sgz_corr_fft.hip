@@ -806,11 +806,16 @@ int fft_screen_layout(sgz_context *ctx)
     for (int f = 0; f < nf; f++) {
         const FileDesc &fd = ctx->h_files[(size_t)f];
         ctx->fblock_begin[(size_t)f] = (int)ctx->h_fblocks.size();
-        for (long long o0 = 0; o0 < fd.num_windows; o0 += fg.hop) {
+        // The file's windows are dealt evenly over the blocks it needs (not hop, hop, ..., rest): a block costs its
+        // spectra and its transform whatever it holds, but its epilogue by the window, and when there are no more
+        // blocks than CUs the launch takes as long as its fullest block.
+        const long long nblk = (fd.num_windows + fg.hop - 1) / fg.hop;
+        const long long per = nblk > 0 ? (fd.num_windows + nblk - 1) / nblk : 0;
+        for (long long o0 = 0; o0 < fd.num_windows; o0 += per) {
             FftBlock b;
             b.file = f;
             b.o0 = (int)o0;
-            b.valid = (int)std::min<long long>(fg.hop, fd.num_windows - o0);
+            b.valid = (int)std::min<long long>(per, fd.num_windows - o0);
             b.pad = 0;
             b.spec = specOff;
             b.win = fd.win_off + o0;

@@ -57,14 +57,15 @@ def _check_upper(ctx, sims, boosts, max_boost=8.0, slack=SLACK):
 @pytest.mark.parametrize("L,n,extra", [
     (64, 4096, [0, 1, 500]),          # a target far shorter than the transform
     (431, 4096, [0, 1, 2 * 3666 + 7]),
-    (3072, 4096, [0, 1, 1500]),       # the longest target a 4096-point block takes (1025 windows per block)
+    (3072, 4096, [0, 1, 1500]),       # the longest target a 4096-point block takes (at most 1025 windows per block)
     (1200, 8192, [0, 1, 300]),
     (2584, 16384, [0, 1]),            # the headline target length
 ])
 def test_bounds_enclose_the_oracle(spectral, monkeypatch, L, n, extra):
     """Every transform length: files of one window, of a partly filled block, of exactly one block of windows plus
-    `extra` (0, 1: the second block then holds a single window), a file shorter than the target (one window over
-    what earlier files left in the ring) -- upper bounds, boosts, the k-th per-file lower bound, the search."""
+    `extra` (0, 1: the file then needs a second block, and its windows are dealt evenly over the two), a file
+    shorter than the target (one window over what earlier files left in the ring) -- upper bounds, boosts, the k-th
+    per-file lower bound, the search."""
     import strugatzki_amd as S
     ctx = spectral
     monkeypatch.setenv("SGZ_FFT_N", str(n))
