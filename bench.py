@@ -262,6 +262,7 @@ def main() -> int:
     # which kernel the layout of this database and target uses for the bounds
     spectral = mode == "f16" and ctx.screen_kernel_in_use == "spectral"
     fft_n, fft_hop, fft_blocks = ctx.screen_geometry
+    spectra_q16 = ctx.spectra_format_in_use == "q16"
     settle_steps = int(args.settle_ms / 0.3)
     for _ in range(settle_steps):
         matches = step()
@@ -405,7 +406,7 @@ def main() -> int:
             # what the kernel is built to move: the blocks' spectra and 16 B of cached statistics per window in (20 B in
             # blocks where some window's boost comes near maxBoost: none in this workload); out only the list of the
             # few windows that can hold their file's maximum and one bound per file
-            q16 = ctx.spectra_format_in_use == "q16"
+            q16 = spectra_q16
             # (16-bit spectra: 4 bytes per complex bin and a 4-byte scale per band of 64 bins; every workgroup also
             # reads the target's spectra, which the caches serve)
             moved = blocks * (2.0 * NUM_CH * n + NUM_CH * n / 32.0 if q16 else 4.0 * NUM_CH * n) + windows * 16.0
@@ -467,7 +468,9 @@ def main() -> int:
         dtype = {"f16": "f16 screening (matrix cores), f64 re-scoring of every returned similarity",
                  "f32": "f32 screening, f64 re-scoring of every returned similarity", "f64": "f64"}[mode]
         if spectral:
-            dtype = "f32 spectral screening (block transforms), f64 re-scoring of every returned similarity"
+            dtype = ("f32 spectral screening (block transforms; spectra kept as 16-bit integers with band scales), "
+                     if spectra_q16 else "f32 spectral screening (block transforms), ") + \
+                "f64 re-scoring of every returned similarity"
         out = {
             "metric": "candidate windows/sec, 30 s target vs 10 h DB, 13-MFCC; 1/2/4/8 GPU",
             "value": unique_windows / (elapsed / args.steps),
