@@ -1,11 +1,16 @@
 #!/usr/bin/env python3
 """Benchmark of the FeatureCorrelation hot path on MI355X.
 
-One step = one complete database search on device-resident synthetic feature
-files: normalise + window statistics + sliding correlation of every window on
-the GPU, then the reference's match selection (head replay, candidate
-compaction, tail replay; one all-gather when sharded).  Metric: candidate
-windows per second, whole job.
+One step = one complete query against device-resident synthetic feature files:
+a NEW target (the timed steps rotate through several distinct targets of the same
+length, each with its own planted answers; the raw target frames are in host
+memory, as a caller has them) is prepared on the GPU -- normalisation, two-pass
+statistics, centring, its spectra -- then the sliding correlation of every window
+of every file, then the reference's match selection (one all-gather when
+sharded).  Metric: candidate windows per second, whole job.  The same search
+with the target left in place (roofline.same_target), a long leg of the headline
+step (roofline.steady), the search with the other screening kernel and the search
+at reference precision (fp64, every window) are timed in the same run.
 
     python bench.py --gpus N --steps K --warmup W          (N=1)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -50,12 +55,17 @@ PEAK_HBM_GBS = 8000.0
 SUSTAINED_F16_RANDOM_TFLOPS = 1965.0  # measured, tools/mfma_peak.hip (register operands, random data, 20-40 ms runs)
 
 
-def plant_list(num: int, L: int, files: list[int], frames_per_file: int):
-    """Copy j of the target goes into files[j] at a distinct offset, noise amplitude 0.02*(j+1)."""
+def target_start(k: int, L: int) -> int:
+    """First frame of target k in the dedicated target file (the targets do not overlap)."""
+    return TARGET_START + k * (L + 64)
+
+
+def plant_list(num: int, L: int, files: list[int], frames_per_file: int, k: int = 0):
+    """Copy j of target k goes into files[j] at a distinct offset, noise amplitude 0.02*(j+1)."""
     out = []
     for j in range(num):
-        off = (4001 + 1733 * j) % (frames_per_file - L)
-        out.append(dict(file=files[j], offset=off, src_file=TARGET_FILE, src_offset=TARGET_START, length=L,
+        off = (4001 + 1733 * j + 389 * k) % (frames_per_file - L)
+        out.append(dict(file=files[j], offset=off, src_file=TARGET_FILE, src_offset=target_start(k, L), length=L,
                         amp=float(np.float32(0.02) * (j + 1)), gain=1.0))
     return out
 
@@ -69,9 +79,23 @@ def norms_default() -> np.ndarray:
 
 
 def cpu_baseline(L: int, frames_per_file: int, budget_s: float) -> dict:
-    """Times the single-threaded CPU oracle on a bounded sample of the same workload."""
+    """Times the single-threaded CPU oracle, pinned to one core, on a bounded sample of the same workload."""
     from oracle import oracle_lib as O
 
+    allowed = sorted(os.sched_getaffinity(0))
+    core = allowed[len(allowed) // 2]
+    os.sched_setaffinity(0, {core})
+    try:
+        out = _cpu_baseline_pinned(O, L, frames_per_file, budget_s)
+    finally:
+        os.sched_setaffinity(0, set(allowed))
+    out["pinned_to_core"] = core
+    out["node_cores"] = os.cpu_count()
+    out["cores_allowed"] = len(allowed)
+    return out
+
+
+def _cpu_baseline_pinned(O, L: int, frames_per_file: int, budget_s: float) -> dict:
     tgt = O.synth_file(SEED, TARGET_FILE, TARGET_START + L + 16, NUM_CH)
     cfg = O.CorrConfig(TARGET_START * STEP, (TARGET_START + L) * STEP, 0.5, 1, 8.0, 10, 1, 0, STEP, NUM_CH - 1)
     norms = norms_default()
@@ -96,11 +120,27 @@ def cpu_baseline(L: int, frames_per_file: int, budget_s: float) -> dict:
         "cores": 1,
         "kind": "port",
         "sample": f"{nfiles} file(s) x {frames} frames, target {L} frames = {windows} windows in {dt:.1f} s "
-                  f"(C restatement of the reference loop, gcc -O2, one thread)",
+                  f"(C restatement of the reference loop, gcc -O2, one thread pinned to one core)",
     }
 
 
-def pmc_traffic_bytes(kernel: str, summary: str = "r02_pmc_summary.csv"):
+PMC_SUMMARY = "r03_pmc_summary.csv"
+
+
+def finite_json(x):
+    """Non-finite floats become null (a JSON document has no NaN)."""
+    if isinstance(x, float):
+        return x if np.isfinite(x) else None
+    if isinstance(x, dict):
+        return {k: finite_json(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [finite_json(v) for v in x]
+    if isinstance(x, (np.floating, np.integer)):
+        return finite_json(x.item())
+    return x
+
+
+def pmc_traffic_bytes(kernel: str, summary: str = PMC_SUMMARY):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of the default N=1 command
     (profiles/<summary>): 2 x FETCH_SIZE (gfx950 tallies 128-byte read requests at 64 bytes) +
     WRITE_SIZE, both in KiB.  None when the summary does not hold the kernel."""
@@ -122,16 +162,25 @@ def pmc_traffic_bytes(kernel: str, summary: str = "r02_pmc_summary.csv"):
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # a step is less than a tenth of a millisecond: the defaults keep the GPU busy for about two seconds (long
+    # a step is about a tenth of a millisecond: the defaults keep the GPU busy for about two seconds (long
     # enough for the clocks to settle and for a once-a-second utilisation sampler to see the run) and still finish
     # at once
-    ap.add_argument("--steps", type=int, default=20000)
+    ap.add_argument("--steps", type=int, default=10000)
     ap.add_argument("--warmup", type=int, default=500)
     ap.add_argument("--files-per-gpu", type=int, default=None,
                     help="database files per GPU (default: 120 at N=1, 1500 at N>1)")
     ap.add_argument("--file-seconds", type=float, default=300.0)
     ap.add_argument("--target-seconds", type=float, default=None,
                     help="target length (default: 30 at N=1, 60 at N>1)")
+    ap.add_argument("--targets", type=int, default=8,
+                    help="distinct targets of the same length the timed steps rotate through (each step sets the next "
+                         "one: a search includes the preparation of its target); 1: the target is set once, before "
+                         "the timed steps")
+    ap.add_argument("--steady-steps", type=int, default=12000,
+                    help="steps of a second, long leg of the same step as the timed ones (roofline.steady), run when "
+                         "--steps is smaller than this; 0 disables")
+    ap.add_argument("--same-target-steps", type=int, default=2000,
+                    help="steps of the search with the target left in place (roofline.same_target); 0 disables")
     ap.add_argument("--exact-steps", type=int, default=100,
                     help="steps of the reference-precision search (fp64 kernel, every window) timed after the main "
                          "loop at N=1 for roofline.exact; 0 disables")
@@ -140,11 +189,12 @@ def main() -> int:
                     help="untimed steps for about this long (counted as 0.3 ms each) before the warm-up steps, so that the "
                          "clocks have settled")
     ap.add_argument("--timing-every", type=int, default=32,
-                    help="HIP events with one launch in n of the dominant kernel (matrix-core path).  A launch that "
+                    help="HIP events with one launch in n of the dominant kernel, at most; with few timed steps n is "
+                         "lowered so that at least four launches of the timed region carry them.  A launch that "
                          "carries events costs the host about 20 us more than one that does not (measured: "
-                         "tools/search_loop.cpp), a tenth of a step at the default workload, so the kernel's average "
-                         "duration over the timed region comes from a sample of its launches")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget; 0 disables")
+                         "tools/search_loop.cpp), so the kernel's average duration over the timed region comes from "
+                         "a sample of its launches")
+    ap.add_argument("--cpu-seconds", type=float, default=30.0, help="CPU baseline budget; 0 disables")
     ap.add_argument("--exact-only", action="store_true",
                     help="fp64 kernel for every file (no screening + re-scoring)")
     ap.add_argument("--sharded", action="store_true",
@@ -165,7 +215,6 @@ def main() -> int:
 
     import strugatzki_amd as S
     from strugatzki_amd import _native as N
-    from strugatzki_amd.search import shard_files
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -187,6 +236,7 @@ def main() -> int:
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    rccl_ranks = None
     if sharded:
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -194,6 +244,7 @@ def main() -> int:
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        rccl_ranks = dist.get_world_size()
 
     sr = 44100.0
     L = int((int(args.target_seconds * sr + 0.5) + TARGET_START * STEP + STEP // 2) // STEP) - TARGET_START
@@ -201,11 +252,18 @@ def main() -> int:
     head_n = args.num_matches
     # weak scaling: every rank holds files_per_gpu files of the database, dealt round robin
     total_files = world * args.files_per_gpu
-    # plants: spread over the whole database, first one inside the head
-    plant_files = [int(round(j * (total_files - 1) / max(args.num_matches - 1, 1))) for j in range(args.num_matches)]
-    plants = plant_list(args.num_matches, L, plant_files, frames_per_file)
-    nplants = [N.Plant(p["file"], p["offset"], p["src_file"], p["src_offset"], p["length"], p["amp"], p["gain"])
-               for p in plants]
+    # Targets and their planted answers: copy j of target k sits in file spread[j] + k (every file holds at most one
+    # copy), noise growing with j, so the expected result of a search with target k is its own ten copies in order.
+    n_tgt = max(1, args.targets)
+    while n_tgt > 1 and total_files < args.num_matches * n_tgt + 1:
+        n_tgt -= 1
+    spread = [int(round(j * (total_files - n_tgt) / max(args.num_matches - 1, 1))) for j in range(args.num_matches)]
+    plants_of = [plant_list(args.num_matches, L, [f + k for f in spread], frames_per_file, k) for k in range(n_tgt)]
+    by_file = {}
+    for plants in plants_of:
+        for p in plants:
+            by_file.setdefault(p["file"], []).append(
+                N.Plant(p["file"], p["offset"], p["src_file"], p["src_offset"], p["length"], p["amp"], p["gain"]))
 
     # sharded: the library's kernels and the RCCL exchange share one stream (no host wait between them)
     ctx = S.Context.on_torch_stream(local_rank) if sharded else S.Context(local_rank)
@@ -218,32 +276,50 @@ def main() -> int:
         head_global = list(range(min(head_n, total_files)))
         tail_global = list(range(len(head_global), total_files))
     for g in head_global + tail_global:
-        ctx.db_add_synthetic(SEED, g, frames_per_file, nplants)
+        ctx.db_add_synthetic(SEED, g, frames_per_file, by_file.get(g, []))
     ctx.set_norms(norms_default())
-    # the target: frames [TARGET_START, TARGET_START + L) of the dedicated target file
+    # the targets: raw frames in host memory, as a caller holds them
     ctx_t = S.Context(local_rank)
     ctx_t.db_reset(NUM_CH)
-    ctx_t.db_add_synthetic(SEED, TARGET_FILE, TARGET_START + L + 16, [])
-    target = ctx_t.db_read_file(0)[TARGET_START:TARGET_START + L].copy()
+    ctx_t.db_add_synthetic(SEED, TARGET_FILE, target_start(n_tgt, L) + 16, [])
+    tfile = ctx_t.db_read_file(0)
+    targets = [np.ascontiguousarray(tfile[target_start(k, L):target_start(k, L) + L]) for k in range(n_tgt)]
     ctx_t.close()
-    ctx.corr_set_target(target, 0.5, 8.0)
+    ctx.corr_set_target(targets[0], 0.5, 8.0)
     ctx.set_screen_kernel(args.screen_kernel)
 
     params = S.SearchParams(args.num_matches, 1, 0, STEP, capacity=1 << 16, screen=not args.exact_only,
                             screen_mode=args.screen_mode)
-    mode = "f64" if args.exact_only else ("f16" if args.screen_mode != "f32" and ctx.screen_f16_available else "f32")
+    mode = "f16" if args.exact_only is False and args.screen_mode != "f32" and ctx.screen_f16_available else (
+        "f64" if args.exact_only else "f32")
     unique_windows = total_files * (frames_per_file - L + 1)
 
-    def step():
+    def search_only():
         if sharded:
             return S.search_sharded(ctx, params, head_global, tail_global, num_files_total=total_files)
         return S.search(ctx, params)
+
+    counter = [0]
+    last_of = [None] * n_tgt
+
+    def step():
+        """The headline step: the next target of the rotation, prepared on the GPU, then the search."""
+        k = counter[0] % n_tgt
+        counter[0] += 1
+        if n_tgt > 1:
+            ctx.corr_set_target(targets[k], 0.5, 8.0)
+        m = search_only()
+        last_of[k] = m
+        return m
 
     def sync():
         if sharded:
             dist.barrier()
         torch.cuda.synchronize()
         ctx.synchronize()
+
+    def keys(ms):
+        return [(m.file, m.start // STEP) for m in ms]
 
     # Host side hygiene of a long-running search service: the interpreter's full
     # garbage collections walk every object torch created at import (tens of ms);
@@ -252,12 +328,33 @@ def main() -> int:
     gc.collect()
     gc.freeze()
 
-    # HIP events travel with one launch in --timing-every of the dominant kernel
-    timing_every = max(1, args.timing_every) if mode == "f16" else 1
-    ctx.set_kernel_timing(timing_every)
+    # HIP events travel with one launch in timing_every of the dominant kernel: at most --timing-every, and few
+    # enough that four launches of the timed region carry them
+    def every_for(steps):
+        return max(1, min(args.timing_every, steps // 4)) if mode == "f16" else 1
+
+    def timed_leg(fn, steps):
+        """`steps` calls of fn between two synchronisations: (seconds, kernel times of the sampled launches)."""
+        te = every_for(steps)
+        ctx.set_kernel_timing(te)
+        kms = []
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+            if mode != "f16":  # several runs per step: the tail launch is the last one
+                kms.append(ctx.corr_last_kernel_ms())
+        sync()
+        dt = time.perf_counter() - t0
+        # the events are read here, after the timed region (a host-side wait on them between steps would sit inside it)
+        if mode == "f16":  # one run per step
+            kms = [float(x) for x in ctx.kernel_ms_history(min(256, -(-steps // te))) if x > 0]
+        return dt, kms
+
     # Clock settling, untimed and reported as such: after an idle period the chip needs some tens of
     # milliseconds of load before it holds its clocks; the first steps then run 5-10 % slower than the rest.
     # (a fixed count, the same on every rank: the sharded step holds a collective)
+    ctx.set_kernel_timing(0)
     matches = step()
     # which kernel the layout of this database and target uses for the bounds
     spectral = mode == "f16" and ctx.screen_kernel_in_use == "spectral"
@@ -265,32 +362,65 @@ def main() -> int:
     spectra_q16 = ctx.spectra_format_in_use == "q16"
     settle_steps = int(args.settle_ms / 0.3)
     for _ in range(settle_steps):
-        matches = step()
+        step()
     for _ in range(args.warmup):
-        matches = step()
-    kernel_ms = []
-    sync()
-    t0 = time.perf_counter()
-    step_ms = []
-    for _ in range(args.steps):
-        ts = time.perf_counter()
-        matches = step()
-        step_ms.append((time.perf_counter() - ts) * 1e3)
-        if mode != "f16":  # several runs per step: the tail launch is the last one
-            kernel_ms.append(ctx.corr_last_kernel_ms())
-    if os.environ.get("SGZ_DEBUG"):
-        print("step ms:", " ".join(f"{x:.2f}" for x in step_ms), file=sys.stderr)
-    sync()
-    elapsed = time.perf_counter() - t0
-    # HIP events travel with every launch of the dominant kernel in the timed region; they are read here, after
-    # it (a host-side wait on them between steps would sit inside the timed region)
-    if mode == "f16":  # one run per step
-        kernel_ms = [float(x) for x in ctx.kernel_ms_history(args.steps // timing_every) if x > 0]
+        step()
+    for k in range(n_tgt):
+        last_of[k] = None
+    elapsed, kernel_ms = timed_leg(step, args.steps)
+    rank_elapsed = [elapsed]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        ts = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(ts, t)
+        rank_elapsed = [float(x.item()) for x in ts]
+        elapsed = max(rank_elapsed)
     screened_work = ctx.corr_last_work()
+    # known answers: the matches of a search with target k are its planted copies, in noise order, at their offsets
+    verified_targets = sum(1 for k in range(n_tgt) if last_of[k] is not None and
+                           keys(last_of[k]) == [(p["file"], p["offset"]) for p in plants_of[k]])
+    searched_targets = sum(1 for k in range(n_tgt) if last_of[k] is not None)
+    verified = searched_targets > 0 and verified_targets == searched_targets
+
+    # The same step for longer (at least a second of GPU work): the figure a few dozen timed steps cannot give
+    # reliably, and long enough for a utilisation sampler to see the kernel.
+    steady = None
+    if 0 < args.steps < args.steady_steps:
+        s_elapsed, s_kms = timed_leg(step, args.steady_steps)
+        if world > 1:
+            t = torch.tensor([s_elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            s_elapsed = float(t.item())
+        steady = (s_elapsed / args.steady_steps, s_kms)
+
+    # The search alone, the target left in place (what the timed steps of earlier versions of this benchmark were).
+    same = None
+    if args.same_target_steps > 0 and n_tgt > 1:
+        ctx.corr_set_target(targets[0], 0.5, 8.0)
+        search_only()
+        q_elapsed, q_kms = timed_leg(search_only, args.same_target_steps)
+        if world > 1:
+            t = torch.tensor([q_elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            q_elapsed = float(t.item())
+        same = (q_elapsed / args.same_target_steps, q_kms)
+
+    # The collective alone (sharded runs): the all-gather of the candidate blocks, their copy to pinned memory and
+    # the event behind it, as the search queues them, without the kernels in front.
+    collective_ms = None
+    if sharded:
+        from strugatzki_amd.search import exchange_only
+        for _ in range(20):
+            exchange_only(ctx, params)
+        sync()
+        tx = time.perf_counter()
+        for _ in range(200):
+            exchange_only(ctx, params)
+        sync()
+        collective_ms = (time.perf_counter() - tx) / 200 * 1e3
+
+    ctx.corr_set_target(targets[0], 0.5, 8.0)
+    matches = search_only()
 
     # Cold step: the half-precision image, prefix records and centring constants of the database are built by the
     # first search after the database, the norms or the target length change and kept afterwards (the timed steps
@@ -304,10 +434,10 @@ def main() -> int:
         for _ in range(5):
             ctx.set_norms(other)
             ctx.set_norms(norms_default())
-            ctx.corr_set_target(target, 0.5, 8.0)
             ctx.synchronize()
             tc = time.perf_counter()
-            step()
+            ctx.corr_set_target(targets[0], 0.5, 8.0)
+            search_only()
             cold_ms.append((time.perf_counter() - tc) * 1e3)
 
     # The same search with the other screening kernel, timed in the same run (the layout is rebuilt, so the first
@@ -316,24 +446,17 @@ def main() -> int:
     if world == 1 and not sharded and mode == "f16" and args.other_steps > 0 and args.screen_kernel == "auto":
         other_name = "matrix" if spectral else "spectral"
         ctx.set_screen_kernel(other_name)
-        ctx.set_kernel_timing(8)
         for _ in range(100):
-            om = step()
+            om = search_only()
         if ctx.screen_kernel_in_use == other_name:
-            ctx.synchronize()
-            to = time.perf_counter()
-            for _ in range(args.other_steps):
-                om = step()
-            ctx.synchronize()
-            o_elapsed = time.perf_counter() - to
-            o_ms = [float(x) for x in ctx.kernel_ms_history(args.other_steps // 8) if x > 0]
+            o_elapsed, o_ms = timed_leg(search_only, args.other_steps)
+            om = search_only()
             o_windows, o_flops = ctx.corr_last_work()
             alt = (other_name, o_elapsed / args.other_steps, float(np.mean(o_ms)) if o_ms else 0.0, o_windows, o_flops,
                      [(m.file, m.start, m.stop, m.sim) for m in om] == [(m.file, m.start, m.stop, m.sim) for m in matches],
                      ctx.screen_geometry)
         ctx.set_screen_kernel(args.screen_kernel)
-        ctx.set_kernel_timing(timing_every)
-        step()
+        search_only()
 
     # The same search at reference arithmetic: the fp64 kernel evaluates every window (no screening), the
     # selection replays over its values.  Timed here, after the main loop, so that the driver's own run carries
@@ -366,22 +489,17 @@ def main() -> int:
             "peak": PEAK_F64_TFLOPS,
             "unit": "TFLOP/s",
             "frac": (e_flops / (ek * 1e-3) / 1e12) / PEAK_F64_TFLOPS if ek > 0 else 0.0,
-            "verified": [(m.file, m.start // STEP) for m in em] == [(p["file"], p["offset"]) for p in plants],
+            "verified": keys(em) == [(p["file"], p["offset"]) for p in plants_of[0]],
             "same_matches_as_screened": [(m.file, m.start, m.stop) for m in em] == [(m.file, m.start, m.stop) for m in matches],
             "note": "every window evaluated by the fp64 kernel (v_fmac_f64, fp64 vector peak 78.6 TFLOP/s), selection "
                     "replayed over its values: the search at the reference's arithmetic, no screening",
         }
 
-    # known answer: match j is plant j (noise grows with j), at its planted offset
-    got = [(m.file, m.start // STEP) for m in matches]
-    want = [(p["file"], p["offset"]) for p in plants]
-    verified = got == want
-
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         # dominant kernel: the launch that evaluates every window of the step
         tail_windows, tail_flops = screened_work
-        k_ms = float(np.mean(kernel_ms))
+        k_ms = float(np.mean(kernel_ms)) if kernel_ms else 0.0
         alg_bytes = tail_windows * 64.0  # one new frame in (56 B), similarity and boost out (8 B)
 
         def matrix_roofline(kms, flops):
@@ -416,6 +534,7 @@ def main() -> int:
                 "algorithmic_bytes": windows * 64.0,
                 "bytes_by_design": moved,
                 "gbs_by_design": moved / (kms * 1e-3) / 1e9 if kms > 0 else 0.0,
+                "frac_by_design": moved / (kms * 1e-3) / 1e9 / PEAK_HBM_GBS if kms > 0 else 0.0,
                 "transform_length": n, "windows_per_block": hop, "blocks": blocks,
                 "spectra": "16-bit integers, one scale per 64 bins" if q16 else "fp32",
                 "note": "one launch over all files, one workgroup per block of N frames: the cross terms of a block's "
@@ -425,18 +544,26 @@ def main() -> int:
                         "summed in the frequency domain, one fp32 inverse transform in LDS); achieved = 64 algorithmic bytes per window (one new "
                         "frame in, similarity and boost out) over the kernel's duration, against 8 TB/s; "
                         "bytes_by_design is what this formulation has to move (overlapping blocks, cached window "
-                        "statistics; the search reads candidate lists, not an upper bound per window).  It yields certified bounds, and every "
+                        "statistics; the search reads candidate lists, not an upper bound per window), frac_by_design "
+                        "that over the same duration and peak.  It yields certified bounds, and every "
                         "window the bounds cannot exclude is re-evaluated in fp64 from the raw frames before the "
                         "selection replay",
             }
 
+        def traffic_of(roof, kernel):
+            """HBM bytes per launch from the committed counter passes of this command (not measured in this run)."""
+            t = pmc_traffic_bytes(kernel) if is_c3 else None
+            roof["traffic"] = t
+            roof["traffic_source"] = f"profiles/{PMC_SUMMARY} (rocprofv3 --pmc passes of this command, committed)" \
+                if t is not None else None
+            if t is not None and roof.get("kernel_ms"):
+                roof["frac_by_traffic"] = t / (roof["kernel_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS
+
         is_c3 = (L, total_files) == (2584, 120)
         if spectral:
             roof = spectral_roofline(k_ms, tail_windows, (fft_n, fft_hop, fft_blocks))
-            roof["traffic"] = pmc_traffic_bytes("corr_fft_kernel") if is_c3 else None
         elif mode == "f16":
             roof = matrix_roofline(k_ms, tail_flops)
-            roof["traffic"] = pmc_traffic_bytes("corr_mfma_kernel") if is_c3 else None
         else:
             achieved = tail_flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
             peak = {"f64": PEAK_F64_TFLOPS, "f32": PEAK_F32_TFLOPS}[mode]
@@ -451,19 +578,39 @@ def main() -> int:
                 }[mode],
             }
         roof.update({
-            "kernel_ms": k_ms,
+            "kernel_ms": k_ms if kernel_ms else None,
             "kernel_ms_samples": len(kernel_ms),
             "windows_per_launch": tail_windows,
             "flop_per_window_direct_form": 2.0 * NUM_CH * L,
             "hbm_frac_algorithmic": (alg_bytes / (k_ms * 1e-3) / 1e9) / PEAK_HBM_GBS if k_ms > 0 else 0.0,
         })
+        if mode == "f16":
+            traffic_of(roof, "corr_fft_kernel" if spectral else "corr_mfma_kernel")
+
+        def leg(per_step, kms, steps, what):
+            km = float(np.mean(kms)) if kms else 0.0
+            sub = spectral_roofline(km, tail_windows, (fft_n, fft_hop, fft_blocks)) if spectral else (
+                matrix_roofline(km, tail_flops) if mode == "f16" else {})
+            sub.pop("note", None)
+            sub.update({"what": what, "steps": steps, "ms_per_step": per_step * 1e3,
+                        "windows_per_s": unique_windows / per_step, "kernel_ms": km if kms else None,
+                        "kernel_ms_samples": len(kms)})
+            return sub
+
+        if steady is not None:
+            roof["steady"] = leg(steady[0], steady[1], args.steady_steps,
+                                 "the timed step (a new target per search) for longer, after the timed steps")
+        if same is not None:
+            roof["same_target"] = leg(same[0], same[1], args.same_target_steps,
+                                      "the search alone, the target left in place (no target preparation in the step)")
         if alt is not None:
             a_name, a_step, a_kms, a_windows, a_flops, a_same, a_geom = alt
             sub = matrix_roofline(a_kms, a_flops) if a_name == "matrix" else spectral_roofline(a_kms, a_windows, a_geom)
             sub.update({"kernel_ms": a_kms, "ms_per_step": a_step * 1e3, "steps": args.other_steps,
-                        "windows_per_s": unique_windows / a_step, "same_matches": a_same})
+                        "windows_per_s": unique_windows / a_step, "same_matches": a_same,
+                        "what": "the search alone (target left in place) with the other screening kernel"})
             if a_name == "matrix":
-                sub["traffic"] = pmc_traffic_bytes("corr_mfma_kernel") if is_c3 else None
+                traffic_of(sub, "corr_mfma_kernel")
             roof["matrix_cores" if a_name == "matrix" else "spectral"] = sub
         dtype = {"f16": "f16 screening (matrix cores), f64 re-scoring of every returned similarity",
                  "f32": "f32 screening, f64 re-scoring of every returned similarity", "f64": "f64"}[mode]
@@ -480,6 +627,11 @@ def main() -> int:
             "warmup": args.warmup,
             "settle_steps": settle_steps,
             "ms_per_step": ms_per_step,
+            "step": ("a new target per search: one of %d distinct targets in rotation, raw frames in host memory -> "
+                     "normalisation, statistics, centring and spectra on the GPU, then the search" % n_tgt) if n_tgt > 1
+                    else "the search alone, the target set once before the timed steps",
+            "targets": n_tgt,
+            "targets_verified": verified_targets,
             "cold_ms_per_step": float(np.median(cold_ms)) if cold_ms else None,
             "higher_is_better": True,
             "scaling": "weak",
@@ -504,6 +656,12 @@ def main() -> int:
             "roofline": roof,
             "verified": verified,
         }
+        if sharded:
+            out["rccl_ranks"] = rccl_ranks
+            out["rank_ms_per_step"] = {"min": min(rank_elapsed) / args.steps * 1e3,
+                                       "max": max(rank_elapsed) / args.steps * 1e3}
+            out["collective_ms_per_step"] = collective_ms
+            out["collective_share_of_step"] = collective_ms / ms_per_step if collective_ms is not None else None
         if exact is not None:
             out["roofline"]["exact"] = exact
         if world == 1 and args.cpu_seconds > 0:
@@ -511,7 +669,7 @@ def main() -> int:
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         sys.stdout.flush()
         os.dup2(json_fd, 1)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(finite_json(out), allow_nan=False), flush=True)
     ctx.close()
     if sharded:
         dist.barrier()

@@ -141,9 +141,16 @@ SGZ_API int sgz_set_norms(sgz_context *ctx, const float *norms);
 /* Sets the punch-in target: `frames` are the raw interleaved feature frames of
  * the target span (L = num_frames >= 1).  Normalises them, computes the
  * temporal / spectral mean and std-dev and ln(avg loudness)
- * (readInBuffer, impl/FeatureCorrelationImpl.scala:83-98). */
+ * (readInBuffer, impl/FeatureCorrelationImpl.scala:83-98) -- on the device: the host
+ * hands over the raw frames only.  The fp64 sums of MathUtil.stat
+ * (impl/MathUtil.scala:29-62) are taken in a fixed tree order, not sequentially: the
+ * statistics agree with the reference's to a few units of the last place of a double. */
 SGZ_API int sgz_corr_set_target(sgz_context *ctx, const float *frames, int num_frames,
                         float temporal_weight, float max_boost);
+/* The statistics of the current target as readInBuffer keeps them
+ * (impl/FeatureCorrelationImpl.scala:90-97): stats_out[0..4] = mean and std-dev of the
+ * loudness row, mean and std-dev of the other rows, ln(average loudness). */
+SGZ_API int sgz_corr_target_stats(const sgz_context *ctx, double *stats_out);
 
 /* Number of sliding windows the reference loop visits for database file `file`
  * with the current target (impl/FeatureCorrelationImpl.scala:182-190,242-246):

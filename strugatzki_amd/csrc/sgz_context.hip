@@ -40,12 +40,26 @@ int sgz_create(int device, void *hip_stream, sgz_context **out)
         delete ctx;
         return SGZ_E_HIP;
     }
-    if (sgz::noalloc_scratch_init(ctx) != SGZ_OK) {
-        (void)hipStreamDestroy(ctx->copy_stream);
-        (void)hipStreamDestroy(ctx->screen_stream);
-        if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
-        delete ctx;
-        return SGZ_E_HIP;
+    // (sgz_corr_rescore_device_noalloc is an optional entry point: where the lookup of its scratch array fails the
+    // context works without it, and that call says so)
+    if (sgz::noalloc_scratch_init(ctx) != SGZ_OK) ctx->noalloc_scratch = nullptr;
+    // the norms as a device table (min[64], then max - min[64]); until sgz_set_norms is called: no normalisation
+    {
+        float tab[2 * SGZ_MAX_CHANNELS];
+        for (int c = 0; c < SGZ_MAX_CHANNELS; c++) {
+            tab[c] = 0.0f;
+            tab[SGZ_MAX_CHANNELS + c] = 1.0f;
+        }
+        if (hipMalloc(reinterpret_cast<void **>(&ctx->d_normtab), sizeof tab) != hipSuccess ||
+            hipMemcpy(ctx->d_normtab, tab, sizeof tab, hipMemcpyHostToDevice) != hipSuccess) {
+            if (ctx->d_normtab) (void)hipFree(ctx->d_normtab);
+            (void)hipStreamDestroy(ctx->copy_stream);
+            (void)hipStreamDestroy(ctx->screen_stream);
+            if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+            delete ctx;
+            return SGZ_E_HIP;
+        }
+        ctx->normtab_cap = 2 * SGZ_MAX_CHANNELS;
     }
     *out = ctx;
     return SGZ_OK;

@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1361,6 +1362,125 @@ __global__ __launch_bounds__(256) void rescore_final_kernel(const FileDesc *__re
 }
 
 // ---------------------------------------------------------------------------
+// Target preparation (readInBuffer, impl/FeatureCorrelationImpl.scala:83-98): normalise the raw frames
+// (MathUtil.normalize, impl/MathUtil.scala:132-152: fp32 subtraction and IEEE division), the two-pass
+// statistics of the loudness row and of the other rows (MathUtil.stat, :29-62: fp64 sums), the centred
+// target in fp64 and rounded to fp32, and what the screening bounds need of the fp32 values.
+//
+// One workgroup.  The raw frames are read from where the host left them (pinned host memory: 145 KB for a
+// 30 s target, cheaper to read in place than to copy first).  Every sum is taken in a fixed order that
+// depends on nothing but the target's shape -- element e of the interleaved frames belongs to thread
+// e mod 1024, a thread adds its elements in index order, the 64 lanes of a wave are folded by a butterfly,
+// the 16 waves added in wave order -- so a target always gets the same statistics; they differ from a
+// sequential summation in the reference's order by a few units of the last place of the fp64 sums.
+// The scalars go to pinned host memory, followed by a sequence word the host polls: the host needs them as
+// kernel arguments of everything that follows.
+// ---------------------------------------------------------------------------
+constexpr int kTpThreads = 1024;
+
+struct TargetReport {
+    double sum1[2];   // sums of the normalised values: loudness row, other rows
+    double sum2[2];   // sums of the squared deviations from the group's mean
+    double csum[2];   // sums of the centred values (what rounding leaves of zero)
+    double fsum[2];   // sums of the centred values rounded to fp32
+    double fsq[2];    // sums of their squares
+    double fsq1;      // ... of channel 1 alone
+    unsigned long long inRange;  // 1: every centred value lies within the half-precision range
+    unsigned long long seq;      // written last
+};
+
+template <int K>
+__device__ __forceinline__ void tp_reduce(double (&v)[K], double *red /* 16 * K doubles */)
+{
+#pragma unroll
+    for (int j = 0; j < K; j++)
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v[j] += __shfl_xor(v[j], off, 64);
+    __syncthreads();  // (the previous round's readers are done with `red`)
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int j = 0; j < K; j++) red[(threadIdx.x >> 6) * K + j] = v[j];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+        double s = 0.0;
+        for (int w = 0; w < kTpThreads / 64; w++) s += red[w * K + j];
+        v[j] = s;
+    }
+}
+
+__global__ __launch_bounds__(kTpThreads) void target_prep_kernel(const float *__restrict__ frames, int L, int numCh,
+                                                                 int Lpad, const float *__restrict__ normTab,
+                                                                 int normEnabled, float *__restrict__ tnorm,
+                                                                 double *__restrict__ aprime,
+                                                                 float *__restrict__ aprimeF, TargetReport *report,
+                                                                 unsigned long long seq)
+{
+    __shared__ double red[(kTpThreads / 64) * 7];
+    const int tid = threadIdx.x;
+    const long long n = (long long)L * numCh;
+    float *tb = tnorm, *tfm = tnorm + n;  // channel-major [numCh][L], then frame-major [L][numCh]
+    double s1[2] = {0.0, 0.0};
+    for (long long e = tid; e < n; e += kTpThreads) {
+        const int i = (int)(e / numCh), c = (int)(e - (long long)i * numCh);
+        float v = frames[e];
+        if (normEnabled) v = (v - normTab[c]) / normTab[SGZ_MAX_CHANNELS + c];
+        tb[(size_t)c * L + i] = v;
+        tfm[e] = v;
+        s1[c > 0] += (double)v;
+    }
+    tp_reduce<2>(s1, red);
+    const double nT = (double)L, nS = (double)L * (double)(numCh - 1);
+    const double meanT = s1[0] / nT, meanS = s1[1] / nS;
+    double acc[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // sum2 T/S, fsq T/S, fsq1, csum T/S
+    double cs[2] = {0.0, 0.0}, fs[2] = {0.0, 0.0};
+    int inRange = 1;
+    for (long long e = tid; e < n; e += kTpThreads) {
+        const int i = (int)(e / numCh), c = (int)(e - (long long)i * numCh);
+        const int g = c > 0;
+        const double v = (double)tfm[e] - (g ? meanS : meanT);  // (this thread wrote tfm[e] itself)
+        aprime[(size_t)c * Lpad + i] = v;
+        acc[g] += v * v;
+        cs[g] += v;
+        inRange &= fabs(v) <= 60000.0;  // (false for NaN as well)
+        const float vf = (float)v;
+        aprimeF[(size_t)c * Lpad + i] = vf;
+        const double w = (double)vf;
+        fs[g] += w;
+        acc[2 + g] += w * w;
+        if (c == 1) acc[4] += w * w;
+    }
+    acc[5] = cs[0];
+    acc[6] = cs[1];
+    // zero padding behind the target's last frame
+    const int padLen = Lpad - L;
+    for (long long e = tid; e < (long long)padLen * numCh; e += kTpThreads) {
+        const int c = (int)(e / padLen), i = L + (int)(e - (long long)c * padLen);
+        aprime[(size_t)c * Lpad + i] = 0.0;
+        aprimeF[(size_t)c * Lpad + i] = 0.0f;
+    }
+    tp_reduce<7>(acc, red);
+    tp_reduce<2>(fs, red);
+    const int allIn = __syncthreads_and(inRange);
+    if (tid == 0) {
+        report->sum1[0] = s1[0];
+        report->sum1[1] = s1[1];
+        report->sum2[0] = acc[0];
+        report->sum2[1] = acc[1];
+        report->fsq[0] = acc[2];
+        report->fsq[1] = acc[3];
+        report->fsq1 = acc[4];
+        report->csum[0] = acc[5];
+        report->csum[1] = acc[6];
+        report->fsum[0] = fs[0];
+        report->fsum[1] = fs[1];
+        report->inRange = allIn ? 1ull : 0ull;
+        __threadfence_system();
+        __hip_atomic_store(&report->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Scratch of sgz_corr_rescore_device_noalloc: the partial sums of the exact re-scoring
 // ([window][slice][kRsParts] doubles), which sgz_corr_rescore_device keeps in a buffer it allocates on
 // demand.  A file-scope device array: every GPU the library runs on holds its own copy, at its own address,
@@ -1605,6 +1725,7 @@ int sgz_db_reset(sgz_context *ctx, int num_channels)
         if (f.owned && f.d_raw) SGZ_HIP(ctx, hipFree(f.d_raw));
     ctx->files.clear();
     ctx->db_tag.clear();
+    ctx->db_serial++;
     ctx->ring_images.clear();
     ctx->numCh = num_channels;
     ctx->layout_dirty = true;
@@ -1638,6 +1759,7 @@ int sgz_db_add_file(sgz_context *ctx, const float *frames, int64_t num_frames)
     if (bytes) SGZ_HIP(ctx, hipMemcpy(f.d_raw, frames, bytes, hipMemcpyHostToDevice));
     ctx->files.push_back(f);
     ctx->db_tag.clear();
+    ctx->db_serial++;
     ctx->layout_dirty = true;
     return SGZ_OK;
 }
@@ -1682,6 +1804,7 @@ int sgz_db_add_file_pcm(sgz_context *ctx, const void *samples, int sample_format
     }
     ctx->files.push_back(f);
     ctx->db_tag.clear();
+    ctx->db_serial++;
     ctx->layout_dirty = true;
     return SGZ_OK;
 }
@@ -1700,6 +1823,7 @@ int sgz_db_add_file_device(sgz_context *ctx, const float *device_frames, int64_t
     f.d_raw = const_cast<float *>(device_frames);
     ctx->files.push_back(f);
     ctx->db_tag.clear();
+    ctx->db_serial++;
     ctx->layout_dirty = true;
     return SGZ_OK;
 }
@@ -1737,6 +1861,7 @@ int sgz_db_add_synthetic(sgz_context *ctx, uint64_t seed, int64_t file_id, int64
     if (d_pl) SGZ_HIP(ctx, hipFree(d_pl));
     ctx->files.push_back(f);
     ctx->db_tag.clear();
+    ctx->db_serial++;
     ctx->layout_dirty = true;
     return SGZ_OK;
 }
@@ -1791,10 +1916,18 @@ int sgz_corr_set_ring_image(sgz_context *ctx, int file, const float *frames, int
     if (!ctx) return SGZ_E_ARG;
     if (file < 0 || file >= (int)ctx->files.size()) return ctx->fail(SGZ_E_ARG, "bad file index");
     if (num_frames < 0 || (num_frames > 0 && !frames)) return ctx->fail(SGZ_E_ARG, "bad ring image");
-    if (!frames)
-        ctx->ring_images.erase(file);
-    else
-        ctx->ring_images[file].assign(frames, frames + (size_t)num_frames * ctx->numCh);
+    // (the same image again -- a caller that hands it over with every search -- leaves the layout as it is)
+    const auto it = ctx->ring_images.find(file);
+    if (!frames) {
+        if (it == ctx->ring_images.end()) return SGZ_OK;
+        ctx->ring_images.erase(it);
+    } else {
+        const size_t n = (size_t)num_frames * ctx->numCh;
+        if (it != ctx->ring_images.end() && it->second.size() == n &&
+            std::memcmp(it->second.data(), frames, sizeof(float) * n) == 0)
+            return SGZ_OK;
+        ctx->ring_images[file].assign(frames, frames + n);
+    }
     ctx->layout_dirty = true;
     return SGZ_OK;
 }
@@ -1820,7 +1953,8 @@ int sgz_set_norms(sgz_context *ctx, const float *norms)
         }
     }
     // the same norms again (a caller that sets them with every query): everything derived from them stays valid
-    if (ctx->d_normtab && std::memcmp(&nrm, &ctx->norm, sizeof nrm) == 0) return SGZ_OK;
+    if (ctx->norms_set && std::memcmp(&nrm, &ctx->norm, sizeof nrm) == 0) return SGZ_OK;
+    ctx->norms_set = true;
     ctx->norm = nrm;
     ctx->have_target = false;  // target statistics depend on the norms
     ctx->layout_dirty = true;  // so do the images of files shorter than the target
@@ -1845,61 +1979,46 @@ int sgz_corr_set_target(sgz_context *ctx, const float *frames, int num_frames, f
     if (!frames || num_frames < 1) return ctx->fail(SGZ_E_ARG, "target needs at least one frame");
     SGZ_HIP(ctx, hipSetDevice(ctx->device));
     const int numCh = ctx->numCh, L = num_frames;
-    // Everything the device gets of a target is written into one pinned buffer and copied asynchronously on the
-    // context's stream (a query service sets a new target per search: four blocking copies out of pageable memory
-    // were most of this call).  The stream is drained first: kernels of the search before may still read the old
-    // target, and its copies this buffer.
+    // The host hands over the raw frames and nothing else: they are written into a pinned buffer that
+    // target_prep_kernel reads in place; normalisation, statistics and the centred copies are device work
+    // (a query service sets a new target per search).  Pinned layout: raw frames, the kernel's report, and the
+    // staging of the matrix-core kernel's target image (fp64 centred target + the image, filled when that kernel
+    // first runs with this target).
     int S = (L + kR - 1) / kR;
     S = (S + 1) & ~1;
     const size_t Lpad = (size_t)S * kR;
     const size_t nTb = (size_t)numCh * L, nAp = (size_t)numCh * Lpad;
     auto up256 = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    const size_t offAp = 0, offTn = up256(offAp + sizeof(double) * nAp), offApf = up256(offTn + sizeof(float) * 2 * nTb);
-    const size_t offImg = up256(offApf + sizeof(float) * nAp);
+    const size_t offRaw = 0, offRep = up256(offRaw + sizeof(float) * nTb), offAp = up256(offRep + sizeof(TargetReport));
+    const size_t offImg = up256(offAp + sizeof(double) * nAp);
     const size_t imgHalfwords = sgz::half_image_halfwords(L, numCh);
     const size_t stageBytes = up256(offImg + sizeof(uint16_t) * imgHalfwords);
-    SGZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // Kernels of the search before read the old target on `stream`, where the new one is written in order behind
+    // them; the fp32 screening reads it on the other stream.  The previous target's kernel has finished with the
+    // pinned frames (its report was waited for).
     SGZ_HIP(ctx, hipStreamSynchronize(ctx->screen_stream));
     if (stageBytes > ctx->tgt_stage_cap) {
+        SGZ_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (a copy out of the old buffer may be on its way)
         if (ctx->h_tgt_stage) (void)hipHostFree(ctx->h_tgt_stage);
         ctx->h_tgt_stage = nullptr;
         ctx->tgt_stage_cap = 0;
         SGZ_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_tgt_stage), stageBytes, hipHostMallocDefault));
         ctx->tgt_stage_cap = stageBytes;
+        std::memset(ctx->h_tgt_stage + offRep, 0, sizeof(TargetReport));
     }
-    double *ap = reinterpret_cast<double *>(ctx->h_tgt_stage + offAp);
-    float *tb = reinterpret_cast<float *>(ctx->h_tgt_stage + offTn), *tfm = tb + nTb;  // channel-major, frame-major
-    float *apf = reinterpret_cast<float *>(ctx->h_tgt_stage + offApf);
-    // readInBuffer (impl/FeatureCorrelationImpl.scala:83-98): de-interleave, normalise (fp32)
-    for (int i = 0; i < L; i++)
-        for (int c = 0; c < numCh; c++) {
-            float v = frames[(size_t)i * numCh + c];
-            if (ctx->norm.enabled) v = (v - ctx->norm.mn[c]) / ctx->norm.d[c];
-            tb[(size_t)c * L + i] = v;
-            tfm[(size_t)i * numCh + c] = v;
-        }
-    // MathUtil.stat over the loudness row and over the MFCC rows (two passes, fp64)
-    auto stat = [&](int c0, int c1, double &mean, double &sd) {
-        double sum = 0.0;
-        for (int c = c0; c < c1; c++)
-            for (int i = 0; i < L; i++) sum += tb[(size_t)c * L + i];
-        const int sz = L * (c1 - c0);
-        mean = sum / sz;
-        sum = 0.0;
-        for (int c = c0; c < c1; c++)
-            for (int i = 0; i < L; i++) {
-                const double d = tb[(size_t)c * L + i] - mean;
-                sum += d * d;
-            }
-        sd = std::sqrt(sum / sz);
-    };
-    double tMean, tStd, sMean, sStd;
-    stat(0, 1, tMean, tStd);
-    stat(1, numCh, sMean, sStd);
-    double lsum = 0.0;
-    for (int i = 0; i < L; i++) lsum += tb[i];
-    const float avgF = (float)(lsum / L);
-
+    std::memcpy(ctx->h_tgt_stage + offRaw, frames, sizeof(float) * nTb);
+    TargetReport *rep = reinterpret_cast<TargetReport *>(ctx->h_tgt_stage + offRep);
+    int rc;
+    if ((rc = ensure(ctx, ctx->d_aprime, ctx->aprime_cap, nAp))) return rc;
+    if ((rc = ensure(ctx, ctx->d_tnorm, ctx->tnorm_cap, 2 * nTb))) return rc;
+    if ((rc = ensure(ctx, ctx->d_aprime_f, ctx->aprime_f_cap, nAp))) return rc;
+    const unsigned long long seq = ++ctx->tgt_seq;
+    // (the report may sit at another offset than last time: the word the host polls must not hold this number yet)
+    __atomic_store_n(&rep->seq, 0ull, __ATOMIC_RELEASE);
+    hipLaunchKernelGGL(target_prep_kernel, dim3(1), dim3(kTpThreads), 0, ctx->stream,
+                       reinterpret_cast<const float *>(ctx->h_tgt_stage + offRaw), L, numCh, (int)Lpad, ctx->d_normtab,
+                       ctx->norm.enabled, ctx->d_tnorm, ctx->d_aprime, ctx->d_aprime_f, rep, seq);
+    SGZ_HIP(ctx, hipGetLastError());
     CorrParams &cp = ctx->cp;
     const int oldL = ctx->have_target ? cp.L : -1;
     cp.numCh = numCh;
@@ -1909,74 +2028,67 @@ int sgz_corr_set_target(sgz_context *ctx, const float *frames, int num_frames, f
     int SB = (S + cp.nb - 1) / cp.nb;
     SB = (SB + 3) & ~3;  // staged blocks start on 16-byte boundaries for both element types
     cp.SB = SB;
+    cp.w = temporal_weight;
+    cp.maxBoost = max_boost;
+    ctx->aspec_dirty = true;
+    // the spectral kernel's transform of the target needs nothing of the report: queued right behind the
+    // preparation while the host waits for the scalars
+    const bool early = oldL == L && !ctx->layout_dirty && ctx->fg.N > 0;
+    if (early && (rc = fft_target_spectra(ctx, ctx->stream))) return rc;
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        bool arrived = false;
+        for (unsigned long long spins = 0;; spins++) {
+            if (__atomic_load_n(&rep->seq, __ATOMIC_ACQUIRE) == seq) {
+                arrived = true;
+                break;
+            }
+            if ((spins & 0xffff) == 0xffff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) break;
+        }
+        if (!arrived) {  // something is wrong on the device: the stream says what
+            SGZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (__atomic_load_n(&rep->seq, __ATOMIC_ACQUIRE) != seq)
+                return ctx->fail(SGZ_E_HIP, "the target preparation kernel did not report");
+        }
+    }
+    // MathUtil.stat: mean = sum / n, sd = sqrt(sum of squared deviations / n)
+    const double nT = (double)L, nS = (double)L * (double)(numCh - 1);
+    const double tMean = rep->sum1[0] / nT, sMean = rep->sum1[1] / nS;
+    const double tStd = std::sqrt(rep->sum2[0] / nT), sStd = std::sqrt(rep->sum2[1] / nS);
+    const float avgF = (float)(rep->sum1[0] / L);  // MathUtil.avg over the loudness row
     cp.kT = tMean;
     cp.kS = sMean;
     cp.aStdT = tStd;
     cp.aStdS = sStd;
     cp.lnAvgIn = std::log((double)avgF);
-    cp.w = temporal_weight;
-    cp.maxBoost = max_boost;
-
-    // centred target in fp64 and rounded to fp32, zero-padded to Lpad per channel; of the fp32 values what the
-    // spectral screening needs: their sums and Euclidean norms per channel group
-    double sumT = 0.0, sumS = 0.0;
-    double fs[2] = {0.0, 0.0}, fq[2] = {0.0, 0.0}, fq1 = 0.0;
-    bool finite = true;  // every centred value within the half-precision range
-    for (int c = 0; c < numCh; c++) {
-        const double mean = c == 0 ? tMean : sMean;
-        double *apc = ap + (size_t)c * Lpad;
-        float *apfc = apf + (size_t)c * Lpad;
-        for (int i = 0; i < L; i++) {
-            const double v = (double)tb[(size_t)c * L + i] - mean;  // ca(i) + aAdd, MathUtil.scala:190
-            apc[i] = v;
-            if (c == 0) sumT += v; else sumS += v;
-            finite = finite && std::fabs(v) <= 60000.0;  // (false for NaN as well)
-            const float vf = (float)v;
-            apfc[i] = vf;
-            const double w = (double)vf;
-            fs[c > 0] += w;
-            fq[c > 0] += w * w;
-            if (c == 1) fq1 += w * w;
-        }
-        for (size_t i = (size_t)L; i < Lpad; i++) {
-            apc[i] = 0.0;
-            apfc[i] = 0.0f;
-        }
-    }
-    cp.sumAT = sumT;
-    cp.sumAS = sumS;
-    ctx->tgt_nrm1 = std::sqrt(fq1);
-    ctx->tgt_sumT = fs[0];
-    ctx->tgt_sumS = fs[1];
-    ctx->tgt_nrmT = std::sqrt(fq[0]);
-    ctx->tgt_nrmS = std::sqrt(fq[1]);
-    ctx->aspec_dirty = true;
+    cp.sumAT = rep->csum[0];
+    cp.sumAS = rep->csum[1];
+    ctx->tgt_nrm1 = std::sqrt(rep->fsq1);
+    ctx->tgt_sumT = rep->fsum[0];
+    ctx->tgt_sumS = rep->fsum[1];
+    ctx->tgt_nrmT = std::sqrt(rep->fsq[0]);
+    ctx->tgt_nrmS = std::sqrt(rep->fsq[1]);
     ctx->aMeanT = tMean;
     ctx->aMeanS = sMean;
-    int rc;
-    if ((rc = ensure(ctx, ctx->d_aprime, ctx->aprime_cap, nAp))) return rc;
-    if ((rc = ensure(ctx, ctx->d_tnorm, ctx->tnorm_cap, 2 * nTb))) return rc;
-    if ((rc = ensure(ctx, ctx->d_aprime_f, ctx->aprime_f_cap, nAp))) return rc;
-    SGZ_HIP(ctx, hipMemcpyAsync(ctx->d_aprime, ap, sizeof(double) * nAp, hipMemcpyHostToDevice, ctx->stream));
-    // normalised target twice: channel-major [numCh][L], then frame-major [L][numCh]
-    SGZ_HIP(ctx, hipMemcpyAsync(ctx->d_tnorm, tb, sizeof(float) * 2 * nTb, hipMemcpyHostToDevice, ctx->stream));
-    SGZ_HIP(ctx, hipMemcpyAsync(ctx->d_aprime_f, apf, sizeof(float) * nAp, hipMemcpyHostToDevice, ctx->stream));
+    const bool finite = rep->inRange != 0;
     ctx->have_target = true;
+    ctx->tgt_serial++;
     // half-precision target image of the matrix-core screening kernel (none when the geometry does not fit)
     const bool hadHalf = ctx->hg.S2 > 0;
-    // (the image itself is built when that kernel first runs with this target: converting 36 000 values to half
-    // precision on the host takes longer than the rest of this call, and searches screened by the spectral kernel
-    // never read it)
-    ctx->half_stage_ap = ap;
+    // (the image itself is built when that kernel first runs with this target: it takes the fp64 target back from
+    // the device and converts 36 000 values to half precision on the host, which takes longer than the rest of this
+    // call, and searches screened by the spectral kernel never read it)
+    ctx->half_stage_ap = reinterpret_cast<double *>(ctx->h_tgt_stage + offAp);
     ctx->half_stage_lpad = Lpad;
     ctx->half_stage_img = reinterpret_cast<uint16_t *>(ctx->h_tgt_stage + offImg);
     ctx->half_stage_halfwords = imgHalfwords;
     if ((rc = half_screen_set_target(ctx, finite))) return rc;
-    // (the fp32 screening runs on the other stream: it waits for the uploads)
+    // (the fp32 screening runs on the other stream: it waits for the preparation)
     if (!ctx->tgt_event) SGZ_HIP(ctx, hipEventCreateWithFlags(&ctx->tgt_event, hipEventDisableTiming));
     SGZ_HIP(ctx, hipEventRecord(ctx->tgt_event, ctx->stream));
     SGZ_HIP(ctx, hipStreamWaitEvent(ctx->screen_stream, ctx->tgt_event, 0));
     if (oldL != L || hadHalf != (ctx->hg.S2 > 0)) ctx->layout_dirty = true;
+    if (early && !ctx->layout_dirty) fft_target_ready(ctx);
     // the NaN marks of half-precision runs belong to the previous target
     // (a pending layout rebuild clears all marks itself, for the files of the new layout)
     if (ctx->d_hflags && !ctx->layout_dirty && !ctx->files.empty()) {
@@ -1984,6 +2096,18 @@ int sgz_corr_set_target(sgz_context *ctx, const float *frames, int num_frames, f
         hipLaunchKernelGGL(clear_nan_flags_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_hflags, n);
         SGZ_HIP(ctx, hipGetLastError());
     }
+    return SGZ_OK;
+}
+
+int sgz_corr_target_stats(const sgz_context *ctx, double *stats_out)
+{
+    if (!ctx || !stats_out) return SGZ_E_ARG;
+    if (!ctx->have_target) return ctx->fail(SGZ_E_STATE, "sgz_corr_set_target has not been called");
+    stats_out[0] = ctx->cp.kT;
+    stats_out[1] = ctx->cp.aStdT;
+    stats_out[2] = ctx->cp.kS;
+    stats_out[3] = ctx->cp.aStdS;
+    stats_out[4] = ctx->cp.lnAvgIn;
     return SGZ_OK;
 }
 
@@ -2481,26 +2605,19 @@ static int rescore_device_impl(sgz_context *ctx, sgz_candidate *device_cands, in
     rg.slices = (ctx->cp.L + rg.sliceFrames - 1) / rg.sliceFrames;  // no empty slice
     int rc;
     double *part = part_noalloc;
-    const float *normtab = ctx->d_normtab;
+    const float *normtab = ctx->d_normtab;  // (exists from sgz_create on)
     if (part_noalloc) {
         // the variant that allocates nothing: partial sums in the device's scratch array.  Every value read is
         // written earlier in the same call, so nothing has to be cleared.
-        const size_t need = (size_t)capacity * rg.slices * kRsParts * sizeof(double);
-        if (need > kNoAllocScratchBytes)
+        const size_t perRecord = (size_t)rg.slices * kRsParts * sizeof(double);
+        if ((size_t)capacity > kNoAllocScratchBytes / perRecord)  // (by division: the product may not fit)
             return ctx->fail(SGZ_E_ARG, "sgz_corr_rescore_device_noalloc: capacity " + std::to_string(capacity) + " x " +
-                                            std::to_string(rg.slices) + " slices of this target needs " +
-                                            std::to_string(need) + " bytes of scratch, the limit is " +
-                                            std::to_string(kNoAllocScratchBytes));
-        // no norms were ever set: normalisation is off and the kernels read but do not use the table
-        if (!normtab) normtab = reinterpret_cast<const float *>(part_noalloc);
+                                            std::to_string(rg.slices) + " slices of this target needs more than the " +
+                                            std::to_string(kNoAllocScratchBytes) + " bytes of scratch (" +
+                                            std::to_string(kNoAllocScratchBytes / perRecord) + " records at most)");
     } else {
         if ((rc = ensure(ctx, ctx->d_rs_part, ctx->rs_part_cap, (size_t)capacity * rg.slices * kRsParts))) return rc;
         part = ctx->d_rs_part;
-        if (!ctx->d_normtab) {  // sgz_set_norms was never called: normalisation is off, the table is not read
-            if ((rc = ensure(ctx, ctx->d_normtab, ctx->normtab_cap, (size_t)2 * SGZ_MAX_CHANNELS))) return rc;
-            SGZ_HIP(ctx, hipMemsetAsync(ctx->d_normtab, 0, sizeof(float) * 2 * SGZ_MAX_CHANNELS, ctx->stream));
-        }
-        normtab = ctx->d_normtab;
     }
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);

@@ -688,8 +688,8 @@ int ensure_tab(sgz_context *ctx)
     return SGZ_OK;
 }
 
-// Target spectra and the target-dependent factors of the error bound (per target; N from the layout).
-int fft_target(sgz_context *ctx, hipStream_t stream)
+// The target's spectra (per target; N from the layout): one kernel on `stream`, reading the centred fp32 target.
+int fft_target_launch(sgz_context *ctx, hipStream_t stream)
 {
     FftGeom &fg = ctx->fg;
     const int N = fg.N, numCh = ctx->cp.numCh, L = ctx->cp.L;
@@ -713,7 +713,15 @@ int fft_target(sgz_context *ctx, hipStream_t stream)
     if (N == 4096) rc = q16 ? launch(fft_target_kernel<4096, true>) : launch(fft_target_kernel<4096, false>);
     else if (N == 8192) rc = q16 ? launch(fft_target_kernel<8192, true>) : launch(fft_target_kernel<8192, false>);
     else rc = q16 ? launch(fft_target_kernel<16384, true>) : launch(fft_target_kernel<16384, false>);
-    if (rc) return rc;
+    return rc;
+}
+
+// The target-dependent factors of the error bound, from the target's statistics (host arithmetic).
+void fft_target_factors(sgz_context *ctx)
+{
+    FftGeom &fg = ctx->fg;
+    const int N = fg.N, numCh = ctx->cp.numCh, L = ctx->cp.L;
+    const bool q16 = fg.q16 != 0;
     const double nT = (double)L, nS = (double)L * (numCh - 1);
     fg.sumAT = ctx->tgt_sumT;
     fg.sumAS = ctx->tgt_sumS;
@@ -736,6 +744,13 @@ int fft_target(sgz_context *ctx, hipStream_t stream)
     fg.kS = numCh > 1 ? (float)(up / (ctx->cp.aStdS * nS)) : 0.0f;
     fg.levelErr = ctx->norm.enabled ? (float)std::ldexp(1.0, -23) : 0.0f;
     fg.relErr = (float)std::ldexp(1.0, -22);
+}
+
+int fft_target(sgz_context *ctx, hipStream_t stream)
+{
+    int rc;
+    if ((rc = fft_target_launch(ctx, stream))) return rc;
+    fft_target_factors(ctx);
     ctx->aspec_dirty = false;
     return SGZ_OK;
 }
@@ -743,6 +758,14 @@ int fft_target(sgz_context *ctx, hipStream_t stream)
 }  // namespace
 
 namespace sgz {
+
+int fft_target_spectra(sgz_context *ctx, hipStream_t stream) { return fft_target_launch(ctx, stream); }
+
+void fft_target_ready(sgz_context *ctx)
+{
+    fft_target_factors(ctx);
+    ctx->aspec_dirty = false;
+}
 
 void fft_screen_free(sgz_context *ctx)
 {

@@ -411,7 +411,7 @@ int half_screen_set_target(sgz_context *ctx, bool in_half_range)
 }
 
 // The target's half-precision image (every channel at shifts 0 and 1 halfword) and the sums of its values, from the
-// fp64 target staged by sgz_corr_set_target; the copy to the device is queued on `stream`.
+// fp64 target of sgz_corr_set_target; the copy to the device is queued on `stream`.
 static int half_image_build(sgz_context *ctx, hipStream_t stream)
 {
     HalfGeom &hg = ctx->hg;
@@ -419,8 +419,11 @@ static int half_image_build(sgz_context *ctx, hipStream_t stream)
     const size_t perCopy = (size_t)2 * hg.LAd;  // halfwords
     const size_t total = (size_t)numCh * 2 * perCopy, Lpad = ctx->half_stage_lpad;
     uint16_t *stage = ctx->half_stage_img;
-    const double *aprime = ctx->half_stage_ap;
+    double *aprime = ctx->half_stage_ap;
     if (!stage || !aprime || total > ctx->half_stage_halfwords) return ctx->fail(SGZ_E_STATE, "no staged target");
+    // the centred fp64 target, which the preparation kernel left on the device
+    SGZ_HIP(ctx, hipMemcpyAsync(aprime, ctx->d_aprime, sizeof(double) * (size_t)numCh * Lpad, hipMemcpyDeviceToHost, stream));
+    SGZ_HIP(ctx, hipStreamSynchronize(stream));
     std::memset(stage, 0, total * sizeof(uint16_t));
     double sumT = 0.0, sumS = 0.0;
     for (int c = 0; c < numCh; c++) {

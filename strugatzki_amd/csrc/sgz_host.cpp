@@ -239,6 +239,7 @@ std::vector<Match> runFeatureCorrelationMulti(const std::vector<sgz_context *> &
         check(ctxs[(size_t)c], sgz_db_set_tag(ctxs[(size_t)c], tag.c_str()));
     }
     for (sgz_context *c : ctxs) {
+        check(c, sgz_corr_set_tail_trim(c, 0));  // (a resident database: nothing of an earlier call may linger)
         check(c, sgz_set_norms(c, cfg.normalize ? norms.data() : nullptr));
         check(c, sgz_corr_set_target(c, afIn.frames.data() + (size_t)start * numCh, L, cfg.punchIn.temporalWeight,
                                      cfg.maxBoost));
@@ -285,9 +286,16 @@ std::vector<Match> runFeatureCorrelationMulti(const std::vector<sgz_context *> &
         };
         std::vector<float> inSim, inBoost, outSim, outBoost;
         std::vector<size_t> inPos, outPos;
-        check(ctx, sgz_corr_set_tail_trim(ctx, minPunch));  // the punch-in pass stops minPunch frames early, :182-185
-        denseAll(inSim, inBoost, inPos);
-        check(ctx, sgz_corr_set_tail_trim(ctx, 0));
+        {
+            // the punch-in pass stops minPunch frames early, :182-185.  The database stays resident on the context:
+            // whatever ends this pass, the next search must see whole files again.
+            struct TrimGuard {
+                sgz_context *c;
+                ~TrimGuard() { (void)sgz_corr_set_tail_trim(c, 0); }
+            } guard{ctx};
+            check(ctx, sgz_corr_set_tail_trim(ctx, minPunch));
+            denseAll(inSim, inBoost, inPos);
+        }
         checkAborted(obs, 0.7);
         check(ctx, sgz_corr_set_target(ctx, afIn.frames.data() + (size_t)oStart * numCh, Lout,
                                        cfg.punchOut->temporalWeight, cfg.maxBoost));

@@ -151,13 +151,18 @@ struct sgz_context {
     int numCh = 0;
     std::vector<sgz::DbFile> files;
     std::string db_tag;                      // the caller's label of the loaded database (sgz_db_set_tag)
+    unsigned long long db_serial = 0;        // bumped by sgz_db_reset and every sgz_db_add_*: the files changed
+    std::string multi_ring_key;              // sgz_corr_search_multi (on its first context): what the ring images of
+                                             // the short files were last worked out for
     sgz::NormParams norm{};
+    bool norms_set = false;                  // sgz_set_norms has been called (else: no normalisation)
 
     // target
     bool have_target = false;
     sgz::CorrParams cp{};
-    // the matrix-core kernel's target image is built from the staged fp64 target when that kernel first needs it
-    const double *half_stage_ap = nullptr;
+    // the matrix-core kernel's target image is built when that kernel first needs it, from the fp64 target fetched
+    // back into this pinned staging area
+    double *half_stage_ap = nullptr;
     size_t half_stage_lpad = 0;
     uint16_t *half_stage_img = nullptr;
     size_t half_stage_halfwords = 0;
@@ -172,6 +177,8 @@ struct sgz_context {
     float *d_tnorm = nullptr;     // [numCh][L] normalised target, fp32 (exact re-scoring)
     size_t tnorm_cap = 0;
     double aMeanT = 0.0, aMeanS = 0.0;
+    unsigned long long tgt_seq = 0;          // sequence number of the latest report of target_prep_kernel
+    unsigned long long tgt_serial = 0;       // targets set so far
     float *d_aprime_f = nullptr;  // the same, rounded to fp32 (screening path)
     size_t aprime_f_cap = 0;
     uint16_t *d_aimg_h = nullptr; // half-precision target image [numCh][2 shifts][2 * LAd] (matrix-core screening)
@@ -376,6 +383,10 @@ int fft_screen_prepare(sgz_context *ctx, int file_begin, int file_end, hipStream
 int fft_screen_launch(sgz_context *ctx, int file_begin, int file_end, hipStream_t stream, hipEvent_t start,
                       hipEvent_t stop);
 void fft_screen_free(sgz_context *ctx);
+// A new target for the layout in force: its spectra can be queued before the host knows the target's statistics
+// (fft_target_spectra); once it does, fft_target_ready derives the error-bound factors and marks the spectra current.
+int fft_target_spectra(sgz_context *ctx, hipStream_t stream);
+void fft_target_ready(sgz_context *ctx);
 // Fills in the boosts the spectral kernel left out for files [file_begin, file_end) (kernels on `stream`);
 // *launched tells whether there was anything to do.
 int boost_materialize(sgz_context *ctx, int file_begin, int file_end, hipStream_t stream, bool *launched = nullptr);

@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -69,7 +70,10 @@ extern "C" int sgz_corr_search_multi(sgz_context *const *ctxs, int num_ctx, cons
         if (p.ctx < 0) return lead->fail(SGZ_E_ARG, "global ids do not cover every file");
     const int L = target_frames, numCh = lead->numCh;
 
-    // Files shorter than the target: the ring contents the single loop over all files would show them.
+    // Files shorter than the target: the ring contents the single loop over all files would show them.  They
+    // depend on the placement, the frame counts, the target length and the norms (positions no file has written
+    // hold raw values that normalise to 0): worked out when one of these changes, not per search -- a resident
+    // database answers its queries without reading frames back.
     {
         std::vector<long long> frames((size_t)num_files_total);
         bool anyShort = false;
@@ -77,7 +81,22 @@ extern "C" int sgz_corr_search_multi(sgz_context *const *ctxs, int num_ctx, cons
             frames[(size_t)g] = ctxs[place[(size_t)g].ctx]->files[(size_t)place[(size_t)g].local].frames;
             anyShort |= frames[(size_t)g] > 0 && frames[(size_t)g] < L;
         }
+        std::string key;
         if (anyShort) {
+            auto put = [&key](const void *p, size_t n) { key.append(reinterpret_cast<const char *>(p), n); };
+            put(&L, sizeof L);
+            put(&num_ctx, sizeof num_ctx);
+            for (int c = 0; c < num_ctx; c++) {
+                put(&ctxs[c], sizeof ctxs[c]);
+                put(&ctxs[c]->db_serial, sizeof ctxs[c]->db_serial);
+                put(&ctxs[c]->norm, sizeof ctxs[c]->norm);
+            }
+            for (int g = 0; g < num_files_total; g++) {
+                put(&place[(size_t)g], sizeof(Place));
+                put(&frames[(size_t)g], sizeof(long long));
+            }
+        }
+        if (anyShort && key != lead->multi_ring_key) {
             const std::vector<sgz_ring_run> runs = sgz::ring_runs(frames.data(), num_files_total, L);
             std::vector<float> zero((size_t)numCh), img;
             for (size_t k = 0; k < runs.size();) {
@@ -100,6 +119,7 @@ extern "C" int sgz_corr_search_multi(sgz_context *const *ctxs, int num_ctx, cons
                 const int rc = sgz_corr_set_ring_image(ctxs[dst.ctx], dst.local, img.data(), (int)(L - own));
                 if (rc) return lead->fail(rc, sgz_last_error(ctxs[dst.ctx]));
             }
+            lead->multi_ring_key = key;  // (only now: a failure on the way leaves the work to be done again)
         }
     }
 

@@ -138,17 +138,25 @@ class Context:
         """norms: [numCh][2] (min, max) or None."""
         if norms is None:
             self._check(lib.sgz_set_norms(self._h, None))
+            self._norms_key = None
             return
         a = np.ascontiguousarray(norms, dtype=np.float32)
         if a.shape != (self.num_channels, 2):
             raise ValueError("norms must be [numCh][2]")
         self._check(lib.sgz_set_norms(self._h, N.ptr(a)))
+        self._norms_key = a.tobytes()  # (the sharded search keys what it derived from the norms on this)
 
     # ---- correlation -----------------------------------------------------
     def corr_set_target(self, frames: np.ndarray, temporal_weight: float, max_boost: float) -> None:
         a = _as_frames(frames, self.num_channels)
         self._check(lib.sgz_corr_set_target(self._h, N.ptr(a), a.shape[0], temporal_weight, max_boost))
         self.target_frames = a.shape[0]
+
+    def corr_target_stats(self) -> np.ndarray:
+        """(mean, std-dev) of the loudness row, (mean, std-dev) of the other rows, ln(average loudness) of the target."""
+        out = np.zeros(5, dtype=np.float64)
+        self._check(lib.sgz_corr_target_stats(self._h, N.ptr(out)))
+        return out
 
     def corr_num_windows(self, file: int) -> int:
         return lib.sgz_corr_num_windows(self._h, file)

@@ -247,7 +247,8 @@ def _exchange_ring_images(ctx: Context, local_to_global: Sequence[int], group) -
     (ring_runs over the frame counts of all files in global order), the ranks all-gather the runs' frames
     (each rank fills in the runs it holds), and every rank hands its short files their ring contents
     (Context.corr_set_ring_image).  One collective, and only when the database holds such a file; done once per
-    (placement, target length)."""
+    (placement, target length, norms): ring positions no file has written hold raw values that normalise to 0, and
+    those depend on the norms in force."""
     import torch
     import torch.distributed as dist
 
@@ -255,15 +256,17 @@ def _exchange_ring_images(ctx: Context, local_to_global: Sequence[int], group) -
 
     maps = _rank_maps(ctx, local_to_global, group)
     L = ctx.target_frames
-    if maps["ring_for"] == L:
+    done_for = (L, ctx.__dict__.get("_norms_key"))
+    if maps["ring_for"] == done_for:
         return
-    maps["ring_for"] = L
     frames = maps["frames"]
     nfiles = len(frames)
     if sorted(frames) != list(range(nfiles)):
+        maps["ring_for"] = done_for
         return  # not a dense global numbering: the caller's own affair
     counts = [frames[g] for g in range(nfiles)]
     if not any(0 < c < L for c in counts):
+        maps["ring_for"] = done_for
         return
     runs = ring_runs(counts, L)
     rank = dist.get_rank(group)
@@ -303,6 +306,7 @@ def _exchange_ring_images(ctx: Context, local_to_global: Sequence[int], group) -
             k += 1
         if g in local_of:
             ctx.corr_set_ring_image(local_of[g], img)
+    maps["ring_for"] = done_for  # (only now: an exception on the way leaves the exchange to be done again)
 
 
 def _exchange_buffers(ctx: Context, cap: int, world: int, on_gpu: bool):
@@ -323,6 +327,34 @@ def _exchange_buffers(ctx: Context, cap: int, world: int, on_gpu: bool):
                           count_ptr=rec.data_ptr(), rec_ptr=rec[1:].data_ptr(),
                           view=host.numpy().reshape(world, rows, 4), event=torch.cuda.Event())
     return cache[key]
+
+
+def exchange_only(ctx: Context, p: SearchParams, group=None) -> None:
+    """The collective of a sharded search by itself, as _sharded_over_bounds queues it (all-gather of the candidate
+    blocks, their copy to pinned memory, the event the host polls) over whatever the buffers hold: for timing the
+    exchange apart from the kernels.  Needs an earlier sharded search on this context (its buffers)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    on_gpu = dist.get_backend(group) != "gloo"
+    b = _exchange_buffers(ctx, p.capacity, world, on_gpu)
+    ts = ctx.torch_stream
+    if on_gpu and ts is not None:
+        with torch.cuda.stream(ts):
+            dist.all_gather_into_tensor(b["gathered"], b["send"], group=group)
+            b["host"].copy_(b["gathered"], non_blocking=True)
+            b["event"].record(ts)
+        while not b["event"].query():
+            pass
+    elif on_gpu:
+        ctx.synchronize()
+        dist.all_gather_into_tensor(b["gathered"], b["send"], group=group)
+        b["host"].copy_(b["gathered"], non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+    else:
+        ctx.synchronize()
+        dist.all_gather_into_tensor(b["gathered"], b["send"].cpu(), group=group)
 
 
 def _sharded_over_bounds(ctx: Context, p: SearchParams, local_to_global: Sequence[int], num_files_total: int,

@@ -67,6 +67,32 @@ def test_dense_parity_ragged_and_short_files(ctx):
     _check_dense(ctx, db, tgt, ts, L, norms_default())
 
 
+@pytest.mark.parametrize("L,num_ch,normalize", [(2584, 14, True), (200, 14, True), (431, 14, False), (1, 14, True),
+                                                 (1025, 5, True), (300, 64, True), (5168, 14, True), (77, 2, False)])
+def test_target_statistics_from_the_device(ctx, L, num_ch, normalize):
+    """readInBuffer (impl/FeatureCorrelationImpl.scala:83-98) runs on the device: mean / std-dev of the loudness row
+    and of the other rows and ln(avg loudness) against MathUtil.stat / avg of the oracle.  The device adds in a fixed
+    tree order, the reference sequentially: equal to a few units of the last place of a double."""
+    ts = 3
+    tgt = synth_target(ts, L, num_ch=num_ch)[ts:ts + L] * np.float32(1.7) + np.float32(0.125)
+    norms = norms_default(num_ch) if normalize else None
+    ctx.db_reset(num_ch)
+    ctx.set_norms(norms)
+    ctx.corr_set_target(tgt, 0.5, 8.0)
+    got = ctx.corr_target_stats()
+    mat = O.normalize(norms, np.ascontiguousarray(tgt.T), 0, L)  # [ch][frame]
+    t_mean, t_std = O.stat(mat, 0, L, 0, 1)
+    s_mean, s_std = O.stat(mat, 0, L, 1, num_ch - 1)
+    ln_avg = np.log(np.float64(np.float32(O.avg(mat[0], 0, L))))
+    want = np.array([t_mean, t_std, s_mean, s_std, ln_avg])
+    np.testing.assert_allclose(got[[0, 2, 4]], want[[0, 2, 4]], rtol=1e-14, atol=0)
+    # (a one-frame loudness row has no spread: the deviations are what rounding leaves)
+    np.testing.assert_allclose(got[[1, 3]], want[[1, 3]], rtol=1e-13, atol=1e-300 if L > 1 else 1e-15)
+    # the same target again gives the same bits (fixed summation order)
+    ctx.corr_set_target(tgt, 0.5, 8.0)
+    assert np.array_equal(ctx.corr_target_stats(), got)
+
+
 @pytest.mark.parametrize("weight", [0.0, 1.0, 0.25])
 def test_dense_parity_weights(ctx, weight):
     L, ts = 80, 11

@@ -22,7 +22,13 @@ class _Hip:
         self.lib.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
         self.lib.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         self.lib.hipFree.argtypes = [C.c_void_p]
+        self.lib.hipMemGetInfo.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         self.bufs = []
+
+    def free_bytes(self):
+        free, total = self.C.c_size_t(), self.C.c_size_t()
+        assert self.lib.hipMemGetInfo(self.C.byref(free), self.C.byref(total)) == 0
+        return free.value
 
     def alloc(self, nbytes):
         p = self.C.c_void_p()
@@ -90,8 +96,11 @@ def test_rescore_noalloc_equals_rescore(ctx):
             hip.upload(rec_b, h)
             hip.upload(cnt_b, np.array([n], np.int64))
             ctx.corr_rescore_device(rec_a, cap, cnt_a)
+            ctx.synchronize()
+            free_before = hip.free_bytes()
             ctx.corr_rescore_device_noalloc(rec_b, cap, cnt_b)
             ctx.synchronize()
+            assert hip.free_bytes() == free_before  # the call took no device memory
             a = hip.download(rec_a, np.zeros((cap, 4), np.int32))[:n]
             b = hip.download(rec_b, np.zeros((cap, 4), np.int32))[:n]
             assert n > 20 and np.array_equal(a, b)  # same kernels, same order of operations: identical bits
@@ -104,6 +113,9 @@ def test_rescore_noalloc_equals_rescore(ctx):
         rec, cnt = _device_list(hip, 4)
         with pytest.raises(S.NativeError, match="scratch") as e:
             ctx.corr_rescore_device_noalloc(rec, 1 << 20, cnt)
+        assert e.value.code == N.SGZ_E_ARG
+        with pytest.raises(S.NativeError, match="scratch") as e:  # (a size whose byte count does not fit 64 bits)
+            ctx.corr_rescore_device_noalloc(rec, (1 << 62) + 5, cnt)
         assert e.value.code == N.SGZ_E_ARG
     finally:
         ctx.synchronize()
