@@ -583,14 +583,6 @@ __global__ __launch_bounds__(256) void window_static_kernel(const FileDesc *__re
     }
 }
 
-// New target, same layout: the NaN marks the matrix-core kernel left (bit 2) belong to the previous target; the
-// range marks of the image (bit 1) stay.
-__global__ void clear_nan_flags_kernel(int *__restrict__ hflags, int n)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) hflags[i] &= 1;
-}
-
 // ---------------------------------------------------------------------------
 // tile_scan_kernel: per file and moment, turns the tile totals into exclusive
 // tile bases (one wave per moment).
@@ -1367,16 +1359,20 @@ __global__ __launch_bounds__(256) void rescore_final_kernel(const FileDesc *__re
 // statistics of the loudness row and of the other rows (MathUtil.stat, :29-62: fp64 sums), the centred
 // target in fp64 and rounded to fp32, and what the screening bounds need of the fp32 values.
 //
-// One workgroup.  The raw frames are read from where the host left them (pinned host memory: 145 KB for a
-// 30 s target, cheaper to read in place than to copy first).  Every sum is taken in a fixed order that
-// depends on nothing but the target's shape -- element e of the interleaved frames belongs to thread
-// e mod 1024, a thread adds its elements in index order, the 64 lanes of a wave are folded by a butterfly,
-// the 16 waves added in wave order -- so a target always gets the same statistics; they differ from a
-// sequential summation in the reference's order by a few units of the last place of the fp64 sums.
+// Two kernels, one per pass of MathUtil.stat, each over all elements with four elements per thread (all loads in
+// flight at once; the first kernel reads the raw frames from where the host left them, pinned host memory: 145 KB
+// for a 30 s target, cheaper to read in place than to copy first).  Every sum is taken in a fixed order that
+// depends on nothing but the target's shape -- a thread adds its four elements in index order, the 64 lanes of a
+// wave are folded by a butterfly, the 4 waves of a workgroup added in wave order, and the workgroup that finishes
+// last adds the workgroups' sums in workgroup order -- so a target always gets the same statistics; they differ
+// from a sequential summation in the reference's order by a few units of the last place of the fp64 sums.
 // The scalars go to pinned host memory, followed by a sequence word the host polls: the host needs them as
 // kernel arguments of everything that follows.
 // ---------------------------------------------------------------------------
-constexpr int kTpThreads = 1024;
+constexpr int kTpThreads = 256;
+constexpr int kTpPer = 4;                        // elements per thread
+constexpr int kTpTile = kTpThreads * kTpPer;     // elements per workgroup
+constexpr int kTpSums = 10;                      // doubles a workgroup of the second kernel hands on
 
 struct TargetReport {
     double sum1[2];   // sums of the normalised values: loudness row, other rows
@@ -1389,92 +1385,171 @@ struct TargetReport {
     unsigned long long seq;      // written last
 };
 
+// Device-side state of the two kernels: [0..1] the sums of the first pass, [2..3] the means, then the workgroups'
+// partial sums (kTpSums doubles each); `counter` counts the workgroups that are done (reset by the last one).
 template <int K>
-__device__ __forceinline__ void tp_reduce(double (&v)[K], double *red /* 16 * K doubles */)
+__device__ __forceinline__ void tp_wg_sums(double (&v)[K], double *red /* 4 * K doubles */, double *__restrict__ out)
 {
 #pragma unroll
     for (int j = 0; j < K; j++)
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) v[j] += __shfl_xor(v[j], off, 64);
-    __syncthreads();  // (the previous round's readers are done with `red`)
     if ((threadIdx.x & 63) == 0)
 #pragma unroll
         for (int j = 0; j < K; j++) red[(threadIdx.x >> 6) * K + j] = v[j];
     __syncthreads();
-#pragma unroll
-    for (int j = 0; j < K; j++) {
+    if (threadIdx.x < K) {
         double s = 0.0;
-        for (int w = 0; w < kTpThreads / 64; w++) s += red[w * K + j];
-        v[j] = s;
+        for (int w = 0; w < kTpThreads / 64; w++) s += red[w * K + threadIdx.x];
+        out[threadIdx.x] = s;
     }
 }
 
-__global__ __launch_bounds__(kTpThreads) void target_prep_kernel(const float *__restrict__ frames, int L, int numCh,
-                                                                 int Lpad, const float *__restrict__ normTab,
-                                                                 int normEnabled, float *__restrict__ tnorm,
-                                                                 double *__restrict__ aprime,
-                                                                 float *__restrict__ aprimeF, TargetReport *report,
-                                                                 unsigned long long seq)
+// Column j < K of the workgroups' sums, added in workgroup order; valid in thread j.  The rows are fetched by the
+// whole workgroup, kTpRows at a time (a thread per column reading them one after the other from memory would wait
+// for every one of them in turn).
+constexpr int kTpRows = kTpThreads / kTpSums;
+template <int K>
+__device__ __forceinline__ double tp_final_sum(const double *__restrict__ state, double *rows /* kTpRows * kTpSums */)
 {
-    __shared__ double red[(kTpThreads / 64) * 7];
-    const int tid = threadIdx.x;
-    const long long n = (long long)L * numCh;
-    float *tb = tnorm, *tfm = tnorm + n;  // channel-major [numCh][L], then frame-major [L][numCh]
+    double s = 0.0;
+    const int G = (int)gridDim.x;
+    for (int w0 = 0; w0 < G; w0 += kTpRows) {
+        const int nrows = min(kTpRows, G - w0);
+        if ((int)threadIdx.x < nrows * kTpSums) rows[threadIdx.x] = state[4 + (size_t)w0 * kTpSums + threadIdx.x];
+        __syncthreads();
+        if ((int)threadIdx.x < K)
+            for (int r = 0; r < nrows; r++) s += rows[r * kTpSums + threadIdx.x];
+        __syncthreads();
+    }
+    return s;
+}
+
+// True in every thread of the one workgroup that finishes last (whose reads then see all the others' sums).
+__device__ __forceinline__ bool tp_last_workgroup(unsigned int *counter)
+{
+    __shared__ int last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) last = atomicAdd(counter, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (last) __threadfence();
+    return last != 0;
+}
+
+__global__ __launch_bounds__(kTpThreads) void target_norm_kernel(const float *__restrict__ frames, int L, int numCh,
+                                                                 const float *__restrict__ normTab, int normEnabled,
+                                                                 float *__restrict__ tnorm, double *__restrict__ state,
+                                                                 unsigned int *__restrict__ counter)
+{
+    __shared__ double red[(kTpThreads / 64) * 2];
+    // elements in the order of the interleaved frames (e = frame * numCh + channel): reads and writes of a wave are
+    // contiguous
+    const unsigned int n = (unsigned int)L * (unsigned int)numCh;
+    const unsigned int e0 = blockIdx.x * kTpTile + threadIdx.x;
+    float raw[kTpPer];
+#pragma unroll
+    for (int k = 0; k < kTpPer; k++) {
+        const unsigned int e = e0 + k * kTpThreads;
+        raw[k] = e < n ? frames[e] : 0.0f;
+    }
     double s1[2] = {0.0, 0.0};
-    for (long long e = tid; e < n; e += kTpThreads) {
-        const int i = (int)(e / numCh), c = (int)(e - (long long)i * numCh);
-        float v = frames[e];
-        if (normEnabled) v = (v - normTab[c]) / normTab[SGZ_MAX_CHANNELS + c];
-        tb[(size_t)c * L + i] = v;
-        tfm[e] = v;
-        s1[c > 0] += (double)v;
+#pragma unroll
+    for (int k = 0; k < kTpPer; k++) {
+        const unsigned int e = e0 + k * kTpThreads;
+        if (e < n) {
+            const unsigned int c = e % (unsigned int)numCh;
+            float v = raw[k];
+            if (normEnabled) v = (v - normTab[c]) / normTab[SGZ_MAX_CHANNELS + c];
+            tnorm[e] = v;
+            s1[c > 0] += (double)v;
+        }
     }
-    tp_reduce<2>(s1, red);
-    const double nT = (double)L, nS = (double)L * (double)(numCh - 1);
-    const double meanT = s1[0] / nT, meanS = s1[1] / nS;
-    double acc[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // sum2 T/S, fsq T/S, fsq1, csum T/S
-    double cs[2] = {0.0, 0.0}, fs[2] = {0.0, 0.0};
-    int inRange = 1;
-    for (long long e = tid; e < n; e += kTpThreads) {
-        const int i = (int)(e / numCh), c = (int)(e - (long long)i * numCh);
-        const int g = c > 0;
-        const double v = (double)tfm[e] - (g ? meanS : meanT);  // (this thread wrote tfm[e] itself)
-        aprime[(size_t)c * Lpad + i] = v;
-        acc[g] += v * v;
-        cs[g] += v;
-        inRange &= fabs(v) <= 60000.0;  // (false for NaN as well)
-        const float vf = (float)v;
-        aprimeF[(size_t)c * Lpad + i] = vf;
-        const double w = (double)vf;
-        fs[g] += w;
-        acc[2 + g] += w * w;
-        if (c == 1) acc[4] += w * w;
+    tp_wg_sums<2>(s1, red, state + 4 + (size_t)blockIdx.x * kTpSums);
+    if (!tp_last_workgroup(counter)) return;
+    __shared__ double rows[kTpRows * kTpSums];
+    const double s = tp_final_sum<2>(state, rows);
+    if (threadIdx.x < 2) {
+        state[threadIdx.x] = s;
+        const double cnt = threadIdx.x == 0 ? (double)L : (double)L * (double)(numCh - 1);
+        state[2 + threadIdx.x] = s / cnt;  // MathUtil.stat: mean = sum / n
     }
-    acc[5] = cs[0];
-    acc[6] = cs[1];
-    // zero padding behind the target's last frame
-    const int padLen = Lpad - L;
-    for (long long e = tid; e < (long long)padLen * numCh; e += kTpThreads) {
-        const int c = (int)(e / padLen), i = L + (int)(e - (long long)c * padLen);
-        aprime[(size_t)c * Lpad + i] = 0.0;
-        aprimeF[(size_t)c * Lpad + i] = 0.0f;
+    if (threadIdx.x == 0) *counter = 0u;
+}
+
+__global__ __launch_bounds__(kTpThreads) void target_centre_kernel(int L, int numCh, int Lpad,
+                                                                   const float *__restrict__ tnorm,
+                                                                   double *__restrict__ aprime,
+                                                                   float *__restrict__ aprimeF,
+                                                                   double *__restrict__ state,
+                                                                   unsigned int *__restrict__ counter,
+                                                                   int *__restrict__ hflags, int numFiles,
+                                                                   TargetReport *report, unsigned long long seq)
+{
+    __shared__ double red[(kTpThreads / 64) * kTpSums];
+    // elements in the order of the centred copies (q = channel * Lpad + frame, the padding included): the writes of
+    // a wave are contiguous, the reads gather from the 145 KB the kernel before left in the cache
+    const unsigned int n = (unsigned int)Lpad * (unsigned int)numCh;
+    const double meanT = state[2], meanS = state[3];
+    const unsigned int q0 = blockIdx.x * kTpTile + threadIdx.x;
+    float x[kTpPer];
+#pragma unroll
+    for (int k = 0; k < kTpPer; k++) {
+        const unsigned int q = q0 + k * kTpThreads;
+        const unsigned int c = q / (unsigned int)Lpad, i = q - c * (unsigned int)Lpad;
+        x[k] = q < n && i < (unsigned int)L ? tnorm[i * (unsigned int)numCh + c] : 0.0f;
     }
-    tp_reduce<7>(acc, red);
-    tp_reduce<2>(fs, red);
-    const int allIn = __syncthreads_and(inRange);
-    if (tid == 0) {
-        report->sum1[0] = s1[0];
-        report->sum1[1] = s1[1];
-        report->sum2[0] = acc[0];
-        report->sum2[1] = acc[1];
-        report->fsq[0] = acc[2];
-        report->fsq[1] = acc[3];
-        report->fsq1 = acc[4];
-        report->csum[0] = acc[5];
-        report->csum[1] = acc[6];
-        report->fsum[0] = fs[0];
-        report->fsum[1] = fs[1];
-        report->inRange = allIn ? 1ull : 0ull;
+    // sum2 T/S, csum T/S, fsum T/S, fsq T/S, fsq1, count of values outside the half-precision range
+    double acc[kTpSums] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < kTpPer; k++) {
+        const unsigned int q = q0 + k * kTpThreads;
+        if (q < n) {
+            const unsigned int c = q / (unsigned int)Lpad, i = q - c * (unsigned int)Lpad;
+            if (i < (unsigned int)L) {
+                const int g = c > 0;
+                const double v = (double)x[k] - (g ? meanS : meanT);  // ca(i) + aAdd, impl/MathUtil.scala:190
+                aprime[q] = v;
+                acc[g] += v * v;
+                acc[2 + g] += v;
+                if (!(fabs(v) <= 60000.0)) acc[9] += 1.0;  // (NaN counts as outside)
+                const float vf = (float)v;
+                aprimeF[q] = vf;
+                const double w = (double)vf;
+                acc[4 + g] += w;
+                acc[6 + g] += w * w;
+                if (c == 1) acc[8] += w * w;
+            } else {  // zero padding behind the target's last frame
+                aprime[q] = 0.0;
+                aprimeF[q] = 0.0f;
+            }
+        }
+    }
+    // the marks the screening kernels left per file for the previous target (bit 2; the range marks of the
+    // database's image, bit 1, stay)
+    for (long long f = (long long)blockIdx.x * kTpThreads + threadIdx.x; f < numFiles; f += (long long)gridDim.x * kTpThreads)
+        hflags[f] &= 1;
+    tp_wg_sums<kTpSums>(acc, red, state + 4 + (size_t)blockIdx.x * kTpSums);
+    if (!tp_last_workgroup(counter)) return;
+    __shared__ double fin[kTpSums];
+    __shared__ double rows[kTpRows * kTpSums];
+    const double total = tp_final_sum<kTpSums>(state, rows);
+    if (threadIdx.x < kTpSums) fin[threadIdx.x] = total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        *counter = 0u;
+        report->sum1[0] = state[0];
+        report->sum1[1] = state[1];
+        report->sum2[0] = fin[0];
+        report->sum2[1] = fin[1];
+        report->csum[0] = fin[2];
+        report->csum[1] = fin[3];
+        report->fsum[0] = fin[4];
+        report->fsum[1] = fin[5];
+        report->fsq[0] = fin[6];
+        report->fsq[1] = fin[7];
+        report->fsq1 = fin[8];
+        report->inRange = fin[9] == 0.0 ? 1ull : 0ull;
         __threadfence_system();
         __hip_atomic_store(&report->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -1977,6 +2052,7 @@ int sgz_corr_set_target(sgz_context *ctx, const float *frames, int num_frames, f
     if (!ctx) return SGZ_E_ARG;
     if (ctx->numCh == 0) return ctx->fail(SGZ_E_STATE, "sgz_db_reset has not been called");
     if (!frames || num_frames < 1) return ctx->fail(SGZ_E_ARG, "target needs at least one frame");
+    if (((long long)num_frames + 2 * kR) * ctx->numCh >= (1ll << 31)) return ctx->fail(SGZ_E_ARG, "target too long");
     SGZ_HIP(ctx, hipSetDevice(ctx->device));
     const int numCh = ctx->numCh, L = num_frames;
     // The host hands over the raw frames and nothing else: they are written into a pinned buffer that
@@ -2010,14 +2086,32 @@ int sgz_corr_set_target(sgz_context *ctx, const float *frames, int num_frames, f
     TargetReport *rep = reinterpret_cast<TargetReport *>(ctx->h_tgt_stage + offRep);
     int rc;
     if ((rc = ensure(ctx, ctx->d_aprime, ctx->aprime_cap, nAp))) return rc;
-    if ((rc = ensure(ctx, ctx->d_tnorm, ctx->tnorm_cap, 2 * nTb))) return rc;
+    if ((rc = ensure(ctx, ctx->d_tnorm, ctx->tnorm_cap, nTb))) return rc;
     if ((rc = ensure(ctx, ctx->d_aprime_f, ctx->aprime_f_cap, nAp))) return rc;
     const unsigned long long seq = ++ctx->tgt_seq;
     // (the report may sit at another offset than last time: the word the host polls must not hold this number yet)
     __atomic_store_n(&rep->seq, 0ull, __ATOMIC_RELEASE);
-    hipLaunchKernelGGL(target_prep_kernel, dim3(1), dim3(kTpThreads), 0, ctx->stream,
-                       reinterpret_cast<const float *>(ctx->h_tgt_stage + offRaw), L, numCh, (int)Lpad, ctx->d_normtab,
-                       ctx->norm.enabled, ctx->d_tnorm, ctx->d_aprime, ctx->d_aprime_f, rep, seq);
+    // (the second kernel runs over the padded copies: the larger grid sizes the buffer of partial sums)
+    const int tpGridA = (int)((nTb + kTpTile - 1) / kTpTile), tpGrid = (int)((nAp + kTpTile - 1) / kTpTile);
+    {
+        const size_t need = (size_t)4 + (size_t)tpGrid * kTpSums + 1;
+        const bool fresh = !ctx->d_tgt_state || need > ctx->tgt_state_cap;  // (a new buffer may get the old address)
+        if ((rc = ensure(ctx, ctx->d_tgt_state, ctx->tgt_state_cap, need))) return rc;
+        if (fresh) {  // the last double of the buffer is the workgroup counter: starts at zero
+            ctx->tgt_counter_off = ctx->tgt_state_cap - 1;
+            SGZ_HIP(ctx, hipMemsetAsync(ctx->d_tgt_state + ctx->tgt_counter_off, 0, sizeof(double), ctx->stream));
+        }
+    }
+    unsigned int *tpCounter = reinterpret_cast<unsigned int *>(ctx->d_tgt_state + ctx->tgt_counter_off);
+    // the marks of the previous target's screening runs go with it (a layout that is rebuilt clears all marks itself)
+    const int nfMarks = ctx->d_hflags && ctx->hflags_cap >= ctx->files.size() && !ctx->layout_dirty ? (int)ctx->files.size() : 0;
+    hipLaunchKernelGGL(target_norm_kernel, dim3(tpGridA), dim3(kTpThreads), 0, ctx->stream,
+                       reinterpret_cast<const float *>(ctx->h_tgt_stage + offRaw), L, numCh, ctx->d_normtab,
+                       ctx->norm.enabled, ctx->d_tnorm, ctx->d_tgt_state, tpCounter);
+    SGZ_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(target_centre_kernel, dim3(tpGrid), dim3(kTpThreads), 0, ctx->stream, L, numCh, (int)Lpad,
+                       ctx->d_tnorm, ctx->d_aprime, ctx->d_aprime_f, ctx->d_tgt_state, tpCounter, ctx->d_hflags, nfMarks,
+                       rep, seq);
     SGZ_HIP(ctx, hipGetLastError());
     CorrParams &cp = ctx->cp;
     const int oldL = ctx->have_target ? cp.L : -1;
@@ -2089,13 +2183,6 @@ int sgz_corr_set_target(sgz_context *ctx, const float *frames, int num_frames, f
     SGZ_HIP(ctx, hipStreamWaitEvent(ctx->screen_stream, ctx->tgt_event, 0));
     if (oldL != L || hadHalf != (ctx->hg.S2 > 0)) ctx->layout_dirty = true;
     if (early && !ctx->layout_dirty) fft_target_ready(ctx);
-    // the NaN marks of half-precision runs belong to the previous target
-    // (a pending layout rebuild clears all marks itself, for the files of the new layout)
-    if (ctx->d_hflags && !ctx->layout_dirty && !ctx->files.empty()) {
-        const int n = (int)ctx->files.size();
-        hipLaunchKernelGGL(clear_nan_flags_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_hflags, n);
-        SGZ_HIP(ctx, hipGetLastError());
-    }
     return SGZ_OK;
 }
 
@@ -2622,7 +2709,7 @@ static int rescore_device_impl(sgz_context *ctx, sgz_candidate *device_cands, in
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
     const int grid = (int)std::min<long long>((long long)capacity * rg.slices, 8ll * cus);
-    const float *tframes = ctx->d_tnorm + perWindow;
+    const float *tframes = ctx->d_tnorm;
     hipLaunchKernelGGL(rescore_pass_kernel, dim3(grid), dim3(kRsThreads), 0, ctx->stream, ctx->d_files, tframes,
                        normtab, ctx->norm.enabled, ctx->cp, rg, ctx->aMeanT, ctx->aMeanS, device_cands, device_count,
                        (long long)capacity, (int)truncated_ok, part);

@@ -174,10 +174,13 @@ struct sgz_context {
     size_t tgt_stage_cap = 0;              // asynchronously (the stream is idle when the next target overwrites it)
     double *d_aprime = nullptr;  // [numCh][S * kR] centred target, fp64
     size_t aprime_cap = 0;
-    float *d_tnorm = nullptr;     // [numCh][L] normalised target, fp32 (exact re-scoring)
+    float *d_tnorm = nullptr;     // [L][numCh] normalised target, fp32 (exact re-scoring)
     size_t tnorm_cap = 0;
     double aMeanT = 0.0, aMeanS = 0.0;
-    unsigned long long tgt_seq = 0;          // sequence number of the latest report of target_prep_kernel
+    unsigned long long tgt_seq = 0;          // sequence number of the latest report of the target preparation
+    double *d_tgt_state = nullptr;           // its device-side sums (see target_norm_kernel); the last element holds
+    size_t tgt_state_cap = 0;                // the counter of finished workgroups
+    size_t tgt_counter_off = 0;
     unsigned long long tgt_serial = 0;       // targets set so far
     float *d_aprime_f = nullptr;  // the same, rounded to fp32 (screening path)
     size_t aprime_f_cap = 0;

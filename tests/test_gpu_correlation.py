@@ -554,9 +554,11 @@ def _run_ranks(mode, world, backend, extra=()):
     procs = [subprocess.Popen([sys.executable, script, str(port), mode, str(r), str(world), backend, *map(str, extra)],
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
     outs = []
-    for pr in procs:
-        out, err = pr.communicate(timeout=110)
-        assert pr.returncode == 0, err[-2000:]
+    done = [pr.communicate(timeout=110) for pr in procs]
+    # (a rank that dies takes the others down with "connection closed": show every rank's last words)
+    assert all(pr.returncode == 0 for pr in procs), "\n".join(
+        f"--- rank {r} (exit {pr.returncode}) ---\n{err[-1500:]}" for r, (pr, (_, err)) in enumerate(zip(procs, done)))
+    for out, err in done:
         outs.append(json.loads(out.strip().splitlines()[-1]))
     return outs
 
