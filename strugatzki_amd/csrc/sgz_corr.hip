@@ -679,6 +679,8 @@ struct SuspectList {
     unsigned long long *count;  // zero when the kernel starts
     long long capacity;
     float fill;                 // the similarity written for such a window (exact run: NaN until re-evaluated)
+    const int *wholeFile;       // per file (or null): != 0 = every window of the file is re-evaluated from its
+                                // frames anyway (it holds a value that is not a number): not listed here
 };
 
 // T = double: the exact path.  T = float: the screening path -- fp32 products and
@@ -843,7 +845,7 @@ __global__ __launch_bounds__(kThreads, 4) void corr_kernel(const FileDesc *__res
                 // statistics too close to the rounding of the prefix sums: the window is listed for a two-pass
                 // evaluation from its frames (exact run) or made a certain candidate (screening run)
                 sim = sus.fill;
-                if (sus.list) {
+                if (sus.list && !(sus.wholeFile && sus.wholeFile[td.file])) {
                     const unsigned long long slot = atomicAdd(sus.count, 1ull);
                     if ((long long)slot < sus.capacity) {
                         sgz_candidate c;
@@ -858,6 +860,47 @@ __global__ __launch_bounds__(kThreads, 4) void corr_kernel(const FileDesc *__res
             simOut[fd.win_off + o] = sim;
             boostOut[fd.win_off + o] = boost;
         }
+    }
+}
+
+// Per file: does it hold a value that is not a finite number once normalised?  MathUtil.stat and correlate
+// (impl/MathUtil.scala:29-62, 177-196) run over the frames of one window, so such a value spoils exactly the
+// windows that contain it; window statistics from prefix sums would spoil every later window of the file as well.
+// The exact run therefore evaluates every window of such a file from its frames (list_windows_kernel and the
+// re-scoring kernels).  One workgroup per file.
+__global__ __launch_bounds__(256) void nonfinite_scan_kernel(const FileDesc *__restrict__ files,
+                                                             const float *__restrict__ normTab, int normEnabled,
+                                                             int numCh, int *__restrict__ flags)
+{
+    const FileDesc fd = files[blockIdx.x];
+    const long long n = fd.frames * numCh;
+    int bad = 0;
+    for (long long e = threadIdx.x; e < n; e += 256) {
+        float v = fd.raw[e];
+        if (normEnabled) {
+            const int c = (int)(e % numCh);
+            v = (v - normTab[c]) / normTab[SGZ_MAX_CHANNELS + c];
+        }
+        bad |= !(fabsf(v) <= 3.4028234e38f);
+    }
+    bad = __syncthreads_or(bad);
+    if (threadIdx.x == 0) flags[blockIdx.x] = bad ? 1 : 0;
+}
+
+// Windows [o0, o0 + n) of one file as a candidate list (for the re-scoring kernels).
+__global__ __launch_bounds__(256) void list_windows_kernel(int file, long long o0, long long n,
+                                                           sgz_candidate *__restrict__ list,
+                                                           unsigned long long *__restrict__ count)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) *count = (unsigned long long)n;
+    if (i < n) {
+        sgz_candidate c;
+        c.file = file;
+        c.offset = (int)(o0 + i);
+        c.sim = NAN;
+        c.boost = NAN;
+        list[i] = c;
     }
 }
 
@@ -1171,8 +1214,10 @@ __device__ __forceinline__ void window_shift(const float *__restrict__ first, co
         vT = (vT - normTab[0]) / normTab[SGZ_MAX_CHANNELS];
         vS = (vS - normTab[1]) / normTab[SGZ_MAX_CHANNELS + 1];
     }
-    m0T = (double)vT;
-    m0S = (double)vS;
+    // (a first value that is not a finite number is no shift to take: with 0 the sums come out as those of the
+    // reference's own passes do -- infinite or NaN -- and with them boost, gate and similarity)
+    m0T = fabsf(vT) <= 3.4028234e38f ? (double)vT : 0.0;
+    m0S = fabsf(vS) <= 3.4028234e38f ? (double)vS : 0.0;
 }
 
 __global__ __launch_bounds__(kRsThreads) void rescore_pass_kernel(
@@ -1755,6 +1800,16 @@ int build_layout(sgz_context *ctx)
     if (!ctx->h_ptiles.empty())
         SGZ_HIP(ctx, hipMemcpyAsync(ctx->d_ptiles, ctx->h_ptiles.data(), sizeof(PrepTile) * ctx->h_ptiles.size(),
                                     hipMemcpyHostToDevice, ctx->stream));
+    // which files hold a value that is not a finite number (under the norms in force)
+    ctx->h_nonfinite.assign((size_t)nf, 0);
+    if (nf) {
+        if ((rc = ensure(ctx, ctx->d_nonfinite, ctx->nonfinite_cap, (size_t)nf))) return rc;
+        hipLaunchKernelGGL(nonfinite_scan_kernel, dim3(nf), dim3(256), 0, ctx->stream, ctx->d_files, ctx->d_normtab,
+                           ctx->norm.enabled, ctx->numCh, ctx->d_nonfinite);
+        SGZ_HIP(ctx, hipGetLastError());
+        SGZ_HIP(ctx, hipMemcpyAsync(ctx->h_nonfinite.data(), ctx->d_nonfinite, sizeof(int) * (size_t)nf,
+                                    hipMemcpyDeviceToHost, ctx->stream));
+    }
     SGZ_HIP(ctx, hipStreamSynchronize(ctx->stream));  // host vectors may be rebuilt afterwards
     for (auto &r : ctx->runs) ctx->event_pool.push_back(r.done);
     ctx->runs.clear();
@@ -2328,13 +2383,14 @@ static int corr_run_impl(sgz_context *ctx, int file_begin, int file_end, int mod
         return rc;
     const size_t corrLds = exact ? corr_lds_bytes<double>() : corr_lds_bytes<float>();
     // windows whose prefix-sum statistics cannot be trusted (constant stretches): see SuspectList
-    SuspectList suspects{nullptr, nullptr, 0, INFINITY};
+    SuspectList suspects{nullptr, nullptr, 0, INFINITY, nullptr};
     if (exact) {
         if ((rc = ensure(ctx, ctx->d_suspect, ctx->suspect_cap, (size_t)kSuspectCap + 1))) return rc;
         suspects.list = ctx->d_suspect + 1;
         suspects.count = reinterpret_cast<unsigned long long *>(ctx->d_suspect);
         suspects.capacity = kSuspectCap;
         suspects.fill = NAN;
+        suspects.wholeFile = ctx->d_nonfinite;
         SGZ_HIP(ctx, hipMemsetAsync(ctx->d_suspect, 0, sizeof(sgz_candidate), stream));
     }
     // kernel time for sgz_corr_last_kernel_ms: the matrix-core kernel carries the two events in its own
@@ -2364,6 +2420,21 @@ static int corr_run_impl(sgz_context *ctx, int file_begin, int file_end, int mod
         hipLaunchKernelGGL(scatter_kernel, dim3(64), dim3(256), 0, stream, ctx->d_files, suspects.list, suspects.count,
                            (long long)kSuspectCap, ctx->d_sim, ctx->d_boost);
         SGZ_HIP(ctx, hipGetLastError());
+        // files that hold a value that is not a number: every window from its frames, a list's worth at a time
+        for (int f = file_begin; f < file_end; f++) {
+            if (f >= (int)ctx->h_nonfinite.size() || !ctx->h_nonfinite[(size_t)f]) continue;
+            const long long nw = ctx->h_files[(size_t)f].num_windows;
+            for (long long o0 = 0; o0 < nw; o0 += kSuspectCap) {
+                const long long n = std::min<long long>(kSuspectCap, nw - o0);
+                hipLaunchKernelGGL(list_windows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, f, o0, n,
+                                   suspects.list, suspects.count);
+                SGZ_HIP(ctx, hipGetLastError());
+                if ((rc = rescore_device_impl(ctx, suspects.list, kSuspectCap, suspects.count, HostReport{}, true))) return rc;
+                hipLaunchKernelGGL(scatter_kernel, dim3(64), dim3(256), 0, stream, ctx->d_files, suspects.list,
+                                   suspects.count, (long long)kSuspectCap, ctx->d_sim, ctx->d_boost);
+                SGZ_HIP(ctx, hipGetLastError());
+            }
+        }
     }
     if (timed) {
         ctx->ev_valid = true;

@@ -215,6 +215,9 @@ struct sgz_context {
     size_t planar_f_cap = 0;
     uint16_t *d_planar_h = nullptr;          // half-precision image [numCh][16 * M], frames in natural order
     size_t planar_h_cap = 0;
+    int *d_nonfinite = nullptr;              // per file: != 0 = the file holds a value that is not a finite number
+    size_t nonfinite_cap = 0;                // once normalised (scanned when the layout is built; host copy beside it)
+    std::vector<int> h_nonfinite;
     int *d_hflags = nullptr;                 // per file: 1 = a value left the half-precision range
     size_t hflags_cap = 0;
     double *d_prefix = nullptr;

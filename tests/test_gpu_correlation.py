@@ -108,6 +108,40 @@ def test_dense_parity_without_normalisation(ctx):
     _check_dense(ctx, db, tgt, ts, L, None)
 
 
+@pytest.mark.parametrize("weight", [0.5, 0.0, 1.0])
+@pytest.mark.parametrize("normalize", [True, False])
+def test_dense_parity_with_values_that_are_not_numbers(ctx, weight, normalize):
+    """MathUtil.stat / correlate / avg run over one window's frames (impl/MathUtil.scala:29-62, 109-118, 177-196): a
+    NaN or an infinity spoils exactly the windows that contain it, and what comes of it -- a NaN similarity, or 0
+    where the boost gate sees a NaN -- depends on the channel group, the weight and the sign.  Every window against
+    the oracle, NaN for NaN."""
+    L, ts, frames = 90, 7, 1300
+    db = synth_db(6, frames, make_plants(2, L, 6, frames, ts))
+    db[0][500, 3] = np.nan           # an MFCC channel
+    db[1][0, 0] = np.nan             # the loudness channel, first frame of the file
+    db[1][frames - 1, 5] = np.inf    # last frame
+    db[2][400, 0] = np.inf           # loudness +inf: the boost is 0, the gate open
+    db[2][700, 0] = -np.inf          # loudness -inf: the boost is NaN, the gate shut
+    db[3][640, 9] = -np.inf
+    db[3][650, 0] = np.nan
+    db[4][100:130, 1] = np.nan       # a run of them (file 5 holds none)
+    tgt = synth_target(ts, L)
+    norms = norms_default() if normalize else None
+    cfg = corr_config(ts, L, weight=weight, normalize=normalize, num_matches=5)
+    with np.errstate(all="ignore"):
+        _, sims, boosts = O.correlation_run(cfg, tgt, norms, db)
+    _load(ctx, db, norms)
+    ctx.corr_set_target(tgt[ts:ts + L], weight, 8.0)
+    got = _gpu_dense(ctx, len(db))
+    for f, (gs, gb) in enumerate(got):
+        assert np.array_equal(np.isnan(gs), np.isnan(sims[f])), f"file {f}: NaN similarities in other windows"
+        np.testing.assert_allclose(gs, sims[f], rtol=0, atol=TOL)
+        np.testing.assert_allclose(gb, boosts[f], rtol=2e-6, atol=0)
+    if weight == 0.5:  # (the windows around a value are spoilt, the rest of the file is not)
+        assert np.isnan(sims[0][500 - L + 1:501]).all() and not np.isnan(sims[0][:500 - L + 1]).any() \
+            and not np.isnan(sims[0][501:]).any()
+
+
 def test_max_boost_gate_gives_zero_sim(ctx):
     """A quiet copy needs a boost above maxBoost: sim must be exactly 0f (impl/FeatureCorrelationImpl.scala:209)."""
     L, ts, frames = 64, 9, 600

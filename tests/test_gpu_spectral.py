@@ -441,11 +441,12 @@ def test_sixteen_bit_spectra_widen_the_bounds_only_slightly(ctx, monkeypatch):
 @pytest.mark.parametrize("value", [np.nan, np.inf, -np.inf])
 @pytest.mark.parametrize("num_per_file", [1, 2])
 def test_values_that_are_not_numbers(spectral, value, num_per_file):
-    """A NaN or an infinity among a file's frames.  Feature files do not hold such values (the extraction replaces
-    them, impl/NonRealtimeProcessor.scala:178-190), so this is about the library agreeing with itself: the
-    screened search must return what its exact search (every window in fp64, no screening) returns, whatever form
-    the spectra are kept in -- a band of 16-bit spectra with such a component gets a NaN scale, the block's bounds
-    come out as NaN and the file goes to the exact path."""
+    """A NaN or an infinity among a file's frames (feature files do not normally hold such values: the extraction
+    replaces NaNs, impl/NonRealtimeProcessor.scala:178-190).  The reference's statistics run over one window's frames
+    (impl/MathUtil.scala:29-62), so only the windows that contain the value are spoilt: the screened search, the
+    exact search and the oracle's loop must return the same matches, whatever form the spectra are kept in -- a band
+    of 16-bit spectra with such a component gets a NaN scale, the block's bounds come out as NaN and the file goes
+    to the exact path, which evaluates every window of such a file from its frames."""
     import strugatzki_amd as S
     ctx = spectral
     L, ts, nf, frames = 300, 12, 4, 5000
@@ -458,8 +459,12 @@ def test_values_that_are_not_numbers(spectral, value, num_per_file):
     ctx.corr_set_target(tgt[ts:ts + L], 0.5, 8.0)
     got = S.search(ctx, S.SearchParams(4, num_per_file, 0, STEP))
     assert ctx.screen_kernel_in_use == "spectral"
-    want = S.search(ctx, S.SearchParams(4, num_per_file, 0, STEP, screen=False))
+    exact = S.search(ctx, S.SearchParams(4, num_per_file, 0, STEP, screen=False))
+    with np.errstate(all="ignore"):
+        want, _, _ = O.correlation_run(corr_config(ts, L, num_matches=4, num_per_file=num_per_file), tgt,
+                                       norms_default(), db, dense=False)
     assert len(want) == 4
-    assert [(g.file, g.start, g.stop) for g in got] == [(w.file, w.start, w.stop) for w in want]
-    for g, w in zip(got, want):
-        assert abs(g.sim - w.sim) <= 1.2e-7 or (np.isnan(g.sim) and np.isnan(w.sim))
+    for res in (got, exact):
+        assert [(g.file, g.start, g.stop) for g in res] == [(w.file, w.start, w.stop) for w in want]
+        for g, w in zip(res, want):
+            assert abs(g.sim - w.sim) <= 1.2e-7 or (np.isnan(g.sim) and np.isnan(w.sim))
