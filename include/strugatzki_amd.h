@@ -513,6 +513,22 @@ SGZ_API int sgz_selfsim_run(sgz_context *ctx, const float *frames1, int64_t num_
                     float temporal_weight, int colors, float color_warp, float color_ceil,
                     int color_inv, float *sim_out, int32_t *img_out);
 
+/* Rows [x_begin, x_end) of the same matrix: sim_out receives (x_end - x_begin) * img_ext
+ * floats, [x - x_begin][y].  For callers that apply a colour scheme of their own to the
+ * similarities (the reference's default PsychoOptical palette, SelfSimilarity.scala:30-56,
+ * impl/SelfSimilarityImpl.scala:109-110,150) and cannot hold img_ext * img_ext floats in one
+ * buffer: at the reference's largest raster (img_ext = 0xB504, :81-91) the matrix is 8.6 GB,
+ * a JVM direct buffer ends at 2 GB.  The matrix is computed by the first call and stays on
+ * the context's GPU (img_ext * img_ext * 4 bytes) while later calls with the same inputs --
+ * recognised by a digest of frames, norms and geometry -- fetch further bands; inputs that
+ * differ, sgz_selfsim_release or sgz_destroy free it.  The bands put together equal the
+ * sim_out of sgz_selfsim_run bit for bit. */
+SGZ_API int sgz_selfsim_rows(sgz_context *ctx, const float *frames1, int64_t num_frames1,
+                     const float *frames2, int64_t num_frames2, int num_channels,
+                     const float *norms, int af_start, int half_win, int decim, int img_ext,
+                     float temporal_weight, int x_begin, int x_end, float *sim_out);
+SGZ_API int sgz_selfsim_release(sgz_context *ctx);
+
 /* ---- FeatureExtraction --------------------------------------------------- */
 
 /* Feature frames an input of num_frames sample frames yields:
@@ -590,6 +606,14 @@ SGZ_API int sgz_run_segmentation_xml(sgz_context *ctx, const char *config_xml, s
 /* SelfSimilarity.run: <selfsimilarity> in (SelfSimilarity.scala:223-238); writes the
  * PNG named by <output>.  Replaces impl/SelfSimilarityImpl.body(). */
 SGZ_API int sgz_run_selfsimilarity_xml(sgz_context *ctx, const char *config_xml, sgz_progress_fn cb, void *user);
+/* Rows [x_begin, x_end) of the similarity matrix that <selfsimilarity> document describes -- inputs, norms, span,
+ * corrLen, decimation and the automatic decimation worked out as impl/SelfSimilarityImpl.scala:32-96 does -- as
+ * (x_end - x_begin) * img_ext floats, and the matrix extent in *img_ext_out (x_begin == x_end: the extent alone,
+ * sim_out may be NULL).  No colour scheme is applied: the route of a caller that renders the raster with a palette
+ * of its own (colors = psycho, the reference's default: SelfSimilarity.scala:30-56,178) band by band, see
+ * sgz_selfsim_rows. */
+SGZ_API int sgz_run_selfsimilarity_rows_xml(sgz_context *ctx, const char *config_xml, int x_begin, int x_end,
+                                            float *sim_out, int *img_ext_out);
 /* FeatureExtraction.run: <feature> in (FeatureExtraction.scala:163-172); reads <input>,
  * writes the feature AIFF <output> and, if <meta> is set, the config XML there.
  * Replaces impl/FeatureExtractionImpl.body() (:31-78). */

@@ -189,6 +189,9 @@ std::vector<Break> runFeatureSegmentation(sgz_context *ctx, const FeatureSegment
 // ColorScheme::GrayScale is implemented (the psycho-optical palette is a
 // third-party table that is not part of the reference sources).
 void runSelfSimilarity(sgz_context *ctx, const SelfSimilarityConfig &cfg, const Observer &obs = nullptr);
+// Rows [xBegin, xEnd) of the matrix behind that raster (no colour scheme applied; any cfg.colors), geometry as in
+// impl/SelfSimilarityImpl.scala:64-91; returns the matrix extent (xBegin == xEnd: nothing else).
+int selfSimilarityRows(sgz_context *ctx, const SelfSimilarityConfig &cfg, int xBegin, int xEnd, float *simOut);
 
 // impl/FeatureExtractionImpl.body(): audio file -> feature AIFF (+ meta XML).
 void runFeatureExtraction(sgz_context *ctx, const FeatureExtractionConfig &cfg, const Observer &obs = nullptr);

@@ -5,7 +5,7 @@
  *   Native.runCorrelation      -> sgz_run_correlation_xml / _multi   (impl/FeatureCorrelationImpl.scala:32-412)
  *   Native.runSegmentation     -> sgz_run_segmentation_xml           (impl/FeatureSegmentationImpl.scala:31-142)
  *   Native.runSelfSimilarity   -> sgz_run_selfsimilarity_xml         (impl/SelfSimilarityImpl.scala:31-180)
- *   Native.selfSimilarityMatrix-> sgz_selfsim_run, similarities only (the JVM colours them: IntensityPalette)
+ *   Native.selfSimilarityRows  -> sgz_run_selfsimilarity_rows_xml, bands of similarities (the JVM colours them: IntensityPalette)
  *   Native.runExtraction       -> sgz_run_extraction_xml             (impl/FeatureExtractionImpl.scala:31-78)
  *   Native.runCrossSimilarity  -> sgz_run_crosssimilarity_xml        (impl/CrossSimilarityImpl.scala:32-173)
  *   Native.runFeatureStats     -> sgz_run_feature_stats              (impl/FeatureStatsImpl.scala:30-54)
@@ -185,28 +185,33 @@ JNIEXPORT jdoubleArray JNICALL NATIVE(runFeatureStats)(JNIEnv *env, jobject self
     return res;
 }
 
-/* The decimated similarity matrix without colours, for colour schemes the library does not hold (the psycho-optical
- * palette is a third-party class on the JVM side): frames1 / frames2 and sims are direct FloatBuffers
- * (interleaved frames as AudioFile.read delivers them de-interleaved -- pass the raw interleaved block);
- * norms is a direct FloatBuffer [numCh][2] or null. */
-JNIEXPORT void JNICALL NATIVE(selfSimilarityMatrix)(JNIEnv *env, jobject self, jlong h, jobject frames1, jlong numFrames1,
-                                                   jobject frames2, jlong numFrames2, jint numCh, jobject norms,
-                                                   jint afStart, jint halfWin, jint decim, jint imgExt,
-                                                   jfloat temporalWeight, jobject sims)
+/* Native.selfSimilarityRows: rows [xBegin, xEnd) of the matrix of a <selfsimilarity> document into a direct
+ * FloatBuffer of at least (xEnd - xBegin) * extent floats (may be null when xBegin == xEnd); returns the extent. */
+JNIEXPORT jint JNICALL NATIVE(selfSimilarityRows)(JNIEnv *env, jobject self, jlong h, jstring cfg, jint xBegin, jint xEnd,
+                                                 jobject sims)
 {
     (void)self;
-    const float *f1 = (const float *)(*env)->GetDirectBufferAddress(env, frames1);
-    const float *f2 = frames2 ? (const float *)(*env)->GetDirectBufferAddress(env, frames2) : f1;
-    const float *nr = norms ? (const float *)(*env)->GetDirectBufferAddress(env, norms) : NULL;
-    float *out = (float *)(*env)->GetDirectBufferAddress(env, sims);
-    if (!f1 || !f2 || !out || (*env)->GetDirectBufferCapacity(env, sims) < (jlong)imgExt * imgExt) {
-        throw_for(env, SGZ_E_ARG, "direct buffers of the right size are required");
-        return;
+    int ext = 0;
+    const char *xml = (*env)->GetStringUTFChars(env, cfg, NULL);
+    if (!xml) return 0;
+    float *out = sims ? (float *)(*env)->GetDirectBufferAddress(env, sims) : NULL;
+    int rc = SGZ_OK;
+    if (xEnd > xBegin) {  /* the buffer must hold the band: ask for the extent first */
+        rc = sgz_run_selfsimilarity_rows_xml(ctx_of(h), xml, 0, 0, NULL, &ext);
+        if (rc == SGZ_OK && (!out || (*env)->GetDirectBufferCapacity(env, sims) < (jlong)(xEnd - xBegin) * ext)) {
+            (*env)->ReleaseStringUTFChars(env, cfg, xml);
+            throw_for(env, SGZ_E_ARG, "a direct buffer of (xEnd - xBegin) * extent floats is required");
+            return 0;
+        }
     }
-    const int rc = sgz_selfsim_run(ctx_of(h), f1, numFrames1, f2, frames2 ? numFrames2 : numFrames1, (int)numCh, nr,
-                                   (int)afStart, (int)halfWin, (int)decim, (int)imgExt, temporalWeight, 0, 1.0f, 1.0f, 0,
-                                   out, NULL);
-    if (rc != SGZ_OK) throw_for(env, rc, sgz_last_error(ctx_of(h)));
+    if (rc == SGZ_OK) rc = sgz_run_selfsimilarity_rows_xml(ctx_of(h), xml, (int)xBegin, (int)xEnd, out, &ext);
+    (*env)->ReleaseStringUTFChars(env, cfg, xml);
+    if (rc != SGZ_OK) {
+        const char *msg = sgz_host_last_error();
+        throw_for(env, rc, msg && *msg ? msg : sgz_last_error(ctx_of(h)));
+        return 0;
+    }
+    return (jint)ext;
 }
 
 #endif /* SGZ_HAVE_JNI */

@@ -1273,5 +1273,20 @@ SGZO_API int sgzo_extract(const float *pcm, int64_t numFrames, int numChannels, 
     free(re);
     free(im);
     free(pw);
+    /* fixNaNs (impl/NonRealtimeProcessor.scala:176-190, default true :34).  The stream is written in chunks of
+     * 1024 stream frames (featBufSize, :32), chunk 0 without stream frame 0 (:98-108): output frames [0, 1023),
+     * [1023, 2047), ...  Per chunk a fresh `lasts` array (zeros, :179); per channel a NaN becomes the last
+     * value that was none (:183-187). */
+    for (int64_t c0 = 0; c0 < nOut + 1; c0 += 1024) {
+        const int64_t f0 = c0 > 0 ? c0 - 1 : 0, f1 = c0 + 1023 < nOut ? c0 + 1023 : nOut;
+        for (int c = 0; c < numCh; c++) {
+            float last = 0.0f;
+            for (int64_t i = f0; i < f1; i++) {
+                float *v = out + (size_t)i * numCh + c;
+                if (*v != *v) *v = last;
+                else last = *v;
+            }
+        }
+    }
     return 0;
 }

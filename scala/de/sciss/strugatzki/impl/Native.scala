@@ -32,11 +32,10 @@ private[strugatzki] object Native {
   @native def runCrossSimilarity(ctx: Long, configXML: String, obs: Progress): Unit
   /** Returns min0, max0, min1, max1, ... */
   @native def runFeatureStats   (ctx: Long, featureFiles: Array[String], obs: Progress): Array[Double]
-  /** The decimated similarity matrix [x][y] (x = left) into the direct buffer `sims`; no colours. */
-  @native def selfSimilarityMatrix(ctx: Long, frames1: java.nio.FloatBuffer, numFrames1: Long,
-                                   frames2: java.nio.FloatBuffer, numFrames2: Long, numChannels: Int,
-                                   norms: java.nio.FloatBuffer, afStart: Int, halfWin: Int, decim: Int, imgExt: Int,
-                                   temporalWeight: Float, sims: java.nio.FloatBuffer): Unit
+  /** Rows [xBegin, xEnd) of the similarity matrix of a `<selfsimilarity>` document, [x - xBegin][y] (x = left), into
+    * the direct buffer `sims` (no colours; inputs, norms and geometry are the library's affair); returns the matrix
+    * extent.  `xBegin == xEnd`: the extent alone (`sims` may be null).  sgz_run_selfsimilarity_rows_xml. */
+  @native def selfSimilarityRows(ctx: Long, configXML: String, xBegin: Int, xEnd: Int, sims: java.nio.FloatBuffer): Int
 
   /** Runs `fun` with one context per configured GPU and releases them afterwards. */
   def withContexts[A](devs: Array[Int])(fun: Array[Long] => A): A = {

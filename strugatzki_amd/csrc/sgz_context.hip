@@ -77,7 +77,7 @@ void sgz_destroy(sgz_context *ctx)
                     ctx->d_files,    ctx->d_tiles,    ctx->d_tiles_h, ctx->d_ptiles,  ctx->d_planar, ctx->d_prefix,
                     ctx->d_tbase,    ctx->d_sim,      ctx->d_boost,   ctx->d_cand,    ctx->d_hflags,
                     ctx->d_suspect,  ctx->d_done,     ctx->d_lokey,    ctx->d_thr,      ctx->d_rs_part,  ctx->d_normtab,
-                    ctx->d_prefix_h, ctx->d_tbase_h, ctx->d_wstat_h, ctx->d_prefetch_done, ctx->d_tgt_state, ctx->d_nonfinite};
+                    ctx->d_prefix_h, ctx->d_tbase_h, ctx->d_wstat_h, ctx->d_prefetch_done, ctx->d_tgt_state, ctx->d_nonfinite, ctx->d_ss_sim};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     sgz::fft_screen_free(ctx);

@@ -487,6 +487,36 @@ namespace {
 // uploading them as they are halves (16 bit) the transfer that bounds the call and spares the host a pass over
 // every sample.  An integer v of b bits becomes v / 2^(b-1), rounded once to float where it does not fit (32 bit),
 // as the host-side reader decodes it.
+// fixNaNs of the reference's feature writer (impl/NonRealtimeProcessor.scala:176-190, on by default :34): the
+// feature stream reaches the output file in chunks of 1024 stream frames, the first of them without stream frame 0
+// (:98-108) -- output frames [0, 1023), [1023, 2047), ... -- and within a chunk and channel a NaN is replaced by
+// the last value that was none, 0 at the start of every chunk (`lasts` is a fresh array per chunk).
+// One workgroup per chunk; a chunk without a NaN (all of them, for sane input) costs one read.
+__global__ __launch_bounds__(256) void fix_nans_kernel(float *__restrict__ feat, long long numFrames, int numCh)
+{
+    const long long f0 = max(0ll, 1024ll * blockIdx.x - 1), f1 = min(numFrames, 1024ll * (blockIdx.x + 1) - 1);
+    const int len = (int)(f1 - f0);
+    float *chunk = feat + f0 * numCh;
+    int bad = 0;
+    for (int e = threadIdx.x; e < len * numCh; e += 256) bad |= chunk[e] != chunk[e];
+    if (!__syncthreads_or(bad)) return;
+    if ((int)threadIdx.x < numCh) {  // a channel per thread, frame after frame (eight loads in flight)
+        float last = 0.0f;
+        float *p = chunk + threadIdx.x;
+        for (int i = 0; i < len; i += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = i + u < len ? p[(long long)(i + u) * numCh] : 0.0f;
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (i + u < len) {
+                    if (v[u] != v[u]) p[(long long)(i + u) * numCh] = last;
+                    else last = v[u];
+                }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void pcm16_decode_kernel(const uint4 *__restrict__ raw, long long count, int bigEndian,
                                                            float *__restrict__ out)
 {
@@ -799,6 +829,11 @@ int sgz_extract_pcm(sgz_context *ctx, const void *pcm, int sample_format, int64_
     SGZ_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     ctx->ev_valid = true;
     ctx->ev_runs++;
+    if (nOut > 0) {
+        hipLaunchKernelGGL(fix_nans_kernel, dim3((unsigned)((nOut + 1 + 1023) / 1024)), dim3(256), 0, ctx->stream,
+                           (float *)dOut.p, (long long)nOut, num_coeffs + 1);
+        SGZ_HIP(ctx, hipGetLastError());
+    }
     SGZ_HIP(ctx, hipMemcpyAsync(features_out, dOut.p, outBytes, hipMemcpyDeviceToHost, ctx->stream));
     SGZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return SGZ_OK;

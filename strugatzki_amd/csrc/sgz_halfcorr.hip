@@ -755,11 +755,12 @@ int sgz_segm_curve(sgz_context *ctx, const float *frames, int64_t num_frames, in
     return SGZ_OK;
 }
 
-int sgz_selfsim_run(sgz_context *ctx, const float *frames1, int64_t num_frames1, const float *frames2,
-                    int64_t num_frames2, int num_channels, const float *norms, int af_start, int half_win,
-                    int decim, int img_ext,
-                    float temporal_weight, int colors, float color_warp, float color_ceil, int color_inv,
-                    float *sim_out, int32_t *img_out)
+// sgz_selfsim_run; keep_sim != nullptr: the matrix is computed and stays on the device (the caller owns *keep_sim).
+static int selfsim_impl(sgz_context *ctx, const float *frames1, int64_t num_frames1, const float *frames2,
+                        int64_t num_frames2, int num_channels, const float *norms, int af_start, int half_win,
+                        int decim, int img_ext,
+                        float temporal_weight, int colors, float color_warp, float color_ceil, int color_inv,
+                        float *sim_out, int32_t *img_out, float **keep_sim)
 {
     if (!ctx) return SGZ_E_ARG;
     if (!frames1 || !frames2 || num_frames1 < 0 || num_frames2 < 0 || num_channels < 2 ||
@@ -797,7 +798,7 @@ int sgz_selfsim_run(sgz_context *ctx, const float *frames1, int64_t num_frames1,
     const size_t pix = (size_t)img_ext * img_ext;
     // the reference skips a group whose weight is 0 (:143-145)
     const bool doT = temporal_weight > 0.0f, doS = temporal_weight < 1.0f || !doT;
-    if (sim_out || img_out || (doT && doS)) SGZ_HIP(ctx, hipMalloc(&simd.p, pix * sizeof(float)));
+    if (sim_out || img_out || keep_sim || (doT && doS)) SGZ_HIP(ctx, hipMalloc(&simd.p, pix * sizeof(float)));
     if (img_out) SGZ_HIP(ctx, hipMalloc(&imgd.p, pix * sizeof(int32_t)));
     DevBuf st1, st2, cols1, cols2;
     const unsigned gt = (unsigned)((img_ext + kSsTile - 1) / kSsTile);
@@ -841,8 +842,8 @@ int sgz_selfsim_run(sgz_context *ctx, const float *frames1, int64_t num_frames1,
     a.scale = 1.0f / color_ceil;
     a.inv = color_inv;
     a.simOut = (float *)simd.p;
-    a.wantSim = sim_out ? 1 : 0;
-    a.keepUpper = (sim_out || img_out) ? 1 : 0;
+    a.wantSim = (sim_out || keep_sim) ? 1 : 0;
+    a.keepUpper = (sim_out || img_out || keep_sim) ? 1 : 0;
     a.imgOut = (int *)imgd.p;
     a.wT = temporal_weight;
     // Gray levels are integer work: a pixel whose level the similarity's error bound could change is listed and
@@ -920,6 +921,93 @@ int sgz_selfsim_run(sgz_context *ctx, const float *frames1, int64_t num_frames1,
     if (sim_out && (rc = copy_large(ctx, sim_out, simd.p, pix * sizeof(float), true))) return rc;
     if (img_out && (rc = copy_large(ctx, img_out, imgd.p, pix * sizeof(int32_t), true))) return rc;
     SGZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (keep_sim) {
+        *keep_sim = (float *)simd.p;
+        simd.p = nullptr;
+    }
+    return SGZ_OK;
+}
+
+int sgz_selfsim_run(sgz_context *ctx, const float *frames1, int64_t num_frames1, const float *frames2,
+                    int64_t num_frames2, int num_channels, const float *norms, int af_start, int half_win,
+                    int decim, int img_ext,
+                    float temporal_weight, int colors, float color_warp, float color_ceil, int color_inv,
+                    float *sim_out, int32_t *img_out)
+{
+    return selfsim_impl(ctx, frames1, num_frames1, frames2, num_frames2, num_channels, norms, af_start, half_win, decim,
+                        img_ext, temporal_weight, colors, color_warp, color_ceil, color_inv, sim_out, img_out, nullptr);
+}
+
+// A digest of everything the matrix depends on (FNV-1a over 64-bit words of the frames, then the parameters).
+static unsigned long long selfsim_digest(const float *frames1, int64_t n1, const float *frames2, int64_t n2, int numCh,
+                                         const float *norms, int af_start, int half_win, int decim, int img_ext,
+                                         float temporal_weight)
+{
+    unsigned long long h = 1469598103934665603ull;
+    auto mix = [&h](const void *p, size_t bytes) {
+        const unsigned char *b = static_cast<const unsigned char *>(p);
+        size_t i = 0;
+        for (; i + 8 <= bytes; i += 8) {
+            unsigned long long w;
+            std::memcpy(&w, b + i, 8);
+            h = (h ^ w) * 1099511628211ull;
+        }
+        for (; i < bytes; i++) h = (h ^ b[i]) * 1099511628211ull;
+    };
+    mix(frames1, sizeof(float) * (size_t)n1 * numCh);
+    const bool same = frames1 == frames2 && n1 == n2;
+    if (!same) mix(frames2, sizeof(float) * (size_t)n2 * numCh);
+    const long long par[8] = {n1, n2, numCh, af_start, half_win, decim, img_ext, same ? 1 : 0};
+    mix(par, sizeof par);
+    mix(&temporal_weight, sizeof temporal_weight);
+    if (norms) mix(norms, sizeof(float) * 2 * (size_t)numCh);
+    return h ? h : 1ull;
+}
+
+int sgz_selfsim_rows(sgz_context *ctx, const float *frames1, int64_t num_frames1, const float *frames2,
+                     int64_t num_frames2, int num_channels, const float *norms, int af_start, int half_win, int decim,
+                     int img_ext, float temporal_weight, int x_begin, int x_end, float *sim_out)
+{
+    if (!ctx) return SGZ_E_ARG;
+    if (!frames1 || !frames2 || num_frames1 < 0 || num_frames2 < 0 || num_channels < 2 ||
+        num_channels > SGZ_MAX_CHANNELS)
+        return ctx->fail(SGZ_E_ARG, "bad frames / channels");
+    if (x_begin < 0 || x_end < x_begin || x_end > img_ext || (x_end > x_begin && !sim_out))
+        return ctx->fail(SGZ_E_ARG, "bad band of rows");
+    const unsigned long long key = selfsim_digest(frames1, num_frames1, frames2, num_frames2, num_channels, norms, af_start,
+                                                  half_win, decim, img_ext, temporal_weight);
+    SGZ_HIP(ctx, hipSetDevice(ctx->device));
+    if (key != ctx->ss_key || !ctx->d_ss_sim) {
+        if (ctx->d_ss_sim) (void)hipFree(ctx->d_ss_sim);
+        ctx->d_ss_sim = nullptr;
+        ctx->ss_key = 0;
+        if (img_ext > 0) {
+            const int rc = selfsim_impl(ctx, frames1, num_frames1, frames2, num_frames2, num_channels, norms, af_start,
+                                        half_win, decim, img_ext, temporal_weight, 0, 1.0f, 1.0f, 0, nullptr, nullptr,
+                                        &ctx->d_ss_sim);
+            if (rc) return rc;
+            ctx->ss_key = key;
+        }
+    }
+    if (x_end > x_begin) {
+        const int rc = copy_large(ctx, sim_out, ctx->d_ss_sim + (size_t)x_begin * img_ext,
+                                  sizeof(float) * (size_t)(x_end - x_begin) * img_ext, true);
+        if (rc) return rc;
+        SGZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return SGZ_OK;
+}
+
+int sgz_selfsim_release(sgz_context *ctx)
+{
+    if (!ctx) return SGZ_E_ARG;
+    if (ctx->d_ss_sim) {
+        SGZ_HIP(ctx, hipSetDevice(ctx->device));
+        SGZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        SGZ_HIP(ctx, hipFree(ctx->d_ss_sim));
+    }
+    ctx->d_ss_sim = nullptr;
+    ctx->ss_key = 0;
     return SGZ_OK;
 }
 

@@ -373,51 +373,87 @@ std::vector<Break> runFeatureSegmentation(sgz_context *ctx, const FeatureSegment
 // -----------------------------------------------------------------------------
 // SelfSimilarity: impl/SelfSimilarityImpl.scala:31-180
 // -----------------------------------------------------------------------------
-void runSelfSimilarity(sgz_context *ctx, const SelfSimilarityConfig &cfg, const Observer &obs)
+namespace {
+
+// What SelfSimilarityImpl.body() works out before its loops (impl/SelfSimilarityImpl.scala:32-96): inputs, norms
+// and the geometry of the matrix.
+struct SelfSimPlan {
+    int numCh = 0, halfWinLen = 0, afStart = 0, decim = 1, imgExt = 0;
+    std::vector<float> norms;
+    AudioData a1, a2own;
+    bool same = true;
+    const AudioData &a2() const { return same ? a1 : a2own; }
+};
+
+SelfSimPlan planSelfSimilarity(const SelfSimilarityConfig &cfg)
 {
-    if (!ctx) throw Error(SGZ_E_ARG, "null context");
+    SelfSimPlan p;
     const FeatureExtractionConfig e1 = FeatureExtractionConfig::fromXMLFile(cfg.metaInput);
     const FeatureExtractionConfig e2 = cfg.metaInput2 ? FeatureExtractionConfig::fromXMLFile(*cfg.metaInput2) : e1;
     if (!(e1.fftSize == e2.fftSize && e1.fftOverlap == e2.fftOverlap && e1.numCoeffs == e2.numCoeffs))
         throw Error(SGZ_E_ARG, "requirement failed: the two inputs differ in fftSize, fftOverlap or numCoeffs");  // :34-35
     if (e1.fftOverlap < 1 || e1.fftSize < e1.fftOverlap) throw Error(SGZ_E_ARG, "bad fftSize / fftOverlap");
     const int stepSize = e1.fftSize / e1.fftOverlap;
-    const int numCh = e1.numCoeffs + 1;
-    const int halfWinLen = fullToFeat(cfg.corrLen, stepSize);
-    const int winLen = halfWinLen * 2;
-    if (halfWinLen < 1) throw Error(SGZ_E_ARG, "corrLen is shorter than one feature frame");
-    if (cfg.colors != ColorScheme::GrayScale)
-        throw Error(SGZ_E_ARG, "only the 'gray' color scheme is implemented");
+    p.numCh = e1.numCoeffs + 1;
+    p.halfWinLen = fullToFeat(cfg.corrLen, stepSize);
+    const int winLen = p.halfWinLen * 2;
+    if (p.halfWinLen < 1) throw Error(SGZ_E_ARG, "corrLen is shorter than one feature frame");
     if (cfg.decimation < 1) throw Error(SGZ_E_ARG, "Illegal decimation setting of " + std::to_string(cfg.decimation));
     if (!(cfg.colorWarp > 0)) throw Error(SGZ_E_ARG, "Illegal color warp setting. Must be > 0");
     if (!(cfg.colorCeil > 0)) throw Error(SGZ_E_ARG, "Illegal color ceil setting. Must be > 0");
-    std::vector<float> norms;
-    if (cfg.normalize) norms = readNorms(cfg.databaseFolder, numCh);
-    const AudioData a1 = readAudioFile(e1.featureOutput);
-    const bool same = e1.featureOutput == e2.featureOutput;
-    AudioData a2own;
-    if (!same) a2own = readAudioFile(e2.featureOutput);
-    const AudioData &a2 = same ? a1 : a2own;
-    if (a1.numChannels != numCh || a2.numChannels != numCh)
+    if (cfg.normalize) p.norms = readNorms(cfg.databaseFolder, p.numCh);
+    p.a1 = readAudioFile(e1.featureOutput);
+    p.same = e1.featureOutput == e2.featureOutput;
+    if (!p.same) p.a2own = readAudioFile(e2.featureOutput);
+    if (p.a1.numChannels != p.numCh || p.a2().numChannels != p.numCh)
         throw Error(SGZ_E_IO, "feature file has the wrong number of channels");
-    const int64_t afNumFrames = std::min(a1.numFrames, a2.numFrames);  // :64
+    const int64_t afNumFrames = std::min(p.a1.numFrames, p.a2().numFrames);  // :64
     const Spans sp = spanToFeat(cfg.span, afNumFrames, stepSize);
+    p.afStart = sp.afStart;
     const int afLen = sp.afStop - sp.afStart;
     const int numCorrs = (int)std::max<int64_t>(0, (int64_t)afLen - winLen + 1);  // :75-80
-    int decim = cfg.decimation, imgExt = numCorrs / decim;                          // :81-91
-    if (imgExt > 0xB504) {
-        decim = (numCorrs + 0xB503) / 0xB504;
-        imgExt = numCorrs / decim;
+    p.decim = cfg.decimation;                                                      // :81-91
+    p.imgExt = numCorrs / p.decim;
+    if (p.imgExt > 0xB504) {
+        p.decim = (numCorrs + 0xB503) / 0xB504;
+        p.imgExt = numCorrs / p.decim;
     }
+    return p;
+}
+
+}  // namespace
+
+void runSelfSimilarity(sgz_context *ctx, const SelfSimilarityConfig &cfg, const Observer &obs)
+{
+    if (!ctx) throw Error(SGZ_E_ARG, "null context");
+    if (cfg.colors != ColorScheme::GrayScale)
+        throw Error(SGZ_E_ARG, "only the 'gray' color scheme is rendered by the library (others: selfSimilarityRows + the "
+                               "caller's palette)");
+    const SelfSimPlan p = planSelfSimilarity(cfg);
     checkAborted(obs, 0.0);
-    std::vector<int32_t> img((size_t)imgExt * (size_t)imgExt);
-    check(ctx, sgz_selfsim_run(ctx, a1.frames.data(), a1.numFrames, a2.frames.data(), a2.numFrames, numCh,
-                               cfg.normalize ? norms.data() : nullptr, sp.afStart, halfWinLen, decim, imgExt,
+    std::vector<int32_t> img((size_t)p.imgExt * (size_t)p.imgExt);
+    check(ctx, sgz_selfsim_run(ctx, p.a1.frames.data(), p.a1.numFrames, p.a2().frames.data(), p.a2().numFrames, p.numCh,
+                               cfg.normalize ? p.norms.data() : nullptr, p.afStart, p.halfWinLen, p.decim, p.imgExt,
                                cfg.temporalWeight, 0, cfg.colorWarp, cfg.colorCeil, cfg.colorInv ? 1 : 0, nullptr,
                                img.data()));
     checkAborted(obs, 0.9);
-    writePng(cfg.imageOutput, img.data(), imgExt, imgExt);  // :167
+    writePng(cfg.imageOutput, img.data(), p.imgExt, p.imgExt);  // :167
     notify(obs, 1.0);
+}
+
+// Rows [xBegin, xEnd) of the similarity matrix of this configuration, whatever its colour scheme (none is applied),
+// and the matrix extent: inputs, norms and geometry are worked out as for the raster, so a caller with a palette of
+// its own -- the reference's default, PsychoOptical, is a JVM class -- restates none of them.
+int selfSimilarityRows(sgz_context *ctx, const SelfSimilarityConfig &cfg, int xBegin, int xEnd, float *simOut)
+{
+    if (!ctx) throw Error(SGZ_E_ARG, "null context");
+    const SelfSimPlan p = planSelfSimilarity(cfg);
+    if (xBegin == xEnd) return p.imgExt;  // (the extent alone)
+    if (xBegin < 0 || xEnd < xBegin || xEnd > p.imgExt) throw Error(SGZ_E_ARG, "rows outside the matrix");
+    check(ctx, sgz_selfsim_rows(ctx, p.a1.frames.data(), p.a1.numFrames, p.a2().frames.data(), p.a2().numFrames, p.numCh,
+                                cfg.normalize ? p.norms.data() : nullptr, p.afStart, p.halfWinLen, p.decim, p.imgExt,
+                                cfg.temporalWeight, xBegin, xEnd, simOut));
+    return p.imgExt;
 }
 
 // -----------------------------------------------------------------------------
@@ -667,6 +703,16 @@ int sgz_run_selfsimilarity_xml(sgz_context *ctx, const char *config_xml, sgz_pro
     return guarded([&] {
         const auto cfg = strugatzki::SelfSimilarityConfig::fromXML(config_xml);
         strugatzki::runSelfSimilarity(ctx, cfg, makeObserver(cb, user));
+    });
+}
+
+int sgz_run_selfsimilarity_rows_xml(sgz_context *ctx, const char *config_xml, int x_begin, int x_end, float *sim_out,
+                                    int *img_ext_out)
+{
+    if (!config_xml || !img_ext_out || (x_end != x_begin && !sim_out)) return SGZ_E_ARG;
+    return guarded([&] {
+        const auto cfg = strugatzki::SelfSimilarityConfig::fromXML(config_xml);
+        *img_ext_out = strugatzki::selfSimilarityRows(ctx, cfg, x_begin, x_end, sim_out);
     });
 }
 

@@ -308,6 +308,10 @@ struct sgz_context {
     size_t rs_part_cap = 0;
     void *noalloc_scratch = nullptr;         // this device's copy of the file-scope scratch array (sgz_corr.hip)
 
+    // sgz_selfsim_rows: the similarity matrix of the latest call, kept on the device while bands of it are fetched
+    float *d_ss_sim = nullptr;
+    unsigned long long ss_key = 0;           // digest of the arguments it was computed for (0: none)
+
     sgz_candidate *d_cand = nullptr;         // [two count headers][records]
     sgz_candidate *d_suspect = nullptr;      // [count header][windows an exact run hands to the two-pass kernels]
     size_t suspect_cap = 0;

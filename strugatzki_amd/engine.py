@@ -373,6 +373,22 @@ class Context:
                                         color_ceil, int(color_inv), N.ptr(sim), N.ptr(img)))
         return sim, img
 
+    def selfsim_rows(self, frames1: np.ndarray, frames2: np.ndarray | None, norms: np.ndarray | None, af_start: int,
+                     half_win: int, decim: int, img_ext: int, temporal_weight: float, x_begin: int,
+                     x_end: int) -> np.ndarray:
+        """Rows [x_begin, x_end) of the similarity matrix (sgz_selfsim_rows): the matrix stays on the GPU between
+        calls with the same inputs."""
+        a1 = _as_frames(frames1)
+        a2 = a1 if frames2 is None else _as_frames(frames2, a1.shape[1])
+        nrm = None if norms is None else np.ascontiguousarray(norms, dtype=np.float32)
+        out = np.zeros((max(x_end - x_begin, 0), img_ext), dtype=np.float32)
+        self._check(lib.sgz_selfsim_rows(self._h, N.ptr(a1), a1.shape[0], N.ptr(a2), a2.shape[0], a1.shape[1],
+                                         N.ptr(nrm), af_start, half_win, decim, img_ext, temporal_weight, x_begin, x_end,
+                                         N.ptr(out) if out.size else None))
+        return out
+
+    def selfsim_release(self) -> None:
+        self._check(lib.sgz_selfsim_release(self._h))
 
     # ---- extraction -----------------------------------------------------------
     # sample layouts of sgz_extract_pcm (SGZ_PCM_*): (bytes per sample, little-endian code); big endian = code + 1

@@ -331,6 +331,22 @@ class SelfSimilarity:
         cb = _callback(observer)
         _host_check(lib.sgz_run_selfsimilarity_xml(ctx._h, config.to_xml().encode(), cb, None))
 
+    @staticmethod
+    def rows(ctx: Context, config: "SelfSimilarity.Config", x_begin: int = 0, x_end: int | None = None) -> np.ndarray:
+        """Rows [x_begin, x_end) (default: all) of the similarity matrix behind the raster, no colour scheme applied
+        (sgz_run_selfsimilarity_rows_xml): what a caller with a palette of its own colours, band by band."""
+        import ctypes as C
+        xml = config.to_xml().encode()
+        ext = C.c_int(0)
+        _host_check(lib.sgz_run_selfsimilarity_rows_xml(ctx._h, xml, 0, 0, None, C.byref(ext)))
+        if x_end is None:
+            x_end = ext.value
+        out = np.zeros((max(x_end - x_begin, 0), ext.value), dtype=np.float32)
+        if out.shape[0] or x_end != x_begin:
+            _host_check(lib.sgz_run_selfsimilarity_rows_xml(ctx._h, xml, x_begin, x_end, N.ptr(out) if out.size else None,
+                                                            C.byref(ext)))
+        return out
+
 
 class CrossSimilarity:
     @dataclass

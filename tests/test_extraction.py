@@ -89,6 +89,51 @@ def test_gpu_features_match_the_oracle(ctx, n, channels, behavior, fft, overlap,
         np.testing.assert_allclose(got[:, 0], want[:, 0], rtol=5e-4, atol=1e-5)
 
 
+def _nan_signal(n, fft):
+    """Samples that are not numbers, placed so that the spoilt feature frames lie at the start of the file, across
+    the first two chunk boundaries of the feature writer (output frames 1023 and 2047) and in the middle of a chunk."""
+    x = _signal(n, seed=3)
+    step = fft // 2
+    for frame in (0, 1, 400, 401, 402, 1021, 1022, 1023, 1024, 2046, 2047, 2048, 2500):
+        if (frame + 1) * step < n:
+            x[frame * step + 5, 0] = np.nan
+    return x
+
+
+def test_oracle_holds_the_last_value_over_nans_and_starts_each_chunk_at_zero():
+    """fixNaNs of the feature writer (impl/NonRealtimeProcessor.scala:176-190): per chunk of 1024 stream frames
+    (the first without stream frame 0) and channel, a NaN becomes the last value that was none, 0 at the start of
+    a chunk."""
+    n, fft = 1_400_000, 1024
+    x = _nan_signal(n, fft)
+    clean = O.extract(_signal(n, seed=3), SR, fft, 2, 13, 0)
+    got = O.extract(x, SR, fft, 2, 13, 0)
+    assert not np.isnan(got).any()
+    # a spoilt sample spoils the two FFT frames that contain it: output frames f and f + 1 of sample f * step + 5
+    assert np.array_equal(got[400:404], np.repeat(got[399:400], 4, axis=0))       # 400 .. 403 hold frame 399
+    assert np.array_equal(got[404], clean[404])
+    assert np.array_equal(got[0:3], np.zeros((3, 14), np.float32))                # nothing to hold yet
+    assert np.array_equal(got[1021:1023], np.repeat(got[1020:1021], 2, axis=0))   # end of chunk 0
+    assert np.array_equal(got[1023:1026], np.zeros((3, 14), np.float32))          # chunk 1 starts afresh
+    assert np.array_equal(got[2046], got[2045])
+    assert np.array_equal(got[2047:2050], np.zeros((3, 14), np.float32))          # chunk 2 as well
+    assert np.array_equal(got[2500:2502], np.repeat(got[2499:2500], 2, axis=0))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fft,coeffs", [(1024, 13), (512, 7)])
+def test_gpu_holds_the_last_value_over_nans(ctx, fft, coeffs):
+    n = 1_400_000
+    x = _nan_signal(n, fft)
+    want = O.extract(x, SR, fft, 2, coeffs, 0)
+    got = ctx.extract(x, SR, fft, 2, coeffs, 0)
+    assert not np.isnan(got).any()
+    np.testing.assert_allclose(got, want, rtol=0, atol=TOL)
+    # the frames that were replaced are exact copies of the frame before (or zeros), not approximations
+    for f in (400, 1023, 2047, 2500):
+        assert np.array_equal(got[f], got[f - 1]) or not got[f].any()
+
+
 @pytest.mark.gpu
 def test_gpu_silence_and_empty_input(ctx):
     got = ctx.extract(np.zeros((5000, 1), np.float32), SR)

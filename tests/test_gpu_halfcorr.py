@@ -131,6 +131,39 @@ def test_selfsim_matrix_for_colour_schemes_the_jvm_renders(ctx):
         ctx.selfsim(frames, None, norms, af_start, 8, d, ext, 0.5, colors=1, want_img=True)
 
 
+@pytest.mark.parametrize("two_files", [False, True])
+def test_selfsim_rows_put_together_are_the_matrix(ctx, two_files):
+    """sgz_selfsim_rows: bands of rows of the similarity matrix, for a caller that colours the similarities itself
+    and cannot hold the whole matrix in one buffer.  The bands concatenated are the matrix of sgz_selfsim_run bit
+    for bit; other inputs are not served from the matrix the context kept."""
+    f1 = _frames(700, 3)
+    f2 = _frames(650, 5) if two_files else None
+    norms = norms_default()
+    n2 = 650 if two_files else 700
+    cfg = O.SelfSimConfig(0, 0, 0, 0, 6 * STEP, 1, 0.5, 0, 1.0, 1.0, 0, 1, STEP, NUM_CH - 1)
+    ext, d, af_start, _ = O.selfsim_geometry(cfg, 700, n2)
+    full, _ = ctx.selfsim(f1, f2, norms, af_start, 6, d, ext, 0.5, want_img=False)
+    cuts = [0, 1, 130, 131, 400, ext]
+    bands = [ctx.selfsim_rows(f1, f2, norms, af_start, 6, d, ext, 0.5, a, b) for a, b in zip(cuts[:-1], cuts[1:])]
+    assert np.array_equal(np.concatenate(bands, axis=0), full)
+    assert ctx.selfsim_rows(f1, f2, norms, af_start, 6, d, ext, 0.5, 7, 7).shape == (0, ext)
+    # another weight: a different matrix, not the one kept on the device
+    other, _ = ctx.selfsim(f1, f2, norms, af_start, 6, d, ext, 0.25, want_img=False)
+    got = ctx.selfsim_rows(f1, f2, norms, af_start, 6, d, ext, 0.25, 100, 140)
+    assert np.array_equal(got, other[100:140]) and not np.array_equal(got, full[100:140])
+    # other frames at the same address and of the same shape
+    f1b = f1.copy()
+    f1b[300:320] *= np.float32(1.5)
+    other, _ = ctx.selfsim(f1b, f2, norms, af_start, 6, d, ext, 0.25, want_img=False)
+    assert np.array_equal(ctx.selfsim_rows(f1b, f2, norms, af_start, 6, d, ext, 0.25, 280, 330), other[280:330])
+    ctx.selfsim_release()
+    assert np.array_equal(ctx.selfsim_rows(f1, f2, norms, af_start, 6, d, ext, 0.5, ext - 10, ext), full[ext - 10:])
+    ctx.selfsim_release()
+    import strugatzki_amd as S
+    with pytest.raises(S.NativeError):
+        ctx.selfsim_rows(f1, f2, norms, af_start, 6, d, ext, 0.5, 5, ext + 1)
+
+
 def test_selfsim_rejects_bad_arguments(ctx):
     import strugatzki_amd as S
     frames = _frames(100)

@@ -293,3 +293,15 @@ def test_self_similarity_png(ctx, tmp_path):
     assert dpx.max() <= 1 and (dpx > 0).mean() < 0.01
     with pytest.raises(P.N.NativeError):
         SelfSimilarity.run(ctx, SelfSimilarity.Config(d, meta, None, out, colors="psycho"))
+    # colors = psycho (the reference's default): the palette is the caller's; the library hands out the matrix in
+    # bands of rows, inputs and geometry (impl/SelfSimilarityImpl.scala:64-91) worked out from the same document
+    pcfg = SelfSimilarity.Config(d, meta, None, out, Span.all(), 8 * STEP, 2, 0.5, "psycho", 1.0, 1.0, False, True)
+    want_sim, _ = O.selfsim_run(ocfg, frames, None, norms, want_img=False)
+    ext = want_sim.shape[0]
+    bands = [SelfSimilarity.rows(ctx, pcfg, a, b) for a, b in ((0, 40), (40, 41), (41, ext))]
+    got = np.concatenate(bands, axis=0)
+    assert got.shape == want_sim.shape
+    np.testing.assert_allclose(got, want_sim, rtol=0, atol=1e-5)
+    assert np.array_equal(SelfSimilarity.rows(ctx, pcfg), got)
+    with pytest.raises(P.N.NativeError):
+        SelfSimilarity.rows(ctx, pcfg, 0, ext + 1)
