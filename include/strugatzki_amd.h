@@ -443,6 +443,18 @@ SGZ_API int sgz_corr_search_multi(sgz_context *const *ctxs, int num_ctx, const i
                                   int num_files_total, int target_frames, int num_matches, int num_per_file,
                                   int64_t min_spacing, int step_size, int64_t capacity, sgz_match *matches_out,
                                   int out_capacity, int *count_out);
+/* How sgz_corr_search_multi led by `lead` (its first context) exchanges the contexts' candidates for numPerFile = 1:
+ * 0 (default) merged in host memory; 1: every context sends a 16 KiB block (header row: count and the context's
+ * threshold; 1023 records) through one RCCL all-gather -- a communicator rank per context, ncclCommInitAll over
+ * their devices, each rank's call queued on its context's stream behind the kernels -- and the selection replays
+ * over the first context's copy: the exchange of a search with one process per GPU, from one process.  RCCL is
+ * loaded on first use, from the ROCm installation of this library's HIP runtime.  Where it cannot serve (contexts
+ * that share a GPU: RCCL wants distinct devices; no library) the merge in host memory is taken and
+ * sgz_last_error(lead) says why.  The environment variable SGZ_MULTI_EXCHANGE = rccl | host overrides the setting.
+ * sgz_multi_last_exchange: what the latest search used (0 / 1).  No counterpart in the reference (single GPU-less
+ * process). */
+SGZ_API int sgz_multi_set_exchange(sgz_context *lead, int mode);
+SGZ_API int sgz_multi_last_exchange(const sgz_context *lead);
 
 /* Feeds the exactly re-scored candidates of sgz_corr_compact_bounded (sorted by
  * (file, offset), files 0 .. num_files-1, the first head_files of them head

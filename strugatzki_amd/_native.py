@@ -160,6 +160,8 @@ SIGNATURES = {
          C.c_int, C.c_int, _vp],
     ),
     "sgz_selfsim_release": (C.c_int, [_vp]),
+    "sgz_multi_set_exchange": (C.c_int, [_vp, C.c_int]),
+    "sgz_multi_last_exchange": (C.c_int, [_vp]),
     "sgz_run_selfsimilarity_rows_xml": (C.c_int, [_vp, C.c_char_p, C.c_int, C.c_int, _vp, _vp]),
     "sgz_extract_num_frames": (C.c_int64, [C.c_int64, C.c_int, C.c_int]),
     "sgz_extract": (

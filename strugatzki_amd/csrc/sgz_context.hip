@@ -71,6 +71,9 @@ void sgz_destroy(sgz_context *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->screen_stream) (void)hipStreamSynchronize(ctx->screen_stream);
+    if (ctx->multi_comm && ctx->multi_comm_free) ctx->multi_comm_free(ctx->multi_comm);  // (before the streams go)
+    ctx->multi_comm = nullptr;
+    (void)hipSetDevice(ctx->device);
     for (auto &f : ctx->files)
         if (f.owned && f.d_raw) (void)hipFree(f.d_raw);
     void *bufs[] = {ctx->d_planar_f, ctx->d_planar_h, ctx->d_aprime, ctx->d_aprime_f, ctx->d_aimg_h, ctx->d_tnorm,

@@ -152,6 +152,11 @@ struct sgz_context {
     std::vector<sgz::DbFile> files;
     std::string db_tag;                      // the caller's label of the loaded database (sgz_db_set_tag)
     unsigned long long db_serial = 0;        // bumped by sgz_db_reset and every sgz_db_add_*: the files changed
+    int multi_exchange = 0;                  // sgz_multi_set_exchange: 0 merge in host memory, 1 RCCL all-gather
+    int multi_exchange_used = 0;             // what the latest sgz_corr_search_multi used
+    void *multi_comm = nullptr;              // RCCL communicators and buffers of the contexts it led (sgz_multi.hip)
+    void (*multi_comm_free)(void *) = nullptr;
+    std::string multi_refused_key, multi_refused_why;  // the set of contexts RCCL last refused, and its reason
     std::string multi_ring_key;              // sgz_corr_search_multi (on its first context): what the ring images of
                                              // the short files were last worked out for
     sgz::NormParams norm{};

@@ -75,6 +75,26 @@ def test_multi_context_search_with_files_shorter_than_the_target(num_ctx, screen
                     c.close()
 
 
+def test_multi_context_search_with_the_exchange_over_rccl():
+    """sgz_multi_set_exchange(1): the contexts' candidate blocks travel through one RCCL all-gather (a communicator
+    rank per context) and the selection replays over the first context's copy.  This box has one GPU: one context
+    exchanges over RCCL for real; two contexts on the same GPU are what RCCL refuses (one rank per device), and the
+    library then merges in host memory and says why.  Every result equals the oracle's."""
+    import json
+    import os
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "multi_rccl_child.py")
+    pr = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=150)
+    assert pr.returncode == 0, pr.stderr[-3000:]
+    res = json.loads(pr.stdout.strip().splitlines()[-1])
+    for case in ("one", "one_awkward"):
+        for r in res[case]:
+            assert r["same"] and r["used"] == 1, (case, r)
+    for r in res["two_on_one_gpu"]:
+        assert r["same"] and r["used"] == 0 and "RCCL" in r["why"], r
+
+
 def test_multi_context_search_rejects_inconsistent_input():
     import strugatzki_amd as S
     L, ts = 40, 3
