@@ -4,7 +4,7 @@ usage: sharded_rank.py PORT MODE RANK WORLD BACKEND [CASES SEED]
 MODE: "bounds" (search over bounds), "general" (replicated head files, screen_head off), "headbounds" (replicated
 head files and the search over bounds: every rank reports the head files' windows), "exact" (no replicated files,
 no screening), "nan" (as "bounds", over a database with constant stretches), "fuzz" (CASES random cases from SEED,
-compared with the oracle on every rank).
+compared with the oracle on every rank), "norms" (two searches with other norms in between, short files first).
 Every rank prints the matches (or the fuzz counts) as one JSON line."""
 import json
 import os
@@ -85,10 +85,45 @@ def fuzz(port: int, rank: int, world: int, backend: str, cases: int, seed: int) 
     return 0
 
 
+def norms_change(port: int, rank: int, world: int, backend: str) -> int:
+    """Two searches with a target of the same length and other norms in between, over a database whose first files
+    are shorter than the target: the ring positions no file has written normalise to 0, so the raw values the ranks
+    hand their short files depend on the norms in force.  Prints both match lists."""
+    import numpy as np
+    L, ts = 120, 5
+    frames = [60, 30, 1000, 119, 700, 400, 260]
+    db = synth_db(len(frames), frames)
+    tgt = synth_target(ts, L)
+    tail = [g for g in range(len(frames)) if g % world == rank]
+    ctx = S.Context(0)
+    ctx.db_reset(db[0].shape[1])
+    for g in tail:
+        ctx.db_add_file(db[g])
+    kw = dict(device_id=torch.device("cuda", 0)) if backend == "nccl" else {}
+    dist.init_process_group(backend, init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, **kw)
+    out = []
+    try:
+        other = norms_default().copy()
+        other[:, 0] -= np.float32(0.25)
+        other[:, 1] += np.float32(0.5)
+        for norms in (norms_default(), other):
+            ctx.set_norms(norms)
+            ctx.corr_set_target(tgt[ts:ts + L], 0.5, 8.0)
+            got = S.search_sharded(ctx, S.SearchParams(5, 1, 0, STEP), [], tail, num_files_total=len(frames))
+            out.append([[m.file, m.start, m.stop, float(m.sim)] for m in got])
+    finally:
+        dist.destroy_process_group()
+    print(json.dumps(out))
+    ctx.close()
+    return 0
+
+
 def main() -> int:
     port, mode, rank, world, backend = int(sys.argv[1]), sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
     if mode == "fuzz":
         return fuzz(port, rank, world, backend, int(sys.argv[6]), int(sys.argv[7]))
+    if mode == "norms":
+        return norms_change(port, rank, world, backend)
     q = CASE
     db = sharded_case_db(mode)
     tgt = synth_target(q["ts"], q["L"])

@@ -637,6 +637,26 @@ def test_search_sharded_two_ranks_on_one_gpu(mode, screen_kernel_env):
         assert any(w.sim != w.sim for w in want)  # the case does exercise a kept NaN match
 
 
+def test_search_sharded_after_the_norms_change():
+    """The ring contents the ranks hand their short files are derived under the norms in force: a second search with
+    a target of the same length and other norms must not reuse them (impl/FeatureCorrelationImpl.scala:154,
+    190-197: the untouched part of the ring holds zeros, i.e. raw values that normalise to 0)."""
+    L, ts = 120, 5
+    frames = [60, 30, 1000, 119, 700, 400, 260]
+    db = synth_db(len(frames), frames)
+    tgt = synth_target(ts, L)
+    other = norms_default().copy()
+    other[:, 0] -= np.float32(0.25)
+    other[:, 1] += np.float32(0.5)
+    outs = _run_ranks("norms", 2, "gloo")
+    for k, norms in enumerate((norms_default(), other)):
+        want, _, _ = O.correlation_run(corr_config(ts, L, num_matches=5), tgt, norms, db, dense=False)
+        for out in outs:
+            got = out[k]
+            assert [(g[0], g[1], g[2]) for g in got] == [(w.file, w.start, w.stop) for w in want]
+            assert all(abs(g[3] - w.sim) <= 1.2e-7 for g, w in zip(got, want))
+
+
 @pytest.mark.parametrize("world,seed", [(2, 5), (3, 6)])
 def test_search_sharded_random_cases(world, seed, screen_kernel_env):
     """Random databases, parameters and ways of sharding (search over bounds, replicated head files, exact),
