@@ -31,6 +31,7 @@
 
 #include "sgz_corr_dev.hpp"
 #include "sgz_internal.hpp"
+#include "sgz_target_dev.hpp"
 
 using namespace sgz;
 
@@ -867,15 +868,19 @@ __global__ __launch_bounds__(kThreads, 4) void corr_kernel(const FileDesc *__res
 // (impl/MathUtil.scala:29-62, 177-196) run over the frames of one window, so such a value spoils exactly the
 // windows that contain it; window statistics from prefix sums would spoil every later window of the file as well.
 // The exact run therefore evaluates every window of such a file from its frames (list_windows_kernel and the
-// re-scoring kernels).  One workgroup per file.
+// re-scoring kernels).  kScanParts workgroups per file (flags cleared beforehand).
+constexpr int kScanParts = 32;
 __global__ __launch_bounds__(256) void nonfinite_scan_kernel(const FileDesc *__restrict__ files,
                                                              const float *__restrict__ normTab, int normEnabled,
                                                              int numCh, int *__restrict__ flags)
 {
-    const FileDesc fd = files[blockIdx.x];
+    const int file = blockIdx.x / kScanParts, part = blockIdx.x % kScanParts;
+    const FileDesc fd = files[file];
     const long long n = fd.frames * numCh;
+    const long long per = ((n + kScanParts - 1) / kScanParts + 3) & ~3ll;
+    const long long e0 = part * per, e1 = min(n, e0 + per);
     int bad = 0;
-    for (long long e = threadIdx.x; e < n; e += 256) {
+    for (long long e = e0 + threadIdx.x; e < e1; e += 256) {
         float v = fd.raw[e];
         if (normEnabled) {
             const int c = (int)(e % numCh);
@@ -884,7 +889,7 @@ __global__ __launch_bounds__(256) void nonfinite_scan_kernel(const FileDesc *__r
         bad |= !(fabsf(v) <= 3.4028234e38f);
     }
     bad = __syncthreads_or(bad);
-    if (threadIdx.x == 0) flags[blockIdx.x] = bad ? 1 : 0;
+    if (threadIdx.x == 0 && bad) atomicOr(&flags[file], 1);
 }
 
 // Windows [o0, o0 + n) of one file as a candidate list (for the re-scoring kernels).
@@ -1415,72 +1420,7 @@ __global__ __launch_bounds__(256) void rescore_final_kernel(const FileDesc *__re
 // kernel arguments of everything that follows.
 // ---------------------------------------------------------------------------
 constexpr int kTpThreads = 256;
-constexpr int kTpPer = 4;                        // elements per thread
 constexpr int kTpTile = kTpThreads * kTpPer;     // elements per workgroup
-constexpr int kTpSums = 10;                      // doubles a workgroup of the second kernel hands on
-
-struct TargetReport {
-    double sum1[2];   // sums of the normalised values: loudness row, other rows
-    double sum2[2];   // sums of the squared deviations from the group's mean
-    double csum[2];   // sums of the centred values (what rounding leaves of zero)
-    double fsum[2];   // sums of the centred values rounded to fp32
-    double fsq[2];    // sums of their squares
-    double fsq1;      // ... of channel 1 alone
-    unsigned long long inRange;  // 1: every centred value lies within the half-precision range
-    unsigned long long seq;      // written last
-};
-
-// Device-side state of the two kernels: [0..1] the sums of the first pass, [2..3] the means, then the workgroups'
-// partial sums (kTpSums doubles each); `counter` counts the workgroups that are done (reset by the last one).
-template <int K>
-__device__ __forceinline__ void tp_wg_sums(double (&v)[K], double *red /* 4 * K doubles */, double *__restrict__ out)
-{
-#pragma unroll
-    for (int j = 0; j < K; j++)
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) v[j] += __shfl_xor(v[j], off, 64);
-    if ((threadIdx.x & 63) == 0)
-#pragma unroll
-        for (int j = 0; j < K; j++) red[(threadIdx.x >> 6) * K + j] = v[j];
-    __syncthreads();
-    if (threadIdx.x < K) {
-        double s = 0.0;
-        for (int w = 0; w < kTpThreads / 64; w++) s += red[w * K + threadIdx.x];
-        out[threadIdx.x] = s;
-    }
-}
-
-// Column j < K of the workgroups' sums, added in workgroup order; valid in thread j.  The rows are fetched by the
-// whole workgroup, kTpRows at a time (a thread per column reading them one after the other from memory would wait
-// for every one of them in turn).
-constexpr int kTpRows = kTpThreads / kTpSums;
-template <int K>
-__device__ __forceinline__ double tp_final_sum(const double *__restrict__ state, double *rows /* kTpRows * kTpSums */)
-{
-    double s = 0.0;
-    const int G = (int)gridDim.x;
-    for (int w0 = 0; w0 < G; w0 += kTpRows) {
-        const int nrows = min(kTpRows, G - w0);
-        if ((int)threadIdx.x < nrows * kTpSums) rows[threadIdx.x] = state[4 + (size_t)w0 * kTpSums + threadIdx.x];
-        __syncthreads();
-        if ((int)threadIdx.x < K)
-            for (int r = 0; r < nrows; r++) s += rows[r * kTpSums + threadIdx.x];
-        __syncthreads();
-    }
-    return s;
-}
-
-// True in every thread of the one workgroup that finishes last (whose reads then see all the others' sums).
-__device__ __forceinline__ bool tp_last_workgroup(unsigned int *counter)
-{
-    __shared__ int last;
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) last = atomicAdd(counter, 1u) == gridDim.x - 1;
-    __syncthreads();
-    if (last) __threadfence();
-    return last != 0;
-}
 
 __global__ __launch_bounds__(kTpThreads) void target_norm_kernel(const float *__restrict__ frames, int L, int numCh,
                                                                  const float *__restrict__ normTab, int normEnabled,
@@ -1510,10 +1450,11 @@ __global__ __launch_bounds__(kTpThreads) void target_norm_kernel(const float *__
             s1[c > 0] += (double)v;
         }
     }
-    tp_wg_sums<2>(s1, red, state + 4 + (size_t)blockIdx.x * kTpSums);
-    if (!tp_last_workgroup(counter)) return;
-    __shared__ double rows[kTpRows * kTpSums];
-    const double s = tp_final_sum<2>(state, rows);
+    tp_wg_sums<kTpThreads, 2>(s1, red, state + 4 + (size_t)blockIdx.x * kTpSums);
+    __shared__ int lastFlag;
+    if (!tp_last_workgroup(counter, (int)gridDim.x, &lastFlag)) return;
+    __shared__ double rows[(kTpThreads / kTpSums) * kTpSums];
+    const double s = tp_final_sum<kTpThreads, 2>(state, rows, (int)gridDim.x);
     if (threadIdx.x < 2) {
         state[threadIdx.x] = s;
         const double cnt = threadIdx.x == 0 ? (double)L : (double)L * (double)(numCh - 1);
@@ -1522,82 +1463,10 @@ __global__ __launch_bounds__(kTpThreads) void target_norm_kernel(const float *__
     if (threadIdx.x == 0) *counter = 0u;
 }
 
-__global__ __launch_bounds__(kTpThreads) void target_centre_kernel(int L, int numCh, int Lpad,
-                                                                   const float *__restrict__ tnorm,
-                                                                   double *__restrict__ aprime,
-                                                                   float *__restrict__ aprimeF,
-                                                                   double *__restrict__ state,
-                                                                   unsigned int *__restrict__ counter,
-                                                                   int *__restrict__ hflags, int numFiles,
-                                                                   TargetReport *report, unsigned long long seq)
+__global__ __launch_bounds__(kTpThreads) void target_centre_kernel(TargetCentreArgs a)
 {
-    __shared__ double red[(kTpThreads / 64) * kTpSums];
-    // elements in the order of the centred copies (q = channel * Lpad + frame, the padding included): the writes of
-    // a wave are contiguous, the reads gather from the 145 KB the kernel before left in the cache
-    const unsigned int n = (unsigned int)Lpad * (unsigned int)numCh;
-    const double meanT = state[2], meanS = state[3];
-    const unsigned int q0 = blockIdx.x * kTpTile + threadIdx.x;
-    float x[kTpPer];
-#pragma unroll
-    for (int k = 0; k < kTpPer; k++) {
-        const unsigned int q = q0 + k * kTpThreads;
-        const unsigned int c = q / (unsigned int)Lpad, i = q - c * (unsigned int)Lpad;
-        x[k] = q < n && i < (unsigned int)L ? tnorm[i * (unsigned int)numCh + c] : 0.0f;
-    }
-    // sum2 T/S, csum T/S, fsum T/S, fsq T/S, fsq1, count of values outside the half-precision range
-    double acc[kTpSums] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int k = 0; k < kTpPer; k++) {
-        const unsigned int q = q0 + k * kTpThreads;
-        if (q < n) {
-            const unsigned int c = q / (unsigned int)Lpad, i = q - c * (unsigned int)Lpad;
-            if (i < (unsigned int)L) {
-                const int g = c > 0;
-                const double v = (double)x[k] - (g ? meanS : meanT);  // ca(i) + aAdd, impl/MathUtil.scala:190
-                aprime[q] = v;
-                acc[g] += v * v;
-                acc[2 + g] += v;
-                if (!(fabs(v) <= 60000.0)) acc[9] += 1.0;  // (NaN counts as outside)
-                const float vf = (float)v;
-                aprimeF[q] = vf;
-                const double w = (double)vf;
-                acc[4 + g] += w;
-                acc[6 + g] += w * w;
-                if (c == 1) acc[8] += w * w;
-            } else {  // zero padding behind the target's last frame
-                aprime[q] = 0.0;
-                aprimeF[q] = 0.0f;
-            }
-        }
-    }
-    // the marks the screening kernels left per file for the previous target (bit 2; the range marks of the
-    // database's image, bit 1, stay)
-    for (long long f = (long long)blockIdx.x * kTpThreads + threadIdx.x; f < numFiles; f += (long long)gridDim.x * kTpThreads)
-        hflags[f] &= 1;
-    tp_wg_sums<kTpSums>(acc, red, state + 4 + (size_t)blockIdx.x * kTpSums);
-    if (!tp_last_workgroup(counter)) return;
-    __shared__ double fin[kTpSums];
-    __shared__ double rows[kTpRows * kTpSums];
-    const double total = tp_final_sum<kTpSums>(state, rows);
-    if (threadIdx.x < kTpSums) fin[threadIdx.x] = total;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        *counter = 0u;
-        report->sum1[0] = state[0];
-        report->sum1[1] = state[1];
-        report->sum2[0] = fin[0];
-        report->sum2[1] = fin[1];
-        report->csum[0] = fin[2];
-        report->csum[1] = fin[3];
-        report->fsum[0] = fin[4];
-        report->fsum[1] = fin[5];
-        report->fsq[0] = fin[6];
-        report->fsq[1] = fin[7];
-        report->fsq1 = fin[8];
-        report->inRange = fin[9] == 0.0 ? 1ull : 0ull;
-        __threadfence_system();
-        __hip_atomic_store(&report->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    target_centre_body<kTpThreads>((int)blockIdx.x, (int)gridDim.x, a.L, a.numCh, a.Lpad, a.tnorm, a.aprime, a.aprimeF,
+                                   a.state, a.counter, a.hflags, a.numFiles, a.report, a.seq);
 }
 
 // ---------------------------------------------------------------------------
@@ -1804,8 +1673,9 @@ int build_layout(sgz_context *ctx)
     ctx->h_nonfinite.assign((size_t)nf, 0);
     if (nf) {
         if ((rc = ensure(ctx, ctx->d_nonfinite, ctx->nonfinite_cap, (size_t)nf))) return rc;
-        hipLaunchKernelGGL(nonfinite_scan_kernel, dim3(nf), dim3(256), 0, ctx->stream, ctx->d_files, ctx->d_normtab,
-                           ctx->norm.enabled, ctx->numCh, ctx->d_nonfinite);
+        SGZ_HIP(ctx, hipMemsetAsync(ctx->d_nonfinite, 0, sizeof(int) * (size_t)nf, ctx->stream));
+        hipLaunchKernelGGL(nonfinite_scan_kernel, dim3((unsigned)nf * kScanParts), dim3(256), 0, ctx->stream, ctx->d_files,
+                           ctx->d_normtab, ctx->norm.enabled, ctx->numCh, ctx->d_nonfinite);
         SGZ_HIP(ctx, hipGetLastError());
         SGZ_HIP(ctx, hipMemcpyAsync(ctx->h_nonfinite.data(), ctx->d_nonfinite, sizeof(int) * (size_t)nf,
                                     hipMemcpyDeviceToHost, ctx->stream));
@@ -2127,7 +1997,7 @@ int sgz_corr_set_target(sgz_context *ctx, const float *frames, int num_frames, f
     // Kernels of the search before read the old target on `stream`, where the new one is written in order behind
     // them; the fp32 screening reads it on the other stream.  The previous target's kernel has finished with the
     // pinned frames (its report was waited for).
-    SGZ_HIP(ctx, hipStreamSynchronize(ctx->screen_stream));
+    if (ctx->screen_stream_used) SGZ_HIP(ctx, hipStreamSynchronize(ctx->screen_stream));
     if (stageBytes > ctx->tgt_stage_cap) {
         SGZ_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (a copy out of the old buffer may be on its way)
         if (ctx->h_tgt_stage) (void)hipHostFree(ctx->h_tgt_stage);
@@ -2146,7 +2016,8 @@ int sgz_corr_set_target(sgz_context *ctx, const float *frames, int num_frames, f
     const unsigned long long seq = ++ctx->tgt_seq;
     // (the report may sit at another offset than last time: the word the host polls must not hold this number yet)
     __atomic_store_n(&rep->seq, 0ull, __ATOMIC_RELEASE);
-    // (the second kernel runs over the padded copies: the larger grid sizes the buffer of partial sums)
+    // (the second pass runs over the padded copies, in workgroups of 256 threads or -- carried along by the launch
+    // that transforms the target -- of more: the larger grid sizes the buffer of partial sums)
     const int tpGridA = (int)((nTb + kTpTile - 1) / kTpTile), tpGrid = (int)((nAp + kTpTile - 1) / kTpTile);
     {
         const size_t need = (size_t)4 + (size_t)tpGrid * kTpSums + 1;
@@ -2164,10 +2035,6 @@ int sgz_corr_set_target(sgz_context *ctx, const float *frames, int num_frames, f
                        reinterpret_cast<const float *>(ctx->h_tgt_stage + offRaw), L, numCh, ctx->d_normtab,
                        ctx->norm.enabled, ctx->d_tnorm, ctx->d_tgt_state, tpCounter);
     SGZ_HIP(ctx, hipGetLastError());
-    hipLaunchKernelGGL(target_centre_kernel, dim3(tpGrid), dim3(kTpThreads), 0, ctx->stream, L, numCh, (int)Lpad,
-                       ctx->d_tnorm, ctx->d_aprime, ctx->d_aprime_f, ctx->d_tgt_state, tpCounter, ctx->d_hflags, nfMarks,
-                       rep, seq);
-    SGZ_HIP(ctx, hipGetLastError());
     CorrParams &cp = ctx->cp;
     const int oldL = ctx->have_target ? cp.L : -1;
     cp.numCh = numCh;
@@ -2180,10 +2047,29 @@ int sgz_corr_set_target(sgz_context *ctx, const float *frames, int num_frames, f
     cp.w = temporal_weight;
     cp.maxBoost = max_boost;
     ctx->aspec_dirty = true;
-    // the spectral kernel's transform of the target needs nothing of the report: queued right behind the
-    // preparation while the host waits for the scalars
+    TargetCentreArgs ca;
+    ca.L = L;
+    ca.numCh = numCh;
+    ca.Lpad = (int)Lpad;
+    ca.tnorm = ctx->d_tnorm;
+    ca.aprime = ctx->d_aprime;
+    ca.aprimeF = ctx->d_aprime_f;
+    ca.state = ctx->d_tgt_state;
+    ca.counter = tpCounter;
+    ca.hflags = ctx->d_hflags;
+    ca.numFiles = nfMarks;
+    ca.report = rep;
+    ca.seq = seq;
+    // Where the spectral kernel screens and the layout stays, the launch that transforms the target needs nothing of
+    // the report: it is queued now and carries the second pass along, so that the host's wait for the scalars, the
+    // centring and the transform overlap.
     const bool early = oldL == L && !ctx->layout_dirty && ctx->fg.N > 0;
-    if (early && (rc = fft_target_spectra(ctx, ctx->stream))) return rc;
+    if (early) {
+        if ((rc = fft_target_spectra(ctx, ctx->stream, &ca))) return rc;
+    } else {
+        hipLaunchKernelGGL(target_centre_kernel, dim3(tpGrid), dim3(kTpThreads), 0, ctx->stream, ca);
+        SGZ_HIP(ctx, hipGetLastError());
+    }
     {
         const auto t0 = std::chrono::steady_clock::now();
         bool arrived = false;
@@ -2232,10 +2118,13 @@ int sgz_corr_set_target(sgz_context *ctx, const float *frames, int num_frames, f
     ctx->half_stage_img = reinterpret_cast<uint16_t *>(ctx->h_tgt_stage + offImg);
     ctx->half_stage_halfwords = imgHalfwords;
     if ((rc = half_screen_set_target(ctx, finite))) return rc;
-    // (the fp32 screening runs on the other stream: it waits for the preparation)
-    if (!ctx->tgt_event) SGZ_HIP(ctx, hipEventCreateWithFlags(&ctx->tgt_event, hipEventDisableTiming));
-    SGZ_HIP(ctx, hipEventRecord(ctx->tgt_event, ctx->stream));
-    SGZ_HIP(ctx, hipStreamWaitEvent(ctx->screen_stream, ctx->tgt_event, 0));
+    // (the fp32 screening runs on the other stream: it waits for the preparation.  A context that has never run it
+    // -- every search over bounds -- is spared the two calls; the first such run waits for the stream itself.)
+    if (ctx->screen_stream_used) {
+        if (!ctx->tgt_event) SGZ_HIP(ctx, hipEventCreateWithFlags(&ctx->tgt_event, hipEventDisableTiming));
+        SGZ_HIP(ctx, hipEventRecord(ctx->tgt_event, ctx->stream));
+        SGZ_HIP(ctx, hipStreamWaitEvent(ctx->screen_stream, ctx->tgt_event, 0));
+    }
     if (oldL != L || hadHalf != (ctx->hg.S2 > 0)) ctx->layout_dirty = true;
     if (early && !ctx->layout_dirty) fft_target_ready(ctx);
     return SGZ_OK;
@@ -2328,6 +2217,11 @@ static int corr_run_impl(sgz_context *ctx, int file_begin, int file_end, int mod
     // (the matrix-core screening is compute bound like the exact kernel: nothing to gain from a second
     // stream, and its consumers on ctx->stream then need no cross-stream wait)
     hipStream_t stream = mode == kRunScreenF32 ? ctx->screen_stream : ctx->stream;
+    if (mode == kRunScreenF32 && !ctx->screen_stream_used) {
+        // the first run on the other stream: whatever the main stream holds of the target's preparation comes first
+        SGZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->screen_stream_used = true;
+    }
     // an earlier run over some of these files (possibly on the other stream) writes the same outputs
     for (auto &run : ctx->runs)
         if (run.fb < file_end && run.fe > file_begin && (rc = ctx->wait_for_run(run, stream))) return rc;

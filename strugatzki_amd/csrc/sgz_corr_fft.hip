@@ -49,11 +49,13 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "sgz_corr_dev.hpp"
 #include "sgz_fft_dev.hpp"
 #include "sgz_internal.hpp"
+#include "sgz_target_dev.hpp"
 
 using namespace sgz;
 
@@ -90,18 +92,35 @@ __device__ __forceinline__ float2 q16_decode(unsigned int q, float scale)
     return make_float2((float)(short)(q & 0xffffu) * scale, (float)((int)q >> 16) * scale);
 }
 
+// Largest value over the 64 lanes of a wave, the same in every lane afterwards: four steps inside the rows of 16
+// lanes and two across them on the cross-lane data path, the result taken from the last lane.  (Lanes without a
+// source in a step keep their own value.)
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ float dpp_max(float v)
+{
+    const int own = __float_as_int(v);
+    return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(own, own, kCtrl, kRowMask, 0xf, false)));
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+    v = dpp_max<0x111, 0xf>(v);  // row_shr:1
+    v = dpp_max<0x112, 0xf>(v);  // row_shr:2
+    v = dpp_max<0x114, 0xf>(v);  // row_shr:4
+    v = dpp_max<0x118, 0xf>(v);  // row_shr:8
+    v = dpp_max<0x142, 0xa>(v);  // row_bcast:15 -> rows 1 and 3
+    v = dpp_max<0x143, 0xc>(v);  // row_bcast:31 -> rows 2 and 3
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 // Rounds one band (the 64 bins of a wave, one per lane) to 16 bits: the band's scale is its largest component / 32767
 // (NaN when a component is not finite, so that the block's results come out as NaN like those of fp32 spectra; 0 when
 // the band is all but empty).  Returns the packed bin, adds the squared distance to `dq`.
 __device__ __forceinline__ unsigned int q16_encode_band(float2 v, float &scaleOut, float &dq)
 {
-    float mx = fmaxf(fabsf(v.x), fabsf(v.y));
-    int bad = !(fabsf(v.x) <= 3.0e38f) || !(fabsf(v.y) <= 3.0e38f);  // (fmaxf drops a NaN next to a number)
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-        bad |= __shfl_xor(bad, off, 64);
-    }
+    // (a component that is not finite counts as infinite: a maximum drops a NaN next to a number)
+    const bool fin = fabsf(v.x) <= 3.0e38f && fabsf(v.y) <= 3.0e38f;
+    const float mx = wave_max(fin ? fmaxf(fabsf(v.x), fabsf(v.y)) : INFINITY);
+    const bool bad = !(mx <= 3.0e38f);
     float scale = 0.0f, inv = 0.0f;
     if (mx >= 1.0e-30f) {
         scale = mx * (1.0f / 32767.0f);
@@ -216,24 +235,47 @@ __global__ __launch_bounds__(N / 16) void fft_spectra_kernel(const FileDesc *__r
 // transform's factor), packed like the database spectra.
 // Q16: as 16-bit integers like the database's (q16_encode_band), with the scales and per channel the squared
 // distance of what was stored to what was computed.
-template <int N, bool Q16>
+// FUSED: launched right behind the first pass of the target preparation, before the centred target exists: the
+// workgroups behind the channel pairs' carry out the centring pass (target_centre_body, whose report the host waits
+// for), while these form their centred values themselves from the normalised target and the means -- the same two
+// operations, so the same bits.
+template <int N, bool Q16, bool FUSED>
 __global__ __launch_bounds__(N / 16) void fft_target_kernel(const float *__restrict__ aprime, int Lpad, int L, int numCh,
                                                             const float2 *__restrict__ tab, float2 *__restrict__ aspec,
-                                                            float *__restrict__ ascale, float *__restrict__ tgtdq)
+                                                            float *__restrict__ ascale, float *__restrict__ tgtdq,
+                                                            TargetCentreArgs ca)
 {
     constexpr int T = N / 16, NH = N / 2;
     extern __shared__ __attribute__((aligned(16))) float2 buf[];
     __shared__ float red[16];
     const int tid = threadIdx.x;
+    const int numPairs = (numCh + 1) / 2;
+    if constexpr (FUSED) {
+        if ((int)blockIdx.x >= numPairs) {
+            target_centre_body<T>((int)blockIdx.x - numPairs, (int)gridDim.x - numPairs, ca.L, ca.numCh, ca.Lpad, ca.tnorm,
+                                  ca.aprime, ca.aprimeF, ca.state, ca.counter, ca.hflags, ca.numFiles, ca.report, ca.seq);
+            return;
+        }
+    }
     const int c0 = 2 * blockIdx.x, c1 = c0 + 1;
     const bool two = c1 < numCh;
+    double mean0 = 0.0, mean1 = 0.0;
+    if constexpr (FUSED) {
+        mean0 = c0 == 0 ? ca.state[2] : ca.state[3];
+        mean1 = ca.state[3];
+    }
 #pragma unroll 4
     for (int m = 0; m < 16; m++) {
         const int n = tid + m * T;
         float a = 0.0f, b = 0.0f;
         if (n < L) {
-            a = aprime[(size_t)c0 * Lpad + n];
-            if (two) b = aprime[(size_t)c1 * Lpad + n];
+            if constexpr (FUSED) {
+                a = (float)((double)ca.tnorm[(size_t)n * numCh + c0] - mean0);
+                if (two) b = (float)((double)ca.tnorm[(size_t)n * numCh + c1] - mean1);
+            } else {
+                a = aprime[(size_t)c0 * Lpad + n];
+                if (two) b = aprime[(size_t)c1 * Lpad + n];
+            }
         }
         buf[fft_phys(n)] = make_float2(a, b);
     }
@@ -668,12 +710,18 @@ double fft_eps(int N)
     return std::expm1(passes * std::log1p(40.0 * u)) * 1.01;
 }
 
+// Raises a kernel's limit of dynamic LDS where it needs more than the default 64 KB -- once per context and kernel
+// (the call costs microseconds, a search launches the same kernel every time; the size depends on the kernel's
+// template arguments only).
 template <typename K>
-int set_lds(const sgz_context *ctx, K kern, size_t bytes)
+int set_lds(sgz_context *ctx, K kern, size_t bytes)
 {
-    if (bytes > 64 * 1024)
-        SGZ_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)bytes));
+    if (bytes <= 64 * 1024) return SGZ_OK;
+    const void *key = reinterpret_cast<const void *>(kern);
+    for (const void *k : ctx->lds_attr_set)
+        if (k == key) return SGZ_OK;
+    SGZ_HIP(ctx, hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    ctx->lds_attr_set.push_back(key);
     return SGZ_OK;
 }
 
@@ -688,8 +736,10 @@ int ensure_tab(sgz_context *ctx)
     return SGZ_OK;
 }
 
-// The target's spectra (per target; N from the layout): one kernel on `stream`, reading the centred fp32 target.
-int fft_target_launch(sgz_context *ctx, hipStream_t stream)
+// The target's spectra (per target; N from the layout): one kernel on `stream`, reading the centred fp32 target --
+// or, with `centre`, launched behind the first pass of the target preparation and carrying its second pass along in
+// further workgroups (the centred target is not needed then).
+int fft_target_launch(sgz_context *ctx, hipStream_t stream, const TargetCentreArgs *centre)
 {
     FftGeom &fg = ctx->fg;
     const int N = fg.N, numCh = ctx->cp.numCh, L = ctx->cp.L;
@@ -703,17 +753,25 @@ int fft_target_launch(sgz_context *ctx, hipStream_t stream)
     }
     const size_t lds = sizeof(float2) * fft_lds_elems(N);
     const int Lpad = ctx->cp.S * kR;
+    const TargetCentreArgs ca = centre ? *centre : TargetCentreArgs{};
+    // the workgroups of the centring pass: N / 16 threads, four elements per thread
+    const int extra = centre ? (int)(((size_t)numCh * Lpad + (size_t)(N / 16) * kTpPer - 1) / ((size_t)(N / 16) * kTpPer)) : 0;
     auto launch = [&](auto kern) -> int {
         if ((rc = set_lds(ctx, kern, lds))) return rc;
-        hipLaunchKernelGGL(kern, dim3(numPairs), dim3(N / 16), lds, stream, ctx->d_aprime_f, Lpad, L, numCh, ctx->d_fft_tab,
-                           ctx->d_aspec, q16 ? ctx->d_aspecscale : nullptr, q16 ? ctx->d_tgtdq : nullptr);
+        hipLaunchKernelGGL(kern, dim3(numPairs + extra), dim3(N / 16), lds, stream, ctx->d_aprime_f, Lpad, L, numCh,
+                           ctx->d_fft_tab, ctx->d_aspec, q16 ? ctx->d_aspecscale : nullptr, q16 ? ctx->d_tgtdq : nullptr,
+                           ca);
         SGZ_HIP(ctx, hipGetLastError());
         return SGZ_OK;
     };
-    if (N == 4096) rc = q16 ? launch(fft_target_kernel<4096, true>) : launch(fft_target_kernel<4096, false>);
-    else if (N == 8192) rc = q16 ? launch(fft_target_kernel<8192, true>) : launch(fft_target_kernel<8192, false>);
-    else rc = q16 ? launch(fft_target_kernel<16384, true>) : launch(fft_target_kernel<16384, false>);
-    return rc;
+    auto pick = [&](auto n_) -> int {
+        constexpr int kN = decltype(n_)::value;
+        if (centre) return q16 ? launch(fft_target_kernel<kN, true, true>) : launch(fft_target_kernel<kN, false, true>);
+        return q16 ? launch(fft_target_kernel<kN, true, false>) : launch(fft_target_kernel<kN, false, false>);
+    };
+    if (N == 4096) return pick(std::integral_constant<int, 4096>{});
+    if (N == 8192) return pick(std::integral_constant<int, 8192>{});
+    return pick(std::integral_constant<int, 16384>{});
 }
 
 // The target-dependent factors of the error bound, from the target's statistics (host arithmetic).
@@ -749,7 +807,7 @@ void fft_target_factors(sgz_context *ctx)
 int fft_target(sgz_context *ctx, hipStream_t stream)
 {
     int rc;
-    if ((rc = fft_target_launch(ctx, stream))) return rc;
+    if ((rc = fft_target_launch(ctx, stream, nullptr))) return rc;
     fft_target_factors(ctx);
     ctx->aspec_dirty = false;
     return SGZ_OK;
@@ -759,7 +817,16 @@ int fft_target(sgz_context *ctx, hipStream_t stream)
 
 namespace sgz {
 
-int fft_target_spectra(sgz_context *ctx, hipStream_t stream) { return fft_target_launch(ctx, stream); }
+int fft_target_spectra(sgz_context *ctx, hipStream_t stream, const void *centre_args)
+{
+    return fft_target_launch(ctx, stream, static_cast<const TargetCentreArgs *>(centre_args));
+}
+
+int fft_target_centre_workgroups(const sgz_context *ctx, int numCh, int Lpad)
+{
+    const size_t per = (size_t)(ctx->fg.N / 16) * kTpPer;
+    return per ? (int)(((size_t)numCh * Lpad + per - 1) / per) : 0;
+}
 
 void fft_target_ready(sgz_context *ctx)
 {

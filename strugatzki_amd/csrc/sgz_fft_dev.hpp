@@ -8,8 +8,14 @@
 // A workgroup of N / 16 threads owns one radix-16 butterfly per thread and pass; all threads read, meet at a
 // barrier, write to the same buffer, meet again.
 //
-// Element i lives at fft_phys(i) = i + (i >> 4) (one 8-byte pad per 16 elements): the strided writes of the
-// first two passes (16 j + r, resp. 256 a + k + 16 r) then fall on distinct LDS banks.
+// Element i lives at fft_phys(i) = i ^ ((i >> 4) & 15): the four low bits are exchanged with those of the next
+// four.  An 8-byte LDS store is served in groups of 16 consecutive lanes over 32 banks of 4 bytes, an 8-byte load in
+// groups of 32 lanes over 64 banks: a group is free of conflicts when its elements' positions differ modulo 16 resp.
+// 32.  Loads and the last pass's stores touch consecutive elements (an aligned run of 16 stays a permutation of
+// itself); the strided stores of the radix-16 passes -- 16 j + r, 256 a + k + 16 r and 4096 a + k + 256 r over
+// consecutive j resp. k -- have a constant low digit or constant higher digits, and the exchange turns either into
+// 16 distinct positions.  (A pad of one element per 16 does the same for the stores but lets every aligned run
+// of 32 consecutive elements straddle 33 positions: one two-way conflict per group of every load.)
 //
 // The pieces are __host__ __device__ so that a host loop over "threads" runs the same index arithmetic and the
 // same fp32 operations (explicit fma, no contraction) as the kernels: sgz_fft_reference_host.
@@ -24,8 +30,8 @@ namespace sgz {
 
 constexpr int kFftTab = 16384;  // entries of the twiddle table == the largest transform
 
-__host__ __device__ constexpr int fft_phys(int i) { return i + (i >> 4); }
-__host__ __device__ constexpr int fft_lds_elems(int N) { return N + (N >> 4); }
+__host__ __device__ constexpr int fft_phys(int i) { return i ^ ((i >> 4) & 15); }
+__host__ __device__ constexpr int fft_lds_elems(int N) { return N; }
 
 __host__ __device__ inline float2 c_mul(float2 a, float2 b)
 {

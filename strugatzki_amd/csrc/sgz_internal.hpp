@@ -356,6 +356,8 @@ struct sgz_context {
     };
     std::vector<PinSlot> pin_pool;
     hipStream_t screen_stream = nullptr;     // screening runs (overlap with exact runs on `stream`)
+    bool screen_stream_used = false;         // a run has been queued there (until then nobody has to wait for it)
+    std::vector<const void *> lds_attr_set;  // kernels whose dynamic LDS limit has been raised (set_lds)
 
     // Kernel timing: a ring of event pairs, one pair per run (ev0 / ev1 = the pair of the latest run), so that
     // a caller can read the times of many runs after the fact instead of waiting on events between them.
@@ -400,7 +402,10 @@ int fft_screen_launch(sgz_context *ctx, int file_begin, int file_end, hipStream_
 void fft_screen_free(sgz_context *ctx);
 // A new target for the layout in force: its spectra can be queued before the host knows the target's statistics
 // (fft_target_spectra); once it does, fft_target_ready derives the error-bound factors and marks the spectra current.
-int fft_target_spectra(sgz_context *ctx, hipStream_t stream);
+// centre_args (a sgz::TargetCentreArgs, or null): the launch carries the second pass of the target preparation along,
+// in fft_target_centre_workgroups() further workgroups, and forms its own input from the normalised target.
+int fft_target_spectra(sgz_context *ctx, hipStream_t stream, const void *centre_args);
+int fft_target_centre_workgroups(const sgz_context *ctx, int numCh, int Lpad);
 void fft_target_ready(sgz_context *ctx);
 // Fills in the boosts the spectral kernel left out for files [file_begin, file_end) (kernels on `stream`);
 // *launched tells whether there was anything to do.

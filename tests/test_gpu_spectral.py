@@ -100,6 +100,38 @@ def test_bounds_enclose_the_oracle(spectral, monkeypatch, L, n, extra):
     assert [(g.sim, g.file, g.start, g.stop) for g in got] == [(w.sim, w.file, w.start, w.stop) for w in want]
 
 
+@pytest.mark.parametrize("n", [4096, 8192, 16384])
+def test_a_new_target_for_a_resident_database(spectral, monkeypatch, n):
+    """A query service sets a target per search.  With the layout in place the launch that transforms the new target
+    also carries the second pass of its preparation (centring, statistics): the statistics must be the bits the
+    stand-alone preparation gives (first target, no layout yet), and every search must return the oracle's matches."""
+    import strugatzki_amd as S
+    ctx = spectral
+    monkeypatch.setenv("SGZ_FFT_N", str(n))
+    L, nf, frames = 700, 5, 6000
+    starts = [20, 900, 1800, 20]
+    tfile = O.synth_file(SEED, -1, 2600, NUM_CH)
+    db = synth_db(nf, frames)
+    for k, ts in enumerate(starts[:3]):  # a copy of every target somewhere
+        db[k + 1][500 + 300 * k:500 + 300 * k + L] = tfile[ts:ts + L] * np.float32(0.97) + \
+            db[k + 1][500 + 300 * k:500 + 300 * k + L] * np.float32(0.03)
+    norms = norms_default()
+    _load(ctx, db, norms)
+    first_stats = None
+    for ts in starts:
+        ctx.corr_set_target(tfile[ts:ts + L], 0.5, 8.0)
+        stats = ctx.corr_target_stats()
+        if ts == starts[0]:
+            if first_stats is None:
+                first_stats = stats      # prepared before any layout existed
+            else:
+                assert np.array_equal(stats, first_stats)  # the same target again, now beside its transform
+        want, _, _ = O.correlation_run(corr_config(ts, L, num_matches=3), tfile, norms, db, dense=False)
+        got = S.search(ctx, S.SearchParams(3, 1, 0, STEP))
+        assert ctx.screen_kernel_in_use == "spectral" and ctx.screen_geometry[0] == n
+        assert [(g.sim, g.file, g.start, g.stop) for g in got] == [(w.sim, w.file, w.start, w.stop) for w in want]
+
+
 @pytest.mark.parametrize("weight", [0.0, 1.0, 0.25])
 def test_weights(spectral, weight):
     """temporalWeight 0 and 1 leave one channel group out (impl/FeatureCorrelationImpl.scala:201-206)."""

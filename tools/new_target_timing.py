@@ -36,6 +36,18 @@ with S.Context(0) as ctx:
     for i in range(n):
         S.search(ctx, p)
     t2 = time.perf_counter()
+    # the two calls of a query apart (host time of each: the target call returns when the device has reported the
+    # target's statistics, the search when its matches are there)
+    a = b = 0.0
+    for i in range(n):
+        q0 = time.perf_counter()
+        ctx.corr_set_target(tgts[i % 16], 0.5, 8.0)
+        q1 = time.perf_counter()
+        S.search(ctx, p)
+        q2 = time.perf_counter()
+        a += q1 - q0
+        b += q2 - q1
+    print(f"in a query: set_target {1e3 * a / n:.4f} ms, search {1e3 * b / n:.4f} ms", flush=True)
     t3 = time.perf_counter()
     for i in range(n):
         ctx.corr_set_target(tgts[i % 16], 0.5, 8.0)
