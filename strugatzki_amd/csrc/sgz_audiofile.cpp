@@ -285,6 +285,41 @@ AudioData readNext(Reader &r, PcmData *raw)
     return a;
 }
 
+// IRCAM / BICSF: a 1024-byte header -- magic 0x64 0xA3 <machine> 0x00, sample rate (fp32), channels (int32), sample
+// encoding (int32: 0x00002 16-bit, 0x40004 32-bit integers, 0x00004 32-bit floats), then optional code blocks -- and the
+// samples behind it; machine 1 (VAX) and 3 (MIPS) are little endian, 2 (Sun) and 4 (NeXT) big endian.  The frame
+// count is what the file holds behind the header.
+AudioData readIrcam(Reader &r, PcmData *raw)
+{
+    const bool big = r.d[2] == 2 || r.d[2] == 4;
+    auto u32 = [&](size_t at) {
+        const unsigned char *b = r.d.data() + at;
+        return big ? ((uint32_t)b[0] << 24) | ((uint32_t)b[1] << 16) | ((uint32_t)b[2] << 8) | b[3]
+                   : ((uint32_t)b[3] << 24) | ((uint32_t)b[2] << 16) | ((uint32_t)b[1] << 8) | b[0];
+    };
+    if (r.d.size() < 1024) throw Error(SGZ_E_IO, "bad IRCAM header: " + r.path);
+    const uint32_t rateBits = u32(4), ch = u32(8), enc = u32(12);
+    float rate;
+    std::memcpy(&rate, &rateBits, 4);
+    AudioData a;
+    a.numChannels = (int)ch;
+    a.sampleRate = (double)rate;
+    int bits;
+    Fmt fmt = Fmt::Int;
+    switch (enc) {
+        case 0x00002: bits = 16; break;
+        case 0x40004: bits = 32; break;
+        case 0x00004: bits = 32; fmt = Fmt::Float32; break;
+        default: throw Error(SGZ_E_IO, "unsupported IRCAM encoding in " + r.path);
+    }
+    if (a.numChannels < 1) throw Error(SGZ_E_IO, "bad IRCAM header: " + r.path);
+    const size_t fb = (size_t)a.numChannels * (bits / 8);
+    a.numFrames = (int64_t)((r.d.size() - 1024) / fb);
+    const size_t count = (size_t)a.numFrames * a.numChannels;
+    if (count) takeSamples(r, a, 1024, count, bits, fmt, big, false, raw);
+    return a;
+}
+
 void checkData(const AudioData &a)
 {
     if (a.numChannels < 1 || a.numFrames < 0 || a.frames.size() != (size_t)a.numFrames * a.numChannels)
@@ -311,6 +346,7 @@ AudioData readAny(const std::string &path, PcmData *raw)
     if (magic == "FORM") return readAiff(r, raw);
     if (magic == "RIFF") return readWav(r, raw);
     if (magic == ".snd" && r.d.size() >= 24) return readNext(r, raw);
+    if (r.d[0] == 0x64 && r.d[1] == 0xA3 && r.d[2] >= 1 && r.d[2] <= 4 && r.d[3] == 0) return readIrcam(r, raw);
     throw Error(SGZ_E_IO, "unknown audio file format: " + path);
 }
 
@@ -395,13 +431,40 @@ void writeFloatNext(const std::string &path, const AudioData &a)
     writeAll(path, o);
 }
 
+// IRCAM, 32-bit float, big endian (machine code 2: what the JVM's big-endian writers and libsndfile's default
+// produce); the header ends with an empty code block and zeros.  The reference writes this type through its audio
+// file library, whose header details are not part of its sources: this is the published layout.
+void writeFloatIrcam(const std::string &path, const AudioData &a)
+{
+    checkData(a);
+    std::vector<unsigned char> o;
+    auto be32 = [&](uint32_t v) {
+        for (int s = 24; s >= 0; s -= 8) o.push_back((unsigned char)(v >> s));
+    };
+    o.insert(o.end(), {0x64, 0xA3, 0x02, 0x00});
+    const float rate = (float)a.sampleRate;
+    uint32_t rateBits;
+    std::memcpy(&rateBits, &rate, 4);
+    be32(rateBits);
+    be32((uint32_t)a.numChannels);
+    be32(0x00004);
+    o.resize(1024, 0);  // (code 0 = end of the code blocks)
+    for (size_t i = 0; i < a.frames.size(); i++) {
+        uint32_t u;
+        std::memcpy(&u, &a.frames[i], 4);
+        be32(u);
+    }
+    writeAll(path, o);
+}
+
 // `type`: the logical names of the reference's AudioFileType ids, as CrossSimilarity's <outputType> holds them
 void writeFloatAudio(const std::string &path, const AudioData &a, const std::string &type)
 {
     if (type == "aiff") writeFloatAiff(path, a);
     else if (type == "wav" || type == "wave") writeFloatWave(path, a);
     else if (type == "next" || type == "au") writeFloatNext(path, a);
-    else throw Error(SGZ_E_ARG, "output type '" + type + "' cannot be written (aiff, wav and next can)");
+    else if (type == "ircam") writeFloatIrcam(path, a);
+    else throw Error(SGZ_E_ARG, "output type '" + type + "' cannot be written (aiff, wav, next and ircam can)");
 }
 
 void writeFloatAiff(const std::string &path, const AudioData &a)

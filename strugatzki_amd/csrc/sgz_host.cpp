@@ -465,8 +465,9 @@ int selfSimilarityRows(sgz_context *ctx, const SelfSimilarityConfig &cfg, int xB
 void runCrossSimilarity(sgz_context *ctx, const CrossSimilarityConfig &cfg, const Observer &obs)
 {
     if (!ctx) throw Error(SGZ_E_ARG, "null context");
-    if (cfg.audioOutputType != "aiff" && cfg.audioOutputType != "wav" && cfg.audioOutputType != "next")
-        throw Error(SGZ_E_ARG, "outputType '" + cfg.audioOutputType + "' cannot be written (aiff, wav and next can)");
+    if (cfg.audioOutputType != "aiff" && cfg.audioOutputType != "wav" && cfg.audioOutputType != "next" &&
+        cfg.audioOutputType != "ircam")
+        throw Error(SGZ_E_ARG, "outputType '" + cfg.audioOutputType + "' cannot be written (aiff, wav, next and ircam can)");
     const FeatureExtractionConfig e1 = FeatureExtractionConfig::fromXMLFile(cfg.metaInput1);
     const FeatureExtractionConfig e2 = FeatureExtractionConfig::fromXMLFile(cfg.metaInput2);
     if (e1.fftSize != e2.fftSize || e1.fftOverlap != e2.fftOverlap || e1.numCoeffs != e2.numCoeffs)  // :39-41

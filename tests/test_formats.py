@@ -81,7 +81,23 @@ def test_float_wave_and_next_writers_against_independent_readers(tmp_path):
     magic, off, size, enc, rate, ch = struct.unpack(">4sIIIII", d[:24])
     assert (magic, enc, rate, ch, size) == (b".snd", 6, 86, 2, x.size * 4)
     assert np.array_equal(np.frombuffer(d[off:], dtype=">f4").astype(np.float32).reshape(x.shape), x)
-    assert lib.sgz_write_float_audio(str(tmp_path / "o.x").encode(), b"ircam", N.ptr(x), 50, 2, 86.0) == N.SGZ_E_ARG
+    # IRCAM / BICSF: 1024-byte header (magic, fp32 rate, channels, encoding 4 = fp32), big-endian floats behind it
+    path = str(tmp_path / "o.sf")
+    assert lib.sgz_write_float_audio(path.encode(), b"ircam", N.ptr(x), x.shape[0], x.shape[1], 86.1328125) == 0
+    d = open(path, "rb").read()
+    assert d[:4] == bytes([0x64, 0xA3, 0x02, 0x00]) and len(d) == 1024 + x.size * 4
+    rate, ch, enc = struct.unpack(">fII", d[4:16])
+    assert (rate, ch, enc) == (86.1328125, 2, 4) and not any(d[16:1024])
+    assert np.array_equal(np.frombuffer(d[1024:], dtype=">f4").astype(np.float32).reshape(x.shape), x)
+    back, rate = P.read_audio_file(path)
+    assert rate == 86.1328125 and np.array_equal(back, x)
+    # ... and a little-endian one as a VAX-flavoured writer leaves it, 16-bit integers
+    y = (rng.integers(-30000, 30000, size=(40, 1))).astype("<i2")
+    le = bytes([0x64, 0xA3, 0x01, 0x00]) + struct.pack("<fII", 44100.0, 1, 2) + bytes(1008) + y.tobytes()
+    open(str(tmp_path / "le.sf"), "wb").write(le)
+    back, rate = P.read_audio_file(str(tmp_path / "le.sf"))
+    assert rate == 44100.0 and np.array_equal(back[:, 0], y[:, 0].astype(np.float32) / np.float32(32768.0))
+    assert lib.sgz_write_float_audio(str(tmp_path / "o.x").encode(), b"raw", N.ptr(x), 50, 2, 86.0) == N.SGZ_E_ARG
 
 
 def test_secs_to_frames_is_the_references_rounding():

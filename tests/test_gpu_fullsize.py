@@ -14,6 +14,18 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pytestmark = pytest.mark.gpu
 
 
+def _bounds_enclose_exact_everywhere(ctx, nf, windows_per_file):
+    """The screening kernel's upper bound of every window of every file against the exact kernel's similarity of
+    that window (fp64, every window): never below it, and never far above."""
+    ctx.corr_run_screen_f16(0, nf)
+    up = np.concatenate([s for s, _ in ctx.corr_read_dense_range(0, nf)])
+    ctx.corr_run(0, nf)
+    ex = np.concatenate([s for s, _ in ctx.corr_read_dense_range(0, nf)])
+    assert up.shape == ex.shape == (nf * windows_per_file,)
+    d = up.astype(np.float64) - ex
+    assert np.isfinite(d).all() and d.min() >= 0.0 and d.max() < 5e-3
+
+
 def test_config3_search_30s_target_vs_10h_database():
     """120 files x 300 s, 30 s target, top-10 (the benchmark workload): the planted copies come back in noise
     order at their offsets, through the search over bounds and through the general path; the bounds of the
@@ -47,15 +59,8 @@ def test_config3_search_30s_target_vs_10h_database():
         general = S.search(ctx, S.SearchParams(nm, 1, 0, STEP, screen_head=False))
         assert [(m.file, m.start, m.stop, m.sim, m.boost_in) for m in general] == \
                [(m.file, m.start, m.stop, m.sim, m.boost_in) for m in fast]
-        # bounds vs the exact kernel on three whole files
-        ctx.corr_run_screen_f16(0, 3)
-        up = [ctx.corr_read_dense(f)[0] for f in range(3)]
-        ctx.corr_run(0, 3)
-        for f in range(3):
-            ex = ctx.corr_read_dense(f)[0]
-            assert ex.shape[0] == frames - L + 1
-            d = up[f].astype(np.float64) - ex
-            assert d.min() >= 0.0 and d.max() < 5e-3
+        # bounds vs the exact kernel on every window of every file
+        _bounds_enclose_exact_everywhere(ctx, nf, frames - L + 1)
         # one matched window against the oracle (a single window: file cut to L frames)
         m = fast[3]
         raw = ctx.db_read_file(m.file)[m.start // STEP:m.start // STEP + L]
@@ -100,15 +105,8 @@ def test_config5_one_rank_shard_60s_target_1500_files():
         assert key(general) == key(fast) == key(exact)
         assert [m.sim for m in general] == [m.sim for m in fast]
         assert all(abs(a.sim - b.sim) <= 1e-5 for a, b in zip(exact, fast))
-        # bounds vs the exact kernel on whole files from both ends of the shard
-        for f0 in (0, nf - 2):
-            ctx.corr_run_screen_f16(f0, f0 + 2)
-            up = [ctx.corr_read_dense(f)[0] for f in (f0, f0 + 1)]
-            ctx.corr_run(f0, f0 + 2)
-            for k, f in enumerate((f0, f0 + 1)):
-                ex = ctx.corr_read_dense(f)[0]
-                d = up[k].astype(np.float64) - ex
-                assert ex.shape[0] == frames - L + 1 and d.min() >= 0.0 and d.max() < 5e-3
+        # bounds vs the exact kernel on every window of every file of the shard
+        _bounds_enclose_exact_everywhere(ctx, nf, frames - L + 1)
         # one matched window against the oracle (a single window: file cut to L frames)
         m = fast[6]
         raw = ctx.db_read_file(m.file)[m.start // STEP:m.start // STEP + L]

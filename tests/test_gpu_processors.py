@@ -200,14 +200,15 @@ def test_cross_similarity_from_files(ctx, tmp_path, swap):
     assert int(np.argmax(got[:, 0])) == int(np.argmax(want))
     assert seen and seen[-1] == 1.0
     # the other output types the reference's <outputType> can name (CrossSimilarity.scala:55, 213)
-    for typ, name in (("wav", "xsim.wav"), ("next", "xsim.au")):
+    for typ, name in (("wav", "xsim.wav"), ("next", "xsim.au"), ("ircam", "xsim.sf")):
         out2 = os.path.join(d, name)
         P.CrossSimilarity.run(ctx, P.CrossSimilarity.Config(d, cfg.metaInput1, cfg.metaInput2, out2, typ, cfg.span1,
                                                             cfg.span2, 0.5, True, 8.0))
         got2, rate2 = P.read_audio_file(out2)
-        assert np.array_equal(got2, got) and rate2 == round(RATE)  # (these formats hold an integer rate)
+        # (wave and next hold an integer rate, ircam a single-precision one)
+        assert np.array_equal(got2, got) and rate2 == (float(np.float32(RATE)) if typ == "ircam" else round(RATE))
     with pytest.raises(P.N.NativeError):
-        P.CrossSimilarity.run(ctx, P.CrossSimilarity.Config(d, m_short, m_long, out, "ircam"))
+        P.CrossSimilarity.run(ctx, P.CrossSimilarity.Config(d, m_short, m_long, out, "raw"))
 
 
 def test_feature_stats(ctx, tmp_path):
