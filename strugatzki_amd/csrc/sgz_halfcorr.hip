@@ -210,6 +210,21 @@ struct SelfSimArgs {
     struct SelfSimSeq *seqList;
     unsigned int seqCap;
     int forceSeq;  // test knob: every listed pixel goes that way
+    // selfsim_tile16_kernel: the gathered windows as two half-precision parts per value, [group of 8 values][column]
+    // in 16-byte units (the temporal group's kgT groups first, then the other channels' kgS), and what the parts
+    // leave out per window
+    const uint4 *hi1, *lo1, *hi2, *lo2;
+    const struct SelfSimSplit *sp1, *sp2;
+    int kgT, kgS;
+    int doT, doS;  // channel groups with a weight (the reference skips a group whose weight is 0)
+};
+
+// Per window and channel group: how its shifted values v went into two half-precision parts, v 2^e ~ hi + lo.
+struct SelfSimSplit {
+    float rho;   // Euclidean norm of v - (hi + lo) 2^-e over the window, rounded up
+    float lam;   // Euclidean norm of lo 2^-e, rounded up
+    float sq;    // Euclidean norm of v, rounded up
+    int exp2;    // e
 };
 
 struct SelfSimSeq {
@@ -428,6 +443,342 @@ __global__ __launch_bounds__(256, 2) void selfsim_tile_kernel(SelfSimArgs g)
             if (g.wantSim) g.simOut[(long long)py * g.imgExt + px] = sim;
             if (g.imgOut)
                 g.imgOut[(long long)(g.imgExt - 1 - py) * g.imgExt + px] = gray_color(sim, g.warp, g.scale, g.inv);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// The same matrix on the half-precision matrix cores (v_mfma_f32_32x32x16_f16: sixteen products per instruction
+// and row, sixteen times the rate of the fp32 instruction).  A stored value v (fp32, shifted by its window's mean
+// level) is multiplied by a power of two 2^e of its window -- the one that puts the window's largest magnitude
+// just below 2^14 -- and cut into two half-precision parts, hi = half(v 2^e) and lo = half(v 2^e - hi); then
+//     sum va vb  =  2^-(ea + eb) [ sum hi_a hi_b  +  sum (hi_a lo_b + lo_a hi_b) ]  +  rest,
+//     |rest| <= |lo_a| |lo_b| + rho_a |v_b| + rho_b |v_a| + rho_a rho_b      (Euclidean norms over the window)
+// where rho is what the two parts leave of v -- not estimated: selfsim_gather_split_kernel measures it, and |lo|,
+// per window (SelfSimSplit).  Products of half-precision numbers are exact in fp32.  The first sum is accumulated
+// in fp32 over runs of 64 products that are folded into fp64, as the fp32 kernel does (its bound of a run:
+// 67 2^-24 sqrt(Qa Qb)); the second, 2^-11 of it, stays in fp32 over the whole window, and its roundings weigh
+// 2^-11 as much: five more units of 2^-24 cover it.  A pixel for which all that could move the similarity by more
+// than 8e-6 is evaluated by correlate_half_dev instead, as before.
+// Both channel groups in one launch: the temporal group first, its similarities wait in registers while the other
+// channels' products are formed, one epilogue, one trip of the result to memory.
+// Workgroup = 128 x 128 pixels, 8 waves of 64 (x) x 32 (y) pixels each = 2 matrix-core tiles; a stage holds 32
+// products of both sides and both parts: [side][part][group of 8 products][128 columns][16 bytes] = 32 KB, two
+// stages, filled by buffer loads that write the LDS directly.
+// ---------------------------------------------------------------------------
+constexpr int kSfThreads = 512;
+constexpr int kSfStageBytes = 2 * 2 * 4 * kSsTile * 16;
+typedef _Float16 ss_half8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned int ss_pack_halves(_Float16 a, _Float16 b)
+{
+    unsigned short ua, ub;
+    __builtin_memcpy(&ua, &a, 2);
+    __builtin_memcpy(&ub, &b, 2);
+    return (unsigned int)ua | ((unsigned int)ub << 16);
+}
+
+// Window w -> its column of the two parts' images, its statistics (as selfsim_gather_kernel) and its SelfSimSplit.
+__global__ __launch_bounds__(256) void selfsim_gather_split_kernel(const float *__restrict__ x, long long frames,
+                                                                   int numCh, int afStart, int H, int decim, int imgExt,
+                                                                   long long stride, int kgT, int kgS,
+                                                                   uint4 *__restrict__ hi, uint4 *__restrict__ lo,
+                                                                   SelfSimStat *__restrict__ stats,
+                                                                   SelfSimSplit *__restrict__ split)
+{
+    const long long w = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (w >= stride) return;
+    const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+    if (w >= imgExt) {
+        for (long long kg = 0; kg < (long long)kgT + kgS; kg++) {
+            hi[kg * stride + w] = zero;
+            lo[kg * stride + w] = zero;
+        }
+        return;
+    }
+    const long long f0 = (long long)afStart + w * decim;
+    for (int group = 0; group < 2; group++) {
+        const int c0 = group == 0 ? 0 : 1, c1 = group == 0 ? 1 : numCh;
+        const long long kg0 = group == 0 ? 0 : kgT;
+        const int kgN = group == 0 ? kgT : kgS;
+        double sum = 0.0;
+        for (int c = c0; c < c1; c++)
+            for (int k = 0; k < H; k++) sum += (double)x[(long long)c * frames + f0 + k];
+        const double cnt = (double)(c1 - c0) * H;
+        float mu = (float)(sum / cnt);
+        if (!(fabsf(mu) < 3.0e38f)) mu = 0.0f;
+        float mx = 0.0f;
+        bool bad = false;
+        for (int c = c0; c < c1; c++)
+            for (int k = 0; k < H; k++) {
+                const float a = fabsf(x[(long long)c * frames + f0 + k] - mu);
+                bad |= !(a <= 3.0e38f);
+                mx = fmaxf(mx, a);
+            }
+        int e = 0;
+        if (!bad && mx > 0.0f) {
+            int ex;
+            (void)frexpf(mx, &ex);  // mx = m 2^ex, 0.5 <= m < 1
+            e = 14 - ex;            // mx 2^e in [2^13, 2^14)
+        }
+        double S = 0.0, Q = 0.0, R = 0.0, Lm = 0.0;
+        unsigned int ph[4] = {0u, 0u, 0u, 0u}, pl[4] = {0u, 0u, 0u, 0u};
+        _Float16 hprev = (_Float16)0.0f, lprev = (_Float16)0.0f;
+        int idx = 0;
+        for (int c = c0; c < c1; c++)
+            for (int k = 0; k < H; k++, idx++) {
+                const float v = x[(long long)c * frames + f0 + k] - mu;
+                S += (double)v;
+                Q = fma((double)v, (double)v, Q);
+                const float vs = ldexpf(v, e);
+                const _Float16 h = (_Float16)vs;
+                const float d1 = vs - (float)h;
+                const _Float16 l = (_Float16)d1;
+                const float r = d1 - (float)l;
+                R = fma((double)r, (double)r, R);
+                Lm = fma((double)(float)l, (double)(float)l, Lm);
+                const int j = idx & 7;
+                if (j & 1) {
+                    ph[j >> 1] = ss_pack_halves(hprev, h);
+                    pl[j >> 1] = ss_pack_halves(lprev, l);
+                } else {
+                    hprev = h;
+                    lprev = l;
+                }
+                if (j == 7) {
+                    hi[(kg0 + (idx >> 3)) * stride + w] = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+                    lo[(kg0 + (idx >> 3)) * stride + w] = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+                    ph[0] = ph[1] = ph[2] = ph[3] = pl[0] = pl[1] = pl[2] = pl[3] = 0u;
+                }
+            }
+        int kg = idx >> 3;
+        if (idx & 7) {  // the last, partly filled group (an odd count leaves one value waiting)
+            if (idx & 1) {
+                ph[(idx & 7) >> 1] = ss_pack_halves(hprev, (_Float16)0.0f);
+                pl[(idx & 7) >> 1] = ss_pack_halves(lprev, (_Float16)0.0f);
+            }
+            hi[(kg0 + kg) * stride + w] = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+            lo[(kg0 + kg) * stride + w] = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+            kg++;
+        }
+        for (; kg < kgN; kg++) {
+            hi[(kg0 + kg) * stride + w] = zero;
+            lo[(kg0 + kg) * stride + w] = zero;
+        }
+        SelfSimStat st;
+        st.S = S;
+        st.Q = Q;
+        st.mu = (double)mu;
+        st.SR = S + cnt * (double)mu;
+        st.QR = Q + 2.0 * (double)mu * S + cnt * (double)mu * (double)mu;
+        st.pad = 0.0;
+        stats[2 * w + group] = st;
+        SelfSimSplit sp;
+        sp.rho = (float)(ldexp(sqrt(R), -e) * 1.0001);
+        sp.lam = (float)(ldexp(sqrt(Lm), -e) * 1.0001);
+        sp.sq = (float)(sqrt(Q) * 1.0001);
+        sp.exp2 = e;
+        split[2 * w + group] = sp;
+    }
+}
+
+// Similarity of one pixel's channel group from the product sum of the parts (already divided by the two windows'
+// powers of two) and the windows' statistics, or the mark for the exact evaluation: selfsim_pixel with the error
+// terms of the header comment.  (ra, rb: 1e-7 of the windows' raw sums of squares, the guard of the fp64
+// cancellation as there.)
+__device__ __forceinline__ float selfsim_pixel16(double Sa, double mua, double SaR, double QaR, float sqa, float rhoa,
+                                                 float lama, float ra, double mub, double SbR, double QbR, float sqb,
+                                                 float rhob, float lamb, float rb, double pSum, double inv2n,
+                                                 float unsure)
+{
+    const double S = SaR + SbR;
+    const double s2 = S * S * inv2n;
+    const double varsum = (QaR + QbR) - s2;
+    const double cross2 = 2.0 * (fma(mua, SbR, fma(mub, Sa, pSum))) - s2;  // twice the centred product sum
+    const float v = (float)varsum;
+    constexpr float kAcc = 72.0f * 5.9604645e-8f;  // (64 + 3 + 5) 2^-24
+    const float err = fmaf(kAcc * sqa, sqb, fmaf(lama, lamb, fmaf(rhoa, sqb, fmaf(rhob, sqa, rhoa * rhob))));
+    // 2 err <= 8e-6 varsum (both tests fail for NaN as well)
+    const bool sure = err * 1.0001f <= 4.0e-6f * v && ra + rb <= v;
+    return sure ? (float)cross2 / v : unsure;
+}
+
+__global__ __launch_bounds__(kSfThreads, 2) void selfsim_tile16_kernel(SelfSimArgs g)
+{
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    const int super = (slot >> 6) * 8 + xcd, within = slot & 63;
+    const int tileX = (super % g.superEdge) * 8 + (within & 7), tileY = (super / g.superEdge) * 8 + (within >> 3);
+    if (tileY < tileX || tileY >= g.tilesEdge) return;  // pixels with y >= x only (:127-163); the rest is mirrored
+    __shared__ __align__(16) unsigned char ldsRaw[2 * kSfStageBytes];
+    float *lds = reinterpret_cast<float *>(ldsRaw);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, q = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wx = q & 1, wy = q >> 1, l32 = lane & 31, lhi = lane >> 5;
+    const int X0 = tileX * kSsTile, Y0 = tileY * kSsTile;
+    const int H = g.H;
+    typedef float v16f __attribute__((ext_vector_type(16)));
+    constexpr int kRow = kSsTile + 1;
+    const float kUnsure = __int_as_float(0x7fc0beef);  // marks a pixel for the exact evaluation
+    // behind the similarities of half a tile (64 rows): the statistics of the tile's 128 + 128 windows
+    double *stS = reinterpret_cast<double *>(lds + 64 * kRow), *stMu = stS + 2 * kSsTile, *stSR = stMu + 2 * kSsTile,
+           *stQR = stSR + 2 * kSsTile, *stF = stQR + 2 * kSsTile;
+    float *stSq = reinterpret_cast<float *>(stF + 2 * kSsTile), *stRho = stSq + 2 * kSsTile, *stLam = stRho + 2 * kSsTile,
+          *stR7 = stLam + 2 * kSsTile;
+    static_assert((64 * kRow) % 2 == 0 && (64 * kRow + (10 + 4) * 2 * kSsTile) * 4 <= 2 * kSfStageBytes,
+                  "similarities and statistics must fit the stages' memory");
+    float simv[2][16];  // the temporal group's part, later the pixel's similarity
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int v = 0; v < 16; v++) simv[i][v] = 0.0f;
+
+    for (int group = g.doT ? 0 : 1; group < (g.doS ? 2 : 1); group++) {
+        const int nkg = group == 0 ? g.kgT : g.kgS;  // groups of 8 products: a multiple of 4
+        const long long kg0 = group == 0 ? 0 : g.kgT;
+        const int n = H * (group == 0 ? 1 : g.numCh - 1);
+        const unsigned bytes = (unsigned)(((long long)(nkg - 1) * g.stride + kSsTile) * 16);
+        const __amdgpu_buffer_rsrc_t rs[4] = {
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(g.hi1 + kg0 * g.stride + X0), 0, bytes, 0x00020000),
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(g.lo1 + kg0 * g.stride + X0), 0, bytes, 0x00020000),
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(g.hi2 + kg0 * g.stride + Y0), 0, bytes, 0x00020000),
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(g.lo2 + kg0 * g.stride + Y0), 0, bytes, 0x00020000)};
+        // a stage = 16 rows of 2 KB ([side][part][group of 8]); a wave instruction moves half a row
+        auto stage = [&](int s0, int buf) {
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int piece = q * 4 + t, row = piece >> 1, hc = piece & 1;
+                const unsigned off = (unsigned)((((long long)(s0 + (row & 3))) * g.stride + 64 * hc + lane) * 16);
+                ss_lds_void *to = (ss_lds_void *)(ldsRaw + buf * kSfStageBytes + row * 2048 + hc * 1024);
+                switch (row >> 2) {
+                case 0: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[0], to, 16, off, 0, 0, 0); break;
+                case 1: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[1], to, 16, off, 0, 0, 0); break;
+                case 2: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[2], to, 16, off, 0, 0, 0); break;
+                default: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[3], to, 16, off, 0, 0, 0); break;
+                }
+            }
+        };
+        v16f accM[2], accX[2];
+        double sum[2][16];
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int v = 0; v < 16; v++) {
+                accM[i][v] = 0.0f;
+                accX[i][v] = 0.0f;
+                sum[i][v] = 0.0;
+            }
+        __syncthreads();  // (whatever read the LDS before -- the first group's statistics -- is done)
+        stage(0, 0);
+        int buf = 0;
+        for (int s0 = 0; s0 < nkg; s0 += 4, buf ^= 1) {
+            // every direct-to-LDS load of this wave has to have landed before the barrier lets other waves read the
+            // stage (the compiler only waits for what this wave's own reads may touch): vmcnt(0)
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            __syncthreads();  // everyone is done with the other stage
+            if (s0 + 4 < nkg) stage(s0 + 4, buf ^ 1);
+            const unsigned char *st = ldsRaw + buf * kSfStageBytes;
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                const int kgl = 2 * ks + lhi;
+                const ss_half8 bH = *reinterpret_cast<const ss_half8 *>(st + (8 + kgl) * 2048 + (32 * wy + l32) * 16);
+                const ss_half8 bL = *reinterpret_cast<const ss_half8 *>(st + (12 + kgl) * 2048 + (32 * wy + l32) * 16);
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    const ss_half8 aH = *reinterpret_cast<const ss_half8 *>(st + kgl * 2048 + (64 * wx + 32 * i + l32) * 16);
+                    const ss_half8 aL = *reinterpret_cast<const ss_half8 *>(st + (4 + kgl) * 2048 + (64 * wx + 32 * i + l32) * 16);
+                    accM[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aH, bH, accM[i], 0, 0, 0);
+                    accX[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aH, bL, accX[i], 0, 0, 0);
+                    accX[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aL, bH, accX[i], 0, 0, 0);
+                }
+            }
+            if ((s0 & 4) == 0 && s0 + 4 < nkg) continue;  // fold after every second stage (64 products) and the last
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int v = 0; v < 16; v++) {
+                    sum[i][v] += (double)accM[i][v];
+                    accM[i][v] = 0.0f;
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int v = 0; v < 16; v++) sum[i][v] += (double)accX[i][v];
+
+        // the group's similarities: statistics of the tile's windows (indices past the end clamped: those pixels
+        // are never written) into LDS, then every thread its 32 pixels
+        __syncthreads();
+        if (tid < 2 * kSsTile) {
+            const int wdw = min((tid < kSsTile ? X0 + tid : Y0 + tid - kSsTile), g.imgExt - 1);
+            const SelfSimStat st = (tid < kSsTile ? g.st1 : g.st2)[2 * (long long)wdw + group];
+            const SelfSimSplit sp = (tid < kSsTile ? g.sp1 : g.sp2)[2 * (long long)wdw + group];
+            stS[tid] = st.S;
+            stMu[tid] = st.mu;
+            stSR[tid] = st.SR;
+            stQR[tid] = st.QR;
+            stF[tid] = ldexp(1.0, -sp.exp2);
+            stSq[tid] = sp.sq;
+            stRho[tid] = sp.rho;
+            stLam[tid] = sp.lam;
+            stR7[tid] = (float)(1.0e-7 * st.QR);
+        }
+        __syncthreads();
+        const double inv2n = 1.0 / (2.0 * (double)n);
+        const int c0 = group == 0 ? 0 : 1, c1 = group == 0 ? 1 : g.numCh;
+        const float wThis = group == 0 ? g.wT : 1.0f - g.wT;
+        const int pyl = 32 * wy + l32, yb = kSsTile + pyl, py = Y0 + pyl;
+        const double mub = stMu[yb], SbR = stSR[yb], QbR = stQR[yb], fb = stF[yb];
+        const float sqb = stSq[yb], rhob = stRho[yb], lamb = stLam[yb], rb = stR7[yb];
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int v = 0; v < 16; v++) {
+                const int pxl = 64 * wx + 32 * i + 8 * (v >> 2) + 4 * lhi + (v & 3), px = X0 + pxl;
+                float part = selfsim_pixel16(stS[pxl], stMu[pxl], stSR[pxl], stQR[pxl], stSq[pxl], stRho[pxl], stLam[pxl],
+                                             stR7[pxl], mub, SbR, QbR, sqb, rhob, lamb, rb, sum[i][v] * stF[pxl] * fb,
+                                             inv2n, kUnsure);
+                if (__float_as_int(part) == __float_as_int(kUnsure)) {
+                    part = 0.0f;
+                    if (px < g.imgExt && py < g.imgExt && py >= px)
+                        part = correlate_half_exact(g.x1, g.frames1, (long long)g.afStart + (long long)px * g.decim, g.x2,
+                                                    g.frames2, (long long)g.afStart + (long long)py * g.decim, H, c0, c1);
+                }
+                // sim = temporal * w + spectral * (1 - w), impl/SelfSimilarityImpl.scala:146
+                const float term = part * wThis;
+                simv[i][v] = (group == 0 || !g.doT) ? term : simv[i][v] + term;
+            }
+    }
+
+    // Out, half a tile at a time through LDS (row rho of the staging area = pixel row 64 (rho / 32) + 32 half +
+    // rho % 32 of the tile) so that the rows of the matrix and of its mirror image are written by neighbouring lanes.
+    for (int half = 0; half < 2; half++) {
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < 16; v++) {
+            const int rowInTile = 8 * (v >> 2) + 4 * lhi + (v & 3);
+            lds[(32 * wx + rowInTile) * kRow + 32 * wy + l32] = half == 0 ? simv[0][v] : simv[1][v];
+        }
+        __syncthreads();
+        const int XH = X0 + 32 * half;
+        // rows of the matrix: neighbouring lanes = neighbouring y
+        for (int idx = tid; idx < 64 * kSsTile; idx += kSfThreads) {
+            const int pxl = idx >> 7, pyl = idx & (kSsTile - 1);
+            const int px = XH + 64 * (pxl >> 5) + (pxl & 31), py = Y0 + pyl;
+            if (px >= g.imgExt || py >= g.imgExt || py < px) continue;
+            const float sim = lds[pxl * kRow + pyl];
+            if (g.keepUpper) g.simOut[(long long)px * g.imgExt + py] = sim;
+            // (the raster's row is imgExt - 1 - y: of the two pixels that show this value, the one whose
+            // neighbours along y lie in the same row)
+            if (g.imgOut) g.imgOut[(long long)(g.imgExt - 1 - px) * g.imgExt + py] = gray_color(sim, g.warp, g.scale, g.inv);
+        }
+        // rows of the mirror image: neighbouring lanes = neighbouring x
+        for (int idx = tid; idx < 64 * kSsTile; idx += kSfThreads) {
+            const int pxl = idx & 63, pyl = idx >> 6;
+            const int px = XH + 64 * (pxl >> 5) + (pxl & 31), py = Y0 + pyl;
+            if (px >= g.imgExt || py >= g.imgExt || py <= px) continue;
+            const float sim = lds[pxl * kRow + pyl];
+            if (g.wantSim) g.simOut[(long long)py * g.imgExt + px] = sim;
+            if (g.imgOut) g.imgOut[(long long)(g.imgExt - 1 - py) * g.imgExt + px] = gray_color(sim, g.warp, g.scale, g.inv);
         }
     }
 }
@@ -800,24 +1151,44 @@ static int selfsim_impl(sgz_context *ctx, const float *frames1, int64_t num_fram
     const bool doT = temporal_weight > 0.0f, doS = temporal_weight < 1.0f || !doT;
     if (sim_out || img_out || keep_sim || (doT && doS)) SGZ_HIP(ctx, hipMalloc(&simd.p, pix * sizeof(float)));
     if (img_out) SGZ_HIP(ctx, hipMalloc(&imgd.p, pix * sizeof(int32_t)));
-    DevBuf st1, st2, cols1, cols2;
+    DevBuf st1, st2, cols1, cols2, hi1, lo1, hi2, lo2, sp1, sp2;
     const unsigned gt = (unsigned)((img_ext + kSsTile - 1) / kSsTile);
     const long long stride = (long long)gt * kSsTile;
-    const size_t colFloats = (size_t)num_channels * half_win * (size_t)stride;
+    // groups of 8 products per channel group, padded to whole stages of 32 products
+    const long long kgT = ((long long)half_win + 31) / 32 * 4, kgS = ((long long)(num_channels - 1) * half_win + 31) / 32 * 4;
+    // The half-precision matrix cores take it unless a plane of the windows' parts would pass the 4 GB a buffer
+    // descriptor's 32-bit offsets reach (windows of several minutes): then the fp32 kernel, one pass per group.
+    bool split16 = std::max(kgT, kgS) * stride * 16 < (1ll << 32);
+    if (const char *e = std::getenv("SGZ_SELFSIM_KERNEL")) {  // test knob: "f32" forces the fp32 kernel
+        if (std::strcmp(e, "f32") == 0) split16 = false;
+    }
     SGZ_HIP(ctx, hipMalloc(&st1.p, 2 * (size_t)stride * sizeof(SelfSimStat)));
-    SGZ_HIP(ctx, hipMalloc(&cols1.p, colFloats * sizeof(float)));
     const unsigned gs = (unsigned)((stride + 255) / 256);
-    hipLaunchKernelGGL(selfsim_gather_kernel, dim3(gs), dim3(256), 0, ctx->stream, (const float *)p1.p,
-                       (long long)num_frames1, num_channels, af_start, half_win, decim, img_ext, stride,
-                       (float *)cols1.p, (SelfSimStat *)st1.p);
-    SGZ_HIP(ctx, hipGetLastError());
+    const size_t colFloats = (size_t)num_channels * half_win * (size_t)stride;
+    const size_t planeBytes = (size_t)(kgT + kgS) * (size_t)stride * 16;
+    auto gather = [&](const void *planar, long long nframes, DevBuf &st, DevBuf &cols, DevBuf &hi, DevBuf &lo,
+                      DevBuf &sp) -> int {
+        if (split16) {
+            SGZ_HIP(ctx, hipMalloc(&hi.p, planeBytes));
+            SGZ_HIP(ctx, hipMalloc(&lo.p, planeBytes));
+            SGZ_HIP(ctx, hipMalloc(&sp.p, 2 * (size_t)stride * sizeof(SelfSimSplit)));
+            hipLaunchKernelGGL(selfsim_gather_split_kernel, dim3(gs), dim3(256), 0, ctx->stream, (const float *)planar,
+                               nframes, num_channels, af_start, half_win, decim, img_ext, stride, (int)kgT, (int)kgS,
+                               (uint4 *)hi.p, (uint4 *)lo.p, (SelfSimStat *)st.p, (SelfSimSplit *)sp.p);
+        } else {
+            SGZ_HIP(ctx, hipMalloc(&cols.p, colFloats * sizeof(float)));
+            hipLaunchKernelGGL(selfsim_gather_kernel, dim3(gs), dim3(256), 0, ctx->stream, (const float *)planar, nframes,
+                               num_channels, af_start, half_win, decim, img_ext, stride, (float *)cols.p,
+                               (SelfSimStat *)st.p);
+        }
+        SGZ_HIP(ctx, hipGetLastError());
+        return SGZ_OK;
+    };
+    int grc;
+    if ((grc = gather(p1.p, (long long)num_frames1, st1, cols1, hi1, lo1, sp1))) return grc;
     if (!same) {
         SGZ_HIP(ctx, hipMalloc(&st2.p, 2 * (size_t)stride * sizeof(SelfSimStat)));
-        SGZ_HIP(ctx, hipMalloc(&cols2.p, colFloats * sizeof(float)));
-        hipLaunchKernelGGL(selfsim_gather_kernel, dim3(gs), dim3(256), 0, ctx->stream, (const float *)p2.p,
-                           (long long)num_frames2, num_channels, af_start, half_win, decim, img_ext, stride,
-                           (float *)cols2.p, (SelfSimStat *)st2.p);
-        SGZ_HIP(ctx, hipGetLastError());
+        if ((grc = gather(p2.p, (long long)num_frames2, st2, cols2, hi2, lo2, sp2))) return grc;
     }
     SelfSimArgs a;
     a.x1 = (const float *)p1.p;
@@ -828,6 +1199,16 @@ static int selfsim_impl(sgz_context *ctx, const float *frames1, int64_t num_fram
     a.cols2 = (const float *)(same ? cols1.p : cols2.p);
     a.st1 = (const SelfSimStat *)st1.p;
     a.st2 = (const SelfSimStat *)(same ? st1.p : st2.p);
+    a.hi1 = (const uint4 *)hi1.p;
+    a.lo1 = (const uint4 *)lo1.p;
+    a.hi2 = (const uint4 *)(same ? hi1.p : hi2.p);
+    a.lo2 = (const uint4 *)(same ? lo1.p : lo2.p);
+    a.sp1 = (const SelfSimSplit *)sp1.p;
+    a.sp2 = (const SelfSimSplit *)(same ? sp1.p : sp2.p);
+    a.kgT = (int)kgT;
+    a.kgS = (int)kgS;
+    a.doT = doT ? 1 : 0;
+    a.doS = doS ? 1 : 0;
     a.stride = stride;
     a.numCh = num_channels;
     a.afStart = af_start;
@@ -880,7 +1261,14 @@ static int selfsim_impl(sgz_context *ctx, const float *frames1, int64_t num_fram
         a.seqCount = reinterpret_cast<unsigned int *>(seqd.p);
         a.seqList = reinterpret_cast<SelfSimSeq *>(seqd.p) + 1;
     }
-    if (doT) {
+    if (split16) {
+        a.c0 = a.c1 = a.first = 0;
+        a.last = 1;
+        a.wThis = 0.0f;
+        hipLaunchKernelGGL(selfsim_tile16_kernel, dim3(gridWGs), dim3(kSfThreads), 0, ctx->stream, a);
+        SGZ_HIP(ctx, hipGetLastError());
+    }
+    if (!split16 && doT) {
         a.c0 = 0;
         a.c1 = 1;
         a.first = 1;
@@ -889,7 +1277,7 @@ static int selfsim_impl(sgz_context *ctx, const float *frames1, int64_t num_fram
         hipLaunchKernelGGL(selfsim_tile_kernel, dim3(gridWGs), dim3(256), 0, ctx->stream, a);
         SGZ_HIP(ctx, hipGetLastError());
     }
-    if (doS) {
+    if (!split16 && doS) {
         a.c0 = 1;
         a.c1 = num_channels;
         a.first = doT ? 0 : 1;

@@ -55,14 +55,19 @@ def test_segmentation_window_longer_than_span_gives_one_value(ctx, normalize):
 @pytest.mark.parametrize("decim,corr_len,warp,ceil,inv", [(1, 4 * STEP, 1.0, 1.0, False), (3, 8 * STEP, 0.5, 0.8, True),
                                                          (2, 44100, 2.0, 1.0, False), (1, 6 * STEP, 1.0, 0.004, False),
                                                          (1, 2 * STEP, 0.05, 1.0, True)])
-def test_selfsim_matrix_and_image(ctx, decim, corr_len, warp, ceil, inv):
+@pytest.mark.parametrize("kernel,tw", [("split16", 0.5), ("f32", 0.5), ("split16", 0.0), ("split16", 1.0)])
+def test_selfsim_matrix_and_image(ctx, monkeypatch, decim, corr_len, warp, ceil, inv, kernel, tw):
+    """Both tile kernels (products of half-precision pairs with measured residuals; plain fp32, SGZ_SELFSIM_KERNEL=f32)
+    and the one-group cases (temporal weight 0 or 1: the other channel group is not read)."""
     frames = _frames(260)
     norms = norms_default()
-    cfg = O.SelfSimConfig(0, 0, 0, 0, corr_len, decim, 0.5, 0, warp, ceil, int(inv), 1, STEP, NUM_CH - 1)
+    cfg = O.SelfSimConfig(0, 0, 0, 0, corr_len, decim, tw, 0, warp, ceil, int(inv), 1, STEP, NUM_CH - 1)
     ext, d, af_start, _ = O.selfsim_geometry(cfg, frames.shape[0], frames.shape[0])
     want_sim, want_img = O.selfsim_run(cfg, frames, None, norms)
     H = O.full_to_feat(corr_len, STEP)
-    sim, img = ctx.selfsim(frames, None, norms, af_start, H, d, ext, 0.5, 0, warp, ceil, inv)
+    if kernel == "f32":
+        monkeypatch.setenv("SGZ_SELFSIM_KERNEL", "f32")
+    sim, img = ctx.selfsim(frames, None, norms, af_start, H, d, ext, tw, 0, warp, ceil, inv)
     np.testing.assert_allclose(sim, want_sim, rtol=0, atol=1e-5)
     assert np.array_equal(sim, sim.T)
     assert np.array_equal(img, want_img)  # pixels are integer work: bit-exact
