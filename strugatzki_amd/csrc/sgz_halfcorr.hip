@@ -100,10 +100,14 @@ __global__ __launch_bounds__(256) void segm_kernel(const float *__restrict__ x, 
 }
 
 // Gray colour functions of impl/SelfSimilarityImpl.scala:99-107 on v = pow(max(0, sim), warp) * scale (:150).
-__device__ int gray_color(float sim, double warp, float scale, int inv)
+// (a call, not inline code: the power function is some hundred instructions, and the tile kernels evaluate the colour
+// map in loops that have to be unrolled)
+__device__ __noinline__ float gray_warp(float m0, double warp) { return (float)pow((double)m0, warp); }
+
+__device__ __forceinline__ int gray_color(float sim, double warp, float scale, int inv)
 {
     const float m0 = (sim != sim) ? sim : (sim > 0.0f ? sim : 0.0f);
-    const float v = (warp == 1.0 ? m0 : (float)pow((double)m0, warp)) * scale;  // pow(x, 1) == x
+    const float v = (warp == 1.0 ? m0 : gray_warp(m0, warp)) * scale;  // pow(x, 1) == x
     const float s = inv ? (1.0f - v) : v;
     const double d = (double)(s * 255) + 0.5;
     int i;
@@ -585,11 +589,12 @@ __global__ __launch_bounds__(256) void selfsim_gather_split_kernel(const float *
 // Similarity of one pixel's channel group from the product sum of the parts (already divided by the two windows'
 // powers of two) and the windows' statistics, or the mark for the exact evaluation: selfsim_pixel with the error
 // terms of the header comment.  (ra, rb: 1e-7 of the windows' raw sums of squares, the guard of the fp64
-// cancellation as there.)
+// cancellation as there.)  `bound`: how far the returned similarity can be from the exact quotient because of the
+// product sum's error -- at most 8e-6, for most pixels about half of that.
 __device__ __forceinline__ float selfsim_pixel16(double Sa, double mua, double SaR, double QaR, float sqa, float rhoa,
                                                  float lama, float ra, double mub, double SbR, double QbR, float sqb,
                                                  float rhob, float lamb, float rb, double pSum, double inv2n,
-                                                 float unsure)
+                                                 float unsure, float &bound)
 {
     const double S = SaR + SbR;
     const double s2 = S * S * inv2n;
@@ -600,8 +605,15 @@ __device__ __forceinline__ float selfsim_pixel16(double Sa, double mua, double S
     const float err = fmaf(kAcc * sqa, sqb, fmaf(lama, lamb, fmaf(rhoa, sqb, fmaf(rhob, sqa, rhoa * rhob))));
     // 2 err <= 8e-6 varsum (both tests fail for NaN as well)
     const bool sure = err * 1.0001f <= 4.0e-6f * v && ra + rb <= v;
+    bound = 2.0003f * err * __builtin_amdgcn_rcpf(v);
     return sure ? (float)cross2 / v : unsure;
 }
+
+// What the fp32 quotient, the conversions before it and the weighted sum of the two groups add to a similarity's
+// error, with room to spare (each is a rounding or two of a value below 1).
+constexpr float kSsMixErr = 2.0e-6f;
+constexpr int kSfErrBytes = 32 * kSfThreads * 4;  // the first group's error bounds: a float per pixel
+constexpr int kSfHits = 4096;                     // uncertain pixels a tile collects before it appends them one by one
 
 __global__ __launch_bounds__(kSfThreads, 2) void selfsim_tile16_kernel(SelfSimArgs g)
 {
@@ -609,9 +621,13 @@ __global__ __launch_bounds__(kSfThreads, 2) void selfsim_tile16_kernel(SelfSimAr
     const int super = (slot >> 6) * 8 + xcd, within = slot & 63;
     const int tileX = (super % g.superEdge) * 8 + (within & 7), tileY = (super / g.superEdge) * 8 + (within >> 3);
     if (tileY < tileX || tileY >= g.tilesEdge) return;  // pixels with y >= x only (:127-163); the rest is mirrored
-    __shared__ __align__(16) unsigned char ldsRaw[2 * kSfStageBytes];
+    extern __shared__ __align__(16) unsigned char ldsRaw[];  // two stages, then kSfErrBytes
+    __shared__ int hitCount;
+    __shared__ unsigned long long hitBase;
     float *lds = reinterpret_cast<float *>(ldsRaw);
+    float *errLds = reinterpret_cast<float *>(ldsRaw + 2 * kSfStageBytes);  // [pixel of the thread][thread]
     const int tid = threadIdx.x;
+    if (tid == 0) hitCount = 0;  // (the loop below has barriers before anybody counts)
     const int lane = tid & 63, q = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wx = q & 1, wy = q >> 1, l32 = lane & 31, lhi = lane >> 5;
     const int X0 = tileX * kSsTile, Y0 = tileY * kSsTile;
@@ -624,9 +640,12 @@ __global__ __launch_bounds__(kSfThreads, 2) void selfsim_tile16_kernel(SelfSimAr
            *stQR = stSR + 2 * kSsTile, *stF = stQR + 2 * kSsTile;
     float *stSq = reinterpret_cast<float *>(stF + 2 * kSsTile), *stRho = stSq + 2 * kSsTile, *stLam = stRho + 2 * kSsTile,
           *stR7 = stLam + 2 * kSsTile;
-    static_assert((64 * kRow) % 2 == 0 && (64 * kRow + (10 + 4) * 2 * kSsTile) * 4 <= 2 * kSfStageBytes,
-                  "similarities and statistics must fit the stages' memory");
-    float simv[2][16];  // the temporal group's part, later the pixel's similarity
+    // behind the statistics: the tile's uncertain pixels (x | y << 8 within the tile)
+    int *hits = reinterpret_cast<int *>(stR7 + 2 * kSsTile);
+    static_assert((64 * kRow) % 2 == 0 && (64 * kRow + (10 + 4) * 2 * kSsTile + kSfHits) * 4 <= 2 * kSfStageBytes,
+                  "similarities, statistics and the uncertain pixels must fit the stages' memory");
+    // the temporal group's part, later the pixel's similarity -- or, where only the raster is asked for, its colour
+    float simv[2][16];
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -729,24 +748,59 @@ __global__ __launch_bounds__(kSfThreads, 2) void selfsim_tile16_kernel(SelfSimAr
         const int pyl = 32 * wy + l32, yb = kSsTile + pyl, py = Y0 + pyl;
         const double mub = stMu[yb], SbR = stSR[yb], QbR = stQR[yb], fb = stF[yb];
         const float sqb = stSq[yb], rhob = stRho[yb], lamb = stLam[yb], rb = stR7[yb];
+        const bool both = g.doT && g.doS, lastGroup = group == (g.doS ? 1 : 0);
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
             for (int v = 0; v < 16; v++) {
                 const int pxl = 64 * wx + 32 * i + 8 * (v >> 2) + 4 * lhi + (v & 3), px = X0 + pxl;
+                float bound;
                 float part = selfsim_pixel16(stS[pxl], stMu[pxl], stSR[pxl], stQR[pxl], stSq[pxl], stRho[pxl], stLam[pxl],
                                              stR7[pxl], mub, SbR, QbR, sqb, rhob, lamb, rb, sum[i][v] * stF[pxl] * fb,
-                                             inv2n, kUnsure);
+                                             inv2n, kUnsure, bound);
+                const bool inside = px < g.imgExt && py < g.imgExt && py >= px;
                 if (__float_as_int(part) == __float_as_int(kUnsure)) {
                     part = 0.0f;
-                    if (px < g.imgExt && py < g.imgExt && py >= px)
+                    bound = 0.0f;  // (the reference's own value)
+                    if (inside)
                         part = correlate_half_exact(g.x1, g.frames1, (long long)g.afStart + (long long)px * g.decim, g.x2,
                                                     g.frames2, (long long)g.afStart + (long long)py * g.decim, H, c0, c1);
                 }
                 // sim = temporal * w + spectral * (1 - w), impl/SelfSimilarityImpl.scala:146
                 const float term = part * wThis;
-                simv[i][v] = (group == 0 || !g.doT) ? term : simv[i][v] + term;
+                const float sim = (group == 0 || !g.doT) ? term : simv[i][v] + term;
+                simv[i][v] = sim;
+                // The gray level is integer work: it is certain when both ends of the similarity's error interval map
+                // to the same level (the colour map is monotonic); the other pixels are listed for
+                // selfsim_fix_kernel, which evaluates them as the reference does.  (Only where a raster is asked for.)
+                if (g.fixList && !lastGroup) errLds[(16 * i + v) * kSfThreads + tid] = bound * wThis;
+                if (g.fixList && lastGroup) {
+                    float e = fmaf(bound, wThis, kSsMixErr);
+                    if (both) e += errLds[(16 * i + v) * kSfThreads + tid];
+                    const int cLo = gray_color(sim - e, g.warp, g.scale, g.inv), cHi = gray_color(sim + e, g.warp, g.scale, g.inv);
+                    if (!g.wantSim) simv[i][v] = __int_as_float(cLo);
+                    if (cLo != cHi && inside) {
+                        const int mine = atomicAdd(&hitCount, 1);
+                        if (mine < kSfHits) {
+                            hits[mine] = pxl | (pyl << 8);
+                        } else {
+                            const unsigned long long slot = atomicAdd(g.fixCount, 1ull);
+                            if (slot < (unsigned long long)g.fixCap) g.fixList[slot] = make_int2(px, py);
+                        }
+                    }
+                }
             }
+    }
+    if (g.fixList) {  // the tile's uncertain pixels: one place in the list for all of them
+        __syncthreads();
+        const int n = min(hitCount, kSfHits);
+        if (n > 0) {
+            if (tid == 0) hitBase = atomicAdd(g.fixCount, (unsigned long long)n);
+            __syncthreads();
+            for (int i = tid; i < n; i += kSfThreads)
+                if (hitBase + (unsigned long long)i < (unsigned long long)g.fixCap)
+                    g.fixList[hitBase + (unsigned long long)i] = make_int2(X0 + (hits[i] & 255), Y0 + (hits[i] >> 8));
+        }
     }
 
     // Out, half a tile at a time through LDS (row rho of the staging area = pixel row 64 (rho / 32) + 32 half +
@@ -765,11 +819,13 @@ __global__ __launch_bounds__(kSfThreads, 2) void selfsim_tile16_kernel(SelfSimAr
             const int pxl = idx >> 7, pyl = idx & (kSsTile - 1);
             const int px = XH + 64 * (pxl >> 5) + (pxl & 31), py = Y0 + pyl;
             if (px >= g.imgExt || py >= g.imgExt || py < px) continue;
-            const float sim = lds[pxl * kRow + pyl];
-            if (g.keepUpper) g.simOut[(long long)px * g.imgExt + py] = sim;
+            const float sim = lds[pxl * kRow + pyl];  // (the colour, where no similarities are asked for)
+            if (g.wantSim) g.simOut[(long long)px * g.imgExt + py] = sim;
             // (the raster's row is imgExt - 1 - y: of the two pixels that show this value, the one whose
             // neighbours along y lie in the same row)
-            if (g.imgOut) g.imgOut[(long long)(g.imgExt - 1 - px) * g.imgExt + py] = gray_color(sim, g.warp, g.scale, g.inv);
+            if (g.imgOut)
+                g.imgOut[(long long)(g.imgExt - 1 - px) * g.imgExt + py] =
+                    g.wantSim ? gray_color(sim, g.warp, g.scale, g.inv) : __float_as_int(sim);
         }
         // rows of the mirror image: neighbouring lanes = neighbouring x
         for (int idx = tid; idx < 64 * kSsTile; idx += kSfThreads) {
@@ -778,7 +834,9 @@ __global__ __launch_bounds__(kSfThreads, 2) void selfsim_tile16_kernel(SelfSimAr
             if (px >= g.imgExt || py >= g.imgExt || py <= px) continue;
             const float sim = lds[pxl * kRow + pyl];
             if (g.wantSim) g.simOut[(long long)py * g.imgExt + px] = sim;
-            if (g.imgOut) g.imgOut[(long long)(g.imgExt - 1 - py) * g.imgExt + px] = gray_color(sim, g.warp, g.scale, g.inv);
+            if (g.imgOut)
+                g.imgOut[(long long)(g.imgExt - 1 - py) * g.imgExt + px] =
+                    g.wantSim ? gray_color(sim, g.warp, g.scale, g.inv) : __float_as_int(sim);
         }
     }
 }
@@ -1149,8 +1207,6 @@ static int selfsim_impl(sgz_context *ctx, const float *frames1, int64_t num_fram
     const size_t pix = (size_t)img_ext * img_ext;
     // the reference skips a group whose weight is 0 (:143-145)
     const bool doT = temporal_weight > 0.0f, doS = temporal_weight < 1.0f || !doT;
-    if (sim_out || img_out || keep_sim || (doT && doS)) SGZ_HIP(ctx, hipMalloc(&simd.p, pix * sizeof(float)));
-    if (img_out) SGZ_HIP(ctx, hipMalloc(&imgd.p, pix * sizeof(int32_t)));
     DevBuf st1, st2, cols1, cols2, hi1, lo1, hi2, lo2, sp1, sp2;
     const unsigned gt = (unsigned)((img_ext + kSsTile - 1) / kSsTile);
     const long long stride = (long long)gt * kSsTile;
@@ -1162,6 +1218,10 @@ static int selfsim_impl(sgz_context *ctx, const float *frames1, int64_t num_fram
     if (const char *e = std::getenv("SGZ_SELFSIM_KERNEL")) {  // test knob: "f32" forces the fp32 kernel
         if (std::strcmp(e, "f32") == 0) split16 = false;
     }
+    // (the fp32 kernel keeps its first group's part and, for the list of uncertain pixels, the finished half with
+    // y >= x in the matrix; the half-precision one needs it only when the caller wants the matrix)
+    if (sim_out || keep_sim || (!split16 && (img_out || (doT && doS)))) SGZ_HIP(ctx, hipMalloc(&simd.p, pix * sizeof(float)));
+    if (img_out) SGZ_HIP(ctx, hipMalloc(&imgd.p, pix * sizeof(int32_t)));
     SGZ_HIP(ctx, hipMalloc(&st1.p, 2 * (size_t)stride * sizeof(SelfSimStat)));
     const unsigned gs = (unsigned)((stride + 255) / 256);
     const size_t colFloats = (size_t)num_channels * half_win * (size_t)stride;
@@ -1265,7 +1325,11 @@ static int selfsim_impl(sgz_context *ctx, const float *frames1, int64_t num_fram
         a.c0 = a.c1 = a.first = 0;
         a.last = 1;
         a.wThis = 0.0f;
-        hipLaunchKernelGGL(selfsim_tile16_kernel, dim3(gridWGs), dim3(kSfThreads), 0, ctx->stream, a);
+        a.keepUpper = a.wantSim;
+        constexpr int ldsBytes = 2 * kSfStageBytes + kSfErrBytes;
+        SGZ_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(selfsim_tile16_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, ldsBytes));
+        hipLaunchKernelGGL(selfsim_tile16_kernel, dim3(gridWGs), dim3(kSfThreads), ldsBytes, ctx->stream, a);
         SGZ_HIP(ctx, hipGetLastError());
     }
     if (!split16 && doT) {
@@ -1287,8 +1351,10 @@ static int selfsim_impl(sgz_context *ctx, const float *frames1, int64_t num_fram
         SGZ_HIP(ctx, hipGetLastError());
     }
     if (img_out) {
-        hipLaunchKernelGGL(selfsim_list_kernel, dim3(gt * gt), dim3(256), 0, ctx->stream, a);
-        SGZ_HIP(ctx, hipGetLastError());
+        if (!split16) {  // (the half-precision kernel lists its uncertain pixels itself)
+            hipLaunchKernelGGL(selfsim_list_kernel, dim3(gt * gt), dim3(256), 0, ctx->stream, a);
+            SGZ_HIP(ctx, hipGetLastError());
+        }
         hipLaunchKernelGGL(selfsim_fix_kernel, dim3(2048), dim3(256), 0, ctx->stream, a, (const int2 *)a.fixList,
                            (const unsigned long long *)a.fixCount, 0ll);
         SGZ_HIP(ctx, hipGetLastError());
