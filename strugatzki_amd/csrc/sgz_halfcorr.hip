@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -214,21 +215,14 @@ struct SelfSimArgs {
     struct SelfSimSeq *seqList;
     unsigned int seqCap;
     int forceSeq;  // test knob: every listed pixel goes that way
-    // selfsim_tile16_kernel: the gathered windows as two half-precision parts per value, [group of 8 values][column]
-    // in 16-byte units (the temporal group's kgT groups first, then the other channels' kgS), and what the parts
+    float slack;   // test knob: added to every pixel's error bound by selfsim_tile8_kernel (more uncertain pixels)
+    // selfsim_tile8_kernel: the gathered windows as three 8-bit digits per value, [digit][unit of 16 values][column]
+    // in 16-byte units (the temporal group's kgT units first, then the other channels' kgS), and what the digits
     // leave out per window
-    const uint4 *hi1, *lo1, *hi2, *lo2;
-    const struct SelfSimSplit *sp1, *sp2;
+    const uint4 *limbs1, *limbs2;
+    const struct SelfSimLimbs *sp1, *sp2;
     int kgT, kgS;
     int doT, doS;  // channel groups with a weight (the reference skips a group whose weight is 0)
-};
-
-// Per window and channel group: how its shifted values v went into two half-precision parts, v 2^e ~ hi + lo.
-struct SelfSimSplit {
-    float rho;   // Euclidean norm of v - (hi + lo) 2^-e over the window, rounded up
-    float lam;   // Euclidean norm of lo 2^-e, rounded up
-    float sq;    // Euclidean norm of v, rounded up
-    int exp2;    // e
 };
 
 struct SelfSimSeq {
@@ -452,52 +446,56 @@ __global__ __launch_bounds__(256, 2) void selfsim_tile_kernel(SelfSimArgs g)
 }
 
 // ---------------------------------------------------------------------------
-// The same matrix on the half-precision matrix cores (v_mfma_f32_32x32x16_f16: sixteen products per instruction
-// and row, sixteen times the rate of the fp32 instruction).  A stored value v (fp32, shifted by its window's mean
-// level) is multiplied by a power of two 2^e of its window -- the one that puts the window's largest magnitude
-// just below 2^14 -- and cut into two half-precision parts, hi = half(v 2^e) and lo = half(v 2^e - hi); then
-//     sum va vb  =  2^-(ea + eb) [ sum hi_a hi_b  +  sum (hi_a lo_b + lo_a hi_b) ]  +  rest,
-//     |rest| <= |lo_a| |lo_b| + rho_a |v_b| + rho_b |v_a| + rho_a rho_b      (Euclidean norms over the window)
-// where rho is what the two parts leave of v -- not estimated: selfsim_gather_split_kernel measures it, and |lo|,
-// per window (SelfSimSplit).  Products of half-precision numbers are exact in fp32.  The first sum is accumulated
-// in fp32 over runs of 64 products that are folded into fp64, as the fp32 kernel does (its bound of a run:
-// 67 2^-24 sqrt(Qa Qb)); the second, 2^-11 of it, stays in fp32 over the whole window, and its roundings weigh
-// 2^-11 as much: five more units of 2^-24 cover it.  A pixel for which all that could move the similarity by more
-// than 8e-6 is evaluated by correlate_half_dev instead, as before.
+// The same matrix on the integer matrix cores (v_mfma_i32_32x32x32_i8: 32 products per instruction and row, exact
+// 32-bit sums).  A stored value v (fp32, shifted by its window's mean level) is multiplied by a power of two 2^e of
+// its window -- the one that puts the window's largest magnitude just below 2^22 -- rounded to an integer q, and q
+// is written with three signed digits of 8 bits, q = h 2^16 + m 2^8 + l (each within [-128, 127]).  Then
+//     sum qa qb  =  2^32 sum ha hb  +  2^24 sum (ha mb + ma hb)  +  2^16 sum (ha lb + ma mb + la hb)  +  rest,
+//     |rest| <= 2^8 (|ma| |lb| + |la| |mb|) + |la| |lb|                  (Euclidean norms over the window)
+// and the three sums that are kept are exact: no rounding happens before the fp64 epilogue, so nothing is folded
+// along the way and the error of a pixel is what the digits leave out -- about 2^-22 of the product of the windows'
+// norms, a twentieth of what fp32 or half-precision accumulation certifies -- plus what the integers leave of the
+// values themselves, rho = |v - q 2^-e|.  None of it is estimated: selfsim_gather_limbs_kernel measures |m|, |l| and
+// rho per window (SelfSimLimbs).  A pixel for which all that could move the similarity by more than 8e-6 is
+// evaluated by correlate_half_dev instead, as in the fp32 kernel (windows with values that are not finite, windows
+// without spread).
 // Both channel groups in one launch: the temporal group first, its similarities wait in registers while the other
 // channels' products are formed, one epilogue, one trip of the result to memory.
 // Workgroup = 128 x 128 pixels, 8 waves of 64 (x) x 32 (y) pixels each = 2 matrix-core tiles; a stage holds 32
-// products of both sides and both parts: [side][part][group of 8 products][128 columns][16 bytes] = 32 KB, two
-// stages, filled by buffer loads that write the LDS directly.
+// products of both sides and the three digits: [side][digit][group of 16 products][128 columns][16 bytes] = 24 KB,
+// two stages, filled by buffer loads that write the LDS directly.
 // ---------------------------------------------------------------------------
 constexpr int kSfThreads = 512;
-constexpr int kSfStageBytes = 2 * 2 * 4 * kSsTile * 16;
-typedef _Float16 ss_half8 __attribute__((ext_vector_type(8)));
+constexpr int kSfStageBytes = 2 * 3 * 2 * kSsTile * 16;  // 24 KB
+constexpr int kSfFrontBytes = 64 * 1024;                 // the two stages; later similarities, statistics, uncertain pixels
+constexpr int kSfMaxProducts = 40000;                    // per window and group: 3 * 2^14 * this stays below 2^31
 
-__device__ __forceinline__ unsigned int ss_pack_halves(_Float16 a, _Float16 b)
-{
-    unsigned short ua, ub;
-    __builtin_memcpy(&ua, &a, 2);
-    __builtin_memcpy(&ub, &b, 2);
-    return (unsigned int)ua | ((unsigned int)ub << 16);
-}
+// Per window and channel group: how its shifted values v went into integers, v 2^e ~ q = h 2^16 + m 2^8 + l.
+struct SelfSimLimbs {
+    float rho;    // Euclidean norm of v - q 2^-e over the window, rounded up
+    float lamM;   // 2^8 times the Euclidean norm of m 2^-e, rounded up
+    float lamL;   // Euclidean norm of l 2^-e, rounded up
+    float sq;     // Euclidean norm of v, rounded up (NaN: the window holds values that are not finite)
+    int exp2;     // e
+    int pad[3];
+};
 
-// Window w -> its column of the two parts' images, its statistics (as selfsim_gather_kernel) and its SelfSimSplit.
-__global__ __launch_bounds__(256) void selfsim_gather_split_kernel(const float *__restrict__ x, long long frames,
+// Window w -> its column of the three digits' images (plane d of `limbs` holds digit d: 0 = h, 1 = m, 2 = l; a
+// 16-byte unit = 16 consecutive values of the window), its statistics (as selfsim_gather_kernel) and its SelfSimLimbs.
+__global__ __launch_bounds__(256) void selfsim_gather_limbs_kernel(const float *__restrict__ x, long long frames,
                                                                    int numCh, int afStart, int H, int decim, int imgExt,
                                                                    long long stride, int kgT, int kgS,
-                                                                   uint4 *__restrict__ hi, uint4 *__restrict__ lo,
+                                                                   uint4 *__restrict__ limbs,
                                                                    SelfSimStat *__restrict__ stats,
-                                                                   SelfSimSplit *__restrict__ split)
+                                                                   SelfSimLimbs *__restrict__ split)
 {
     const long long w = (long long)blockIdx.x * 256 + threadIdx.x;
     if (w >= stride) return;
     const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+    const long long plane = ((long long)kgT + kgS) * stride;
     if (w >= imgExt) {
-        for (long long kg = 0; kg < (long long)kgT + kgS; kg++) {
-            hi[kg * stride + w] = zero;
-            lo[kg * stride + w] = zero;
-        }
+        for (long long kg = 0; kg < (long long)kgT + kgS; kg++)
+            for (int d = 0; d < 3; d++) limbs[d * plane + kg * stride + w] = zero;
         return;
     }
     const long long f0 = (long long)afStart + w * decim;
@@ -522,53 +520,40 @@ __global__ __launch_bounds__(256) void selfsim_gather_split_kernel(const float *
         int e = 0;
         if (!bad && mx > 0.0f) {
             int ex;
-            (void)frexpf(mx, &ex);  // mx = m 2^ex, 0.5 <= m < 1
-            e = 14 - ex;            // mx 2^e in [2^13, 2^14)
+            (void)frexpf(mx, &ex);  // mx = f 2^ex, 0.5 <= f < 1
+            e = 22 - ex;            // mx 2^e in [2^21, 2^22)
         }
-        double S = 0.0, Q = 0.0, R = 0.0, Lm = 0.0;
-        unsigned int ph[4] = {0u, 0u, 0u, 0u}, pl[4] = {0u, 0u, 0u, 0u};
-        _Float16 hprev = (_Float16)0.0f, lprev = (_Float16)0.0f;
+        double S = 0.0, Q = 0.0, R = 0.0, Mm = 0.0, Lm = 0.0;
+        unsigned int pd[3][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
         int idx = 0;
+        auto flush = [&](long long kg) {
+            for (int d = 0; d < 3; d++) {
+                limbs[d * plane + (kg0 + kg) * stride + w] = make_uint4(pd[d][0], pd[d][1], pd[d][2], pd[d][3]);
+                pd[d][0] = pd[d][1] = pd[d][2] = pd[d][3] = 0u;
+            }
+        };
         for (int c = c0; c < c1; c++)
             for (int k = 0; k < H; k++, idx++) {
                 const float v = x[(long long)c * frames + f0 + k] - mu;
                 S += (double)v;
                 Q = fma((double)v, (double)v, Q);
-                const float vs = ldexpf(v, e);
-                const _Float16 h = (_Float16)vs;
-                const float d1 = vs - (float)h;
-                const _Float16 l = (_Float16)d1;
-                const float r = d1 - (float)l;
-                R = fma((double)r, (double)r, R);
-                Lm = fma((double)(float)l, (double)(float)l, Lm);
-                const int j = idx & 7;
-                if (j & 1) {
-                    ph[j >> 1] = ss_pack_halves(hprev, h);
-                    pl[j >> 1] = ss_pack_halves(lprev, l);
-                } else {
-                    hprev = h;
-                    lprev = l;
-                }
-                if (j == 7) {
-                    hi[(kg0 + (idx >> 3)) * stride + w] = make_uint4(ph[0], ph[1], ph[2], ph[3]);
-                    lo[(kg0 + (idx >> 3)) * stride + w] = make_uint4(pl[0], pl[1], pl[2], pl[3]);
-                    ph[0] = ph[1] = ph[2] = ph[3] = pl[0] = pl[1] = pl[2] = pl[3] = 0u;
-                }
+                // (a window with values that are not finite is marked below; its digits are not looked at)
+                const int q = bad ? 0 : (int)rintf(ldexpf(v, e));
+                const int l = ((q + 128) & 255) - 128, q1 = (q - l) >> 8;
+                const int m = ((q1 + 128) & 255) - 128, h = (q1 - m) >> 8;
+                const double r = (double)v - ldexp((double)q, -e);
+                R = fma(r, r, R);
+                Mm += (double)(m * m);
+                Lm += (double)(l * l);
+                const int j = idx & 15, sh = 8 * (j & 3);
+                pd[0][j >> 2] |= ((unsigned int)h & 255u) << sh;
+                pd[1][j >> 2] |= ((unsigned int)m & 255u) << sh;
+                pd[2][j >> 2] |= ((unsigned int)l & 255u) << sh;
+                if (j == 15) flush(idx >> 4);
             }
-        int kg = idx >> 3;
-        if (idx & 7) {  // the last, partly filled group (an odd count leaves one value waiting)
-            if (idx & 1) {
-                ph[(idx & 7) >> 1] = ss_pack_halves(hprev, (_Float16)0.0f);
-                pl[(idx & 7) >> 1] = ss_pack_halves(lprev, (_Float16)0.0f);
-            }
-            hi[(kg0 + kg) * stride + w] = make_uint4(ph[0], ph[1], ph[2], ph[3]);
-            lo[(kg0 + kg) * stride + w] = make_uint4(pl[0], pl[1], pl[2], pl[3]);
-            kg++;
-        }
-        for (; kg < kgN; kg++) {
-            hi[(kg0 + kg) * stride + w] = zero;
-            lo[(kg0 + kg) * stride + w] = zero;
-        }
+        int kg = idx >> 4;
+        if (idx & 15) flush(kg++);  // the last, partly filled unit
+        for (; kg < kgN; kg++) flush(kg);
         SelfSimStat st;
         st.S = S;
         st.Q = Q;
@@ -577,73 +562,81 @@ __global__ __launch_bounds__(256) void selfsim_gather_split_kernel(const float *
         st.QR = Q + 2.0 * (double)mu * S + cnt * (double)mu * (double)mu;
         st.pad = 0.0;
         stats[2 * w + group] = st;
-        SelfSimSplit sp;
-        sp.rho = (float)(ldexp(sqrt(R), -e) * 1.0001);
-        sp.lam = (float)(ldexp(sqrt(Lm), -e) * 1.0001);
-        sp.sq = (float)(sqrt(Q) * 1.0001);
+        SelfSimLimbs sp;
+        sp.rho = (float)(sqrt(R) * 1.0001);
+        sp.lamM = (float)(ldexp(sqrt(Mm), 8 - e) * 1.0001);
+        sp.lamL = (float)(ldexp(sqrt(Lm), -e) * 1.0001);
+        sp.sq = bad ? __builtin_nanf("") : (float)(sqrt(Q) * 1.0001);
         sp.exp2 = e;
+        sp.pad[0] = sp.pad[1] = sp.pad[2] = 0;
         split[2 * w + group] = sp;
     }
 }
 
-// Similarity of one pixel's channel group from the product sum of the parts (already divided by the two windows'
+// Similarity of one pixel's channel group from the product sum of the integers (already divided by the two windows'
 // powers of two) and the windows' statistics, or the mark for the exact evaluation: selfsim_pixel with the error
 // terms of the header comment.  (ra, rb: 1e-7 of the windows' raw sums of squares, the guard of the fp64
 // cancellation as there.)  `bound`: how far the returned similarity can be from the exact quotient because of the
-// product sum's error -- at most 8e-6, for most pixels about half of that.
-__device__ __forceinline__ float selfsim_pixel16(double Sa, double mua, double SaR, double QaR, float sqa, float rhoa,
-                                                 float lama, float ra, double mub, double SbR, double QbR, float sqb,
-                                                 float rhob, float lamb, float rb, double pSum, double inv2n,
-                                                 float unsure, float &bound)
+// product sum's error -- at most 8e-6, for ordinary windows a few 1e-7.
+__device__ __forceinline__ float selfsim_pixel8(double Sa, double mua, double SaR, double QaR, float sqa, float rhoa,
+                                                float lamMa, float lamLa, float ra, double mub, double SbR, double QbR,
+                                                float sqb, float rhob, float lamMb, float lamLb, float rb, double pSum,
+                                                double inv2n, float unsure, float &bound)
 {
     const double S = SaR + SbR;
     const double s2 = S * S * inv2n;
     const double varsum = (QaR + QbR) - s2;
     const double cross2 = 2.0 * (fma(mua, SbR, fma(mub, Sa, pSum))) - s2;  // twice the centred product sum
     const float v = (float)varsum;
-    constexpr float kAcc = 72.0f * 5.9604645e-8f;  // (64 + 3 + 5) 2^-24
-    const float err = fmaf(kAcc * sqa, sqb, fmaf(lama, lamb, fmaf(rhoa, sqb, fmaf(rhob, sqa, rhoa * rhob))));
+    // digits left out, what the integers leave of the values, and the fp64 roundings of the sum's three terms
+    const float err = fmaf(lamMa, lamLb, fmaf(lamLa, lamMb, fmaf(lamLa, lamLb, fmaf(rhoa, sqb, fmaf(rhob, sqa,
+                      fmaf(3.0f * rhoa, rhob, 1.0e-14f * sqa * sqb))))));
     // 2 err <= 8e-6 varsum (both tests fail for NaN as well)
     const bool sure = err * 1.0001f <= 4.0e-6f * v && ra + rb <= v;
     bound = 2.0003f * err * __builtin_amdgcn_rcpf(v);
     return sure ? (float)cross2 / v : unsure;
 }
 
-// What the fp32 quotient, the conversions before it and the weighted sum of the two groups add to a similarity's
-// error, with room to spare (each is a rounding or two of a value below 1).
-constexpr float kSsMixErr = 2.0e-6f;
+// What the fp32 steps add to the distance between a pixel's similarity and the reference's: the reference rounds each
+// group's fp64 quotient to fp32 once, multiplies by the weight and adds (impl/SelfSimilarityImpl.scala:143-146); here a
+// group's part is fl(fl(cross) / fl(var)), three roundings against one, then the same two products and one sum with
+// arguments that differ by the bounds: with u = 2^-24 and similarities of magnitude 1 at most that is 4 u for the
+// parts, 2 u for the products and 2 u for the sum, 8 u = 4.8e-7.
+constexpr float kSsMixErr = 6.0e-7f;
 constexpr int kSfErrBytes = 32 * kSfThreads * 4;  // the first group's error bounds: a float per pixel
 constexpr int kSfHits = 4096;                     // uncertain pixels a tile collects before it appends them one by one
 
-__global__ __launch_bounds__(kSfThreads, 2) void selfsim_tile16_kernel(SelfSimArgs g)
+__global__ __launch_bounds__(kSfThreads, 2) void selfsim_tile8_kernel(SelfSimArgs g)
 {
     const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
     const int super = (slot >> 6) * 8 + xcd, within = slot & 63;
     const int tileX = (super % g.superEdge) * 8 + (within & 7), tileY = (super / g.superEdge) * 8 + (within >> 3);
     if (tileY < tileX || tileY >= g.tilesEdge) return;  // pixels with y >= x only (:127-163); the rest is mirrored
-    extern __shared__ __align__(16) unsigned char ldsRaw[];  // two stages, then kSfErrBytes
+    extern __shared__ __align__(16) unsigned char ldsRaw[];  // kSfFrontBytes, then kSfErrBytes
     __shared__ int hitCount;
     __shared__ unsigned long long hitBase;
     float *lds = reinterpret_cast<float *>(ldsRaw);
-    float *errLds = reinterpret_cast<float *>(ldsRaw + 2 * kSfStageBytes);  // [pixel of the thread][thread]
+    float *errLds = reinterpret_cast<float *>(ldsRaw + kSfFrontBytes);  // [pixel of the thread][thread]
     const int tid = threadIdx.x;
     if (tid == 0) hitCount = 0;  // (the loop below has barriers before anybody counts)
     const int lane = tid & 63, q = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wx = q & 1, wy = q >> 1, l32 = lane & 31, lhi = lane >> 5;
     const int X0 = tileX * kSsTile, Y0 = tileY * kSsTile;
     const int H = g.H;
-    typedef float v16f __attribute__((ext_vector_type(16)));
+    typedef int v16i __attribute__((ext_vector_type(16)));
+    typedef int v4i __attribute__((ext_vector_type(4)));
     constexpr int kRow = kSsTile + 1;
     const float kUnsure = __int_as_float(0x7fc0beef);  // marks a pixel for the exact evaluation
     // behind the similarities of half a tile (64 rows): the statistics of the tile's 128 + 128 windows
     double *stS = reinterpret_cast<double *>(lds + 64 * kRow), *stMu = stS + 2 * kSsTile, *stSR = stMu + 2 * kSsTile,
            *stQR = stSR + 2 * kSsTile, *stF = stQR + 2 * kSsTile;
-    float *stSq = reinterpret_cast<float *>(stF + 2 * kSsTile), *stRho = stSq + 2 * kSsTile, *stLam = stRho + 2 * kSsTile,
-          *stR7 = stLam + 2 * kSsTile;
+    float *stSq = reinterpret_cast<float *>(stF + 2 * kSsTile), *stRho = stSq + 2 * kSsTile, *stLamM = stRho + 2 * kSsTile,
+          *stLamL = stLamM + 2 * kSsTile, *stR7 = stLamL + 2 * kSsTile;
     // behind the statistics: the tile's uncertain pixels (x | y << 8 within the tile)
     int *hits = reinterpret_cast<int *>(stR7 + 2 * kSsTile);
-    static_assert((64 * kRow) % 2 == 0 && (64 * kRow + (10 + 4) * 2 * kSsTile + kSfHits) * 4 <= 2 * kSfStageBytes,
-                  "similarities, statistics and the uncertain pixels must fit the stages' memory");
+    static_assert((64 * kRow) % 2 == 0 && (64 * kRow + (10 + 5) * 2 * kSsTile + kSfHits) * 4 <= kSfFrontBytes &&
+                      2 * kSfStageBytes <= kSfFrontBytes,
+                  "stages resp. similarities, statistics and the uncertain pixels must fit the front memory");
     // the temporal group's part, later the pixel's similarity -- or, where only the raster is asked for, its colour
     float simv[2][16];
 #pragma unroll
@@ -652,77 +645,72 @@ __global__ __launch_bounds__(kSfThreads, 2) void selfsim_tile16_kernel(SelfSimAr
         for (int v = 0; v < 16; v++) simv[i][v] = 0.0f;
 
     for (int group = g.doT ? 0 : 1; group < (g.doS ? 2 : 1); group++) {
-        const int nkg = group == 0 ? g.kgT : g.kgS;  // groups of 8 products: a multiple of 4
+        const int nkg = group == 0 ? g.kgT : g.kgS;  // units of 16 products: a multiple of 2
         const long long kg0 = group == 0 ? 0 : g.kgT;
         const int n = H * (group == 0 ? 1 : g.numCh - 1);
+        const long long plane = ((long long)g.kgT + g.kgS) * g.stride;
         const unsigned bytes = (unsigned)(((long long)(nkg - 1) * g.stride + kSsTile) * 16);
-        const __amdgpu_buffer_rsrc_t rs[4] = {
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(g.hi1 + kg0 * g.stride + X0), 0, bytes, 0x00020000),
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(g.lo1 + kg0 * g.stride + X0), 0, bytes, 0x00020000),
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(g.hi2 + kg0 * g.stride + Y0), 0, bytes, 0x00020000),
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(g.lo2 + kg0 * g.stride + Y0), 0, bytes, 0x00020000)};
-        // a stage = 16 rows of 2 KB ([side][part][group of 8]); a wave instruction moves half a row
+        // [side][digit]
+        const __amdgpu_buffer_rsrc_t rs[6] = {
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(g.limbs1 + kg0 * g.stride + X0), 0, bytes, 0x00020000),
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(g.limbs1 + plane + kg0 * g.stride + X0), 0, bytes, 0x00020000),
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(g.limbs1 + 2 * plane + kg0 * g.stride + X0), 0, bytes, 0x00020000),
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(g.limbs2 + kg0 * g.stride + Y0), 0, bytes, 0x00020000),
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(g.limbs2 + plane + kg0 * g.stride + Y0), 0, bytes, 0x00020000),
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(g.limbs2 + 2 * plane + kg0 * g.stride + Y0), 0, bytes, 0x00020000)};
+        // a stage = 12 rows of 2 KB ([side][digit][unit]); a wave instruction moves half a row, a wave three of them
         auto stage = [&](int s0, int buf) {
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
-                const int piece = q * 4 + t, row = piece >> 1, hc = piece & 1;
-                const unsigned off = (unsigned)((((long long)(s0 + (row & 3))) * g.stride + 64 * hc + lane) * 16);
+            for (int t = 0; t < 3; t++) {
+                const int piece = q * 3 + t, row = piece >> 1, hc = piece & 1;
+                const unsigned off = (unsigned)((((long long)(s0 + (row & 1))) * g.stride + 64 * hc + lane) * 16);
                 ss_lds_void *to = (ss_lds_void *)(ldsRaw + buf * kSfStageBytes + row * 2048 + hc * 1024);
-                switch (row >> 2) {
+                switch (row >> 1) {
                 case 0: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[0], to, 16, off, 0, 0, 0); break;
                 case 1: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[1], to, 16, off, 0, 0, 0); break;
                 case 2: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[2], to, 16, off, 0, 0, 0); break;
-                default: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[3], to, 16, off, 0, 0, 0); break;
+                case 3: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[3], to, 16, off, 0, 0, 0); break;
+                case 4: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[4], to, 16, off, 0, 0, 0); break;
+                default: __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[5], to, 16, off, 0, 0, 0); break;
                 }
             }
         };
-        v16f accM[2], accX[2];
-        double sum[2][16];
+        v16i acc[3][2];  // [order: h h; h m + m h; h l + m m + l h][matrix-core tile]
 #pragma unroll
-        for (int i = 0; i < 2; i++)
+        for (int o = 0; o < 3; o++)
 #pragma unroll
-            for (int v = 0; v < 16; v++) {
-                accM[i][v] = 0.0f;
-                accX[i][v] = 0.0f;
-                sum[i][v] = 0.0;
-            }
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int v = 0; v < 16; v++) acc[o][i][v] = 0;
         __syncthreads();  // (whatever read the LDS before -- the first group's statistics -- is done)
         stage(0, 0);
         int buf = 0;
-        for (int s0 = 0; s0 < nkg; s0 += 4, buf ^= 1) {
+        for (int s0 = 0; s0 < nkg; s0 += 2, buf ^= 1) {
             // every direct-to-LDS load of this wave has to have landed before the barrier lets other waves read the
             // stage (the compiler only waits for what this wave's own reads may touch): vmcnt(0)
             __builtin_amdgcn_s_waitcnt(0x0F70);
             __syncthreads();  // everyone is done with the other stage
-            if (s0 + 4 < nkg) stage(s0 + 4, buf ^ 1);
+            if (s0 + 2 < nkg) stage(s0 + 2, buf ^ 1);
             const unsigned char *st = ldsRaw + buf * kSfStageBytes;
+            // (the lanes' upper half takes the stage's second unit: the instruction's 32 products)
+            const int colB = (32 * wy + l32) * 16;
+            const v4i bH = *reinterpret_cast<const v4i *>(st + (6 + lhi) * 2048 + colB);
+            const v4i bM = *reinterpret_cast<const v4i *>(st + (8 + lhi) * 2048 + colB);
+            const v4i bL = *reinterpret_cast<const v4i *>(st + (10 + lhi) * 2048 + colB);
 #pragma unroll
-            for (int ks = 0; ks < 2; ks++) {
-                const int kgl = 2 * ks + lhi;
-                const ss_half8 bH = *reinterpret_cast<const ss_half8 *>(st + (8 + kgl) * 2048 + (32 * wy + l32) * 16);
-                const ss_half8 bL = *reinterpret_cast<const ss_half8 *>(st + (12 + kgl) * 2048 + (32 * wy + l32) * 16);
-#pragma unroll
-                for (int i = 0; i < 2; i++) {
-                    const ss_half8 aH = *reinterpret_cast<const ss_half8 *>(st + kgl * 2048 + (64 * wx + 32 * i + l32) * 16);
-                    const ss_half8 aL = *reinterpret_cast<const ss_half8 *>(st + (4 + kgl) * 2048 + (64 * wx + 32 * i + l32) * 16);
-                    accM[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aH, bH, accM[i], 0, 0, 0);
-                    accX[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aH, bL, accX[i], 0, 0, 0);
-                    accX[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aL, bH, accX[i], 0, 0, 0);
-                }
+            for (int i = 0; i < 2; i++) {
+                const int colA = (64 * wx + 32 * i + l32) * 16;
+                const v4i aH = *reinterpret_cast<const v4i *>(st + (0 + lhi) * 2048 + colA);
+                const v4i aM = *reinterpret_cast<const v4i *>(st + (2 + lhi) * 2048 + colA);
+                const v4i aL = *reinterpret_cast<const v4i *>(st + (4 + lhi) * 2048 + colA);
+                acc[0][i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(aH, bH, acc[0][i], 0, 0, 0);
+                acc[1][i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(aH, bM, acc[1][i], 0, 0, 0);
+                acc[1][i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(aM, bH, acc[1][i], 0, 0, 0);
+                acc[2][i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(aH, bL, acc[2][i], 0, 0, 0);
+                acc[2][i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(aM, bM, acc[2][i], 0, 0, 0);
+                acc[2][i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(aL, bH, acc[2][i], 0, 0, 0);
             }
-            if ((s0 & 4) == 0 && s0 + 4 < nkg) continue;  // fold after every second stage (64 products) and the last
-#pragma unroll
-            for (int i = 0; i < 2; i++)
-#pragma unroll
-                for (int v = 0; v < 16; v++) {
-                    sum[i][v] += (double)accM[i][v];
-                    accM[i][v] = 0.0f;
-                }
         }
-#pragma unroll
-        for (int i = 0; i < 2; i++)
-#pragma unroll
-            for (int v = 0; v < 16; v++) sum[i][v] += (double)accX[i][v];
 
         // the group's similarities: statistics of the tile's windows (indices past the end clamped: those pixels
         // are never written) into LDS, then every thread its 32 pixels
@@ -730,15 +718,16 @@ __global__ __launch_bounds__(kSfThreads, 2) void selfsim_tile16_kernel(SelfSimAr
         if (tid < 2 * kSsTile) {
             const int wdw = min((tid < kSsTile ? X0 + tid : Y0 + tid - kSsTile), g.imgExt - 1);
             const SelfSimStat st = (tid < kSsTile ? g.st1 : g.st2)[2 * (long long)wdw + group];
-            const SelfSimSplit sp = (tid < kSsTile ? g.sp1 : g.sp2)[2 * (long long)wdw + group];
+            const SelfSimLimbs sp = (tid < kSsTile ? g.sp1 : g.sp2)[2 * (long long)wdw + group];
             stS[tid] = st.S;
             stMu[tid] = st.mu;
             stSR[tid] = st.SR;
             stQR[tid] = st.QR;
-            stF[tid] = ldexp(1.0, -sp.exp2);
+            stF[tid] = ldexp(1.0, 8 - sp.exp2);  // (2^16 of the sum's common factor, half on either side)
             stSq[tid] = sp.sq;
             stRho[tid] = sp.rho;
-            stLam[tid] = sp.lam;
+            stLamM[tid] = sp.lamM;
+            stLamL[tid] = sp.lamL;
             stR7[tid] = (float)(1.0e-7 * st.QR);
         }
         __syncthreads();
@@ -747,17 +736,19 @@ __global__ __launch_bounds__(kSfThreads, 2) void selfsim_tile16_kernel(SelfSimAr
         const float wThis = group == 0 ? g.wT : 1.0f - g.wT;
         const int pyl = 32 * wy + l32, yb = kSsTile + pyl, py = Y0 + pyl;
         const double mub = stMu[yb], SbR = stSR[yb], QbR = stQR[yb], fb = stF[yb];
-        const float sqb = stSq[yb], rhob = stRho[yb], lamb = stLam[yb], rb = stR7[yb];
+        const float sqb = stSq[yb], rhob = stRho[yb], lamMb = stLamM[yb], lamLb = stLamL[yb], rb = stR7[yb];
         const bool both = g.doT && g.doS, lastGroup = group == (g.doS ? 1 : 0);
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
             for (int v = 0; v < 16; v++) {
                 const int pxl = 64 * wx + 32 * i + 8 * (v >> 2) + 4 * lhi + (v & 3), px = X0 + pxl;
+                // sum qa qb / 2^16 (every term an integer below 2^53: exact)
+                const double t = fma((double)acc[0][i][v], 65536.0, fma((double)acc[1][i][v], 256.0, (double)acc[2][i][v]));
                 float bound;
-                float part = selfsim_pixel16(stS[pxl], stMu[pxl], stSR[pxl], stQR[pxl], stSq[pxl], stRho[pxl], stLam[pxl],
-                                             stR7[pxl], mub, SbR, QbR, sqb, rhob, lamb, rb, sum[i][v] * stF[pxl] * fb,
-                                             inv2n, kUnsure, bound);
+                float part = selfsim_pixel8(stS[pxl], stMu[pxl], stSR[pxl], stQR[pxl], stSq[pxl], stRho[pxl], stLamM[pxl],
+                                            stLamL[pxl], stR7[pxl], mub, SbR, QbR, sqb, rhob, lamMb, lamLb, rb,
+                                            t * stF[pxl] * fb, inv2n, kUnsure, bound);
                 const bool inside = px < g.imgExt && py < g.imgExt && py >= px;
                 if (__float_as_int(part) == __float_as_int(kUnsure)) {
                     part = 0.0f;
@@ -775,7 +766,7 @@ __global__ __launch_bounds__(kSfThreads, 2) void selfsim_tile16_kernel(SelfSimAr
                 // selfsim_fix_kernel, which evaluates them as the reference does.  (Only where a raster is asked for.)
                 if (g.fixList && !lastGroup) errLds[(16 * i + v) * kSfThreads + tid] = bound * wThis;
                 if (g.fixList && lastGroup) {
-                    float e = fmaf(bound, wThis, kSsMixErr);
+                    float e = fmaf(bound, wThis, kSsMixErr + g.slack);
                     if (both) e += errLds[(16 * i + v) * kSfThreads + tid];
                     const int cLo = gray_color(sim - e, g.warp, g.scale, g.inv), cHi = gray_color(sim + e, g.warp, g.scale, g.inv);
                     if (!g.wantSim) simv[i][v] = __int_as_float(cLo);
@@ -1207,34 +1198,33 @@ static int selfsim_impl(sgz_context *ctx, const float *frames1, int64_t num_fram
     const size_t pix = (size_t)img_ext * img_ext;
     // the reference skips a group whose weight is 0 (:143-145)
     const bool doT = temporal_weight > 0.0f, doS = temporal_weight < 1.0f || !doT;
-    DevBuf st1, st2, cols1, cols2, hi1, lo1, hi2, lo2, sp1, sp2;
+    DevBuf st1, st2, cols1, cols2, limbs1, limbs2, sp1, sp2;
     const unsigned gt = (unsigned)((img_ext + kSsTile - 1) / kSsTile);
     const long long stride = (long long)gt * kSsTile;
-    // groups of 8 products per channel group, padded to whole stages of 32 products
-    const long long kgT = ((long long)half_win + 31) / 32 * 4, kgS = ((long long)(num_channels - 1) * half_win + 31) / 32 * 4;
-    // The half-precision matrix cores take it unless a plane of the windows' parts would pass the 4 GB a buffer
-    // descriptor's 32-bit offsets reach (windows of several minutes): then the fp32 kernel, one pass per group.
-    bool split16 = std::max(kgT, kgS) * stride * 16 < (1ll << 32);
+    // units of 16 products per channel group, padded to whole stages of 32 products
+    const long long kgT = ((long long)half_win + 31) / 32 * 2, kgS = ((long long)(num_channels - 1) * half_win + 31) / 32 * 2;
+    // The integer matrix cores take it unless a plane of the windows' digits would pass the 4 GB a buffer
+    // descriptor's 32-bit offsets reach, or a window has more products than 32-bit sums hold (windows of minutes):
+    // then the fp32 kernel, one pass per group.
+    bool limbs = std::max(kgT, kgS) * stride * 16 < (1ll << 32) && std::max(kgT, kgS) * 16 <= kSfMaxProducts;
     if (const char *e = std::getenv("SGZ_SELFSIM_KERNEL")) {  // test knob: "f32" forces the fp32 kernel
-        if (std::strcmp(e, "f32") == 0) split16 = false;
+        if (std::strcmp(e, "f32") == 0) limbs = false;
     }
     // (the fp32 kernel keeps its first group's part and, for the list of uncertain pixels, the finished half with
-    // y >= x in the matrix; the half-precision one needs it only when the caller wants the matrix)
-    if (sim_out || keep_sim || (!split16 && (img_out || (doT && doS)))) SGZ_HIP(ctx, hipMalloc(&simd.p, pix * sizeof(float)));
+    // y >= x in the matrix; the integer one needs it only when the caller wants the matrix)
+    if (sim_out || keep_sim || (!limbs && (img_out || (doT && doS)))) SGZ_HIP(ctx, hipMalloc(&simd.p, pix * sizeof(float)));
     if (img_out) SGZ_HIP(ctx, hipMalloc(&imgd.p, pix * sizeof(int32_t)));
     SGZ_HIP(ctx, hipMalloc(&st1.p, 2 * (size_t)stride * sizeof(SelfSimStat)));
     const unsigned gs = (unsigned)((stride + 255) / 256);
     const size_t colFloats = (size_t)num_channels * half_win * (size_t)stride;
     const size_t planeBytes = (size_t)(kgT + kgS) * (size_t)stride * 16;
-    auto gather = [&](const void *planar, long long nframes, DevBuf &st, DevBuf &cols, DevBuf &hi, DevBuf &lo,
-                      DevBuf &sp) -> int {
-        if (split16) {
-            SGZ_HIP(ctx, hipMalloc(&hi.p, planeBytes));
-            SGZ_HIP(ctx, hipMalloc(&lo.p, planeBytes));
-            SGZ_HIP(ctx, hipMalloc(&sp.p, 2 * (size_t)stride * sizeof(SelfSimSplit)));
-            hipLaunchKernelGGL(selfsim_gather_split_kernel, dim3(gs), dim3(256), 0, ctx->stream, (const float *)planar,
+    auto gather = [&](const void *planar, long long nframes, DevBuf &st, DevBuf &cols, DevBuf &lb, DevBuf &sp) -> int {
+        if (limbs) {
+            SGZ_HIP(ctx, hipMalloc(&lb.p, 3 * planeBytes));
+            SGZ_HIP(ctx, hipMalloc(&sp.p, 2 * (size_t)stride * sizeof(SelfSimLimbs)));
+            hipLaunchKernelGGL(selfsim_gather_limbs_kernel, dim3(gs), dim3(256), 0, ctx->stream, (const float *)planar,
                                nframes, num_channels, af_start, half_win, decim, img_ext, stride, (int)kgT, (int)kgS,
-                               (uint4 *)hi.p, (uint4 *)lo.p, (SelfSimStat *)st.p, (SelfSimSplit *)sp.p);
+                               (uint4 *)lb.p, (SelfSimStat *)st.p, (SelfSimLimbs *)sp.p);
         } else {
             SGZ_HIP(ctx, hipMalloc(&cols.p, colFloats * sizeof(float)));
             hipLaunchKernelGGL(selfsim_gather_kernel, dim3(gs), dim3(256), 0, ctx->stream, (const float *)planar, nframes,
@@ -1245,10 +1235,10 @@ static int selfsim_impl(sgz_context *ctx, const float *frames1, int64_t num_fram
         return SGZ_OK;
     };
     int grc;
-    if ((grc = gather(p1.p, (long long)num_frames1, st1, cols1, hi1, lo1, sp1))) return grc;
+    if ((grc = gather(p1.p, (long long)num_frames1, st1, cols1, limbs1, sp1))) return grc;
     if (!same) {
         SGZ_HIP(ctx, hipMalloc(&st2.p, 2 * (size_t)stride * sizeof(SelfSimStat)));
-        if ((grc = gather(p2.p, (long long)num_frames2, st2, cols2, hi2, lo2, sp2))) return grc;
+        if ((grc = gather(p2.p, (long long)num_frames2, st2, cols2, limbs2, sp2))) return grc;
     }
     SelfSimArgs a;
     a.x1 = (const float *)p1.p;
@@ -1259,12 +1249,10 @@ static int selfsim_impl(sgz_context *ctx, const float *frames1, int64_t num_fram
     a.cols2 = (const float *)(same ? cols1.p : cols2.p);
     a.st1 = (const SelfSimStat *)st1.p;
     a.st2 = (const SelfSimStat *)(same ? st1.p : st2.p);
-    a.hi1 = (const uint4 *)hi1.p;
-    a.lo1 = (const uint4 *)lo1.p;
-    a.hi2 = (const uint4 *)(same ? hi1.p : hi2.p);
-    a.lo2 = (const uint4 *)(same ? lo1.p : lo2.p);
-    a.sp1 = (const SelfSimSplit *)sp1.p;
-    a.sp2 = (const SelfSimSplit *)(same ? sp1.p : sp2.p);
+    a.limbs1 = (const uint4 *)limbs1.p;
+    a.limbs2 = (const uint4 *)(same ? limbs1.p : limbs2.p);
+    a.sp1 = (const SelfSimLimbs *)sp1.p;
+    a.sp2 = (const SelfSimLimbs *)(same ? sp1.p : sp2.p);
     a.kgT = (int)kgT;
     a.kgS = (int)kgS;
     a.doT = doT ? 1 : 0;
@@ -1304,6 +1292,8 @@ static int selfsim_impl(sgz_context *ctx, const float *frames1, int64_t num_fram
     a.seqList = nullptr;
     a.seqCap = 1u << 20;
     a.forceSeq = 0;
+    a.slack = 0.0f;
+    if (const char *e = std::getenv("SGZ_SELFSIM_SLACK")) a.slack = std::max(0.0f, (float)std::atof(e));
     if (const char *e = std::getenv("SGZ_SELFSIM_SEQ")) {  // test knob: "force[,capacity]"
         a.forceSeq = std::strncmp(e, "force", 5) == 0;
         if (const char *c = std::strchr(e, ',')) a.seqCap = (unsigned)std::max(0ll, std::atoll(c + 1));
@@ -1321,18 +1311,18 @@ static int selfsim_impl(sgz_context *ctx, const float *frames1, int64_t num_fram
         a.seqCount = reinterpret_cast<unsigned int *>(seqd.p);
         a.seqList = reinterpret_cast<SelfSimSeq *>(seqd.p) + 1;
     }
-    if (split16) {
+    if (limbs) {
         a.c0 = a.c1 = a.first = 0;
         a.last = 1;
         a.wThis = 0.0f;
         a.keepUpper = a.wantSim;
-        constexpr int ldsBytes = 2 * kSfStageBytes + kSfErrBytes;
-        SGZ_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(selfsim_tile16_kernel),
+        constexpr int ldsBytes = kSfFrontBytes + kSfErrBytes;
+        SGZ_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(selfsim_tile8_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, ldsBytes));
-        hipLaunchKernelGGL(selfsim_tile16_kernel, dim3(gridWGs), dim3(kSfThreads), ldsBytes, ctx->stream, a);
+        hipLaunchKernelGGL(selfsim_tile8_kernel, dim3(gridWGs), dim3(kSfThreads), ldsBytes, ctx->stream, a);
         SGZ_HIP(ctx, hipGetLastError());
     }
-    if (!split16 && doT) {
+    if (!limbs && doT) {
         a.c0 = 0;
         a.c1 = 1;
         a.first = 1;
@@ -1341,7 +1331,7 @@ static int selfsim_impl(sgz_context *ctx, const float *frames1, int64_t num_fram
         hipLaunchKernelGGL(selfsim_tile_kernel, dim3(gridWGs), dim3(256), 0, ctx->stream, a);
         SGZ_HIP(ctx, hipGetLastError());
     }
-    if (!split16 && doS) {
+    if (!limbs && doS) {
         a.c0 = 1;
         a.c1 = num_channels;
         a.first = doT ? 0 : 1;
@@ -1351,7 +1341,7 @@ static int selfsim_impl(sgz_context *ctx, const float *frames1, int64_t num_fram
         SGZ_HIP(ctx, hipGetLastError());
     }
     if (img_out) {
-        if (!split16) {  // (the half-precision kernel lists its uncertain pixels itself)
+        if (!limbs) {  // (the integer kernel lists its uncertain pixels itself)
             hipLaunchKernelGGL(selfsim_list_kernel, dim3(gt * gt), dim3(256), 0, ctx->stream, a);
             SGZ_HIP(ctx, hipGetLastError());
         }
@@ -1361,6 +1351,9 @@ static int selfsim_impl(sgz_context *ctx, const float *frames1, int64_t num_fram
         unsigned long long listed = 0;
         SGZ_HIP(ctx, hipMemcpyAsync(&listed, a.fixCount, sizeof listed, hipMemcpyDeviceToHost, ctx->stream));
         SGZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (std::getenv("SGZ_SELFSIM_VERBOSE"))
+            std::fprintf(stderr, "selfsim: %llu of %zu pixels listed for the exact evaluation (list of %lld)\n", listed,
+                         pix, fixCap);
         if (listed > (unsigned long long)fixCap) {  // more than the list holds: every pixel that way
             SGZ_HIP(ctx, hipMemsetAsync(a.seqCount, 0, sizeof(unsigned int), ctx->stream));
             hipLaunchKernelGGL(selfsim_fix_kernel, dim3(8192), dim3(256), 0, ctx->stream, a, (const int2 *)nullptr,

@@ -55,9 +55,9 @@ def test_segmentation_window_longer_than_span_gives_one_value(ctx, normalize):
 @pytest.mark.parametrize("decim,corr_len,warp,ceil,inv", [(1, 4 * STEP, 1.0, 1.0, False), (3, 8 * STEP, 0.5, 0.8, True),
                                                          (2, 44100, 2.0, 1.0, False), (1, 6 * STEP, 1.0, 0.004, False),
                                                          (1, 2 * STEP, 0.05, 1.0, True)])
-@pytest.mark.parametrize("kernel,tw", [("split16", 0.5), ("f32", 0.5), ("split16", 0.0), ("split16", 1.0)])
+@pytest.mark.parametrize("kernel,tw", [("limbs", 0.5), ("f32", 0.5), ("limbs", 0.0), ("limbs", 1.0)])
 def test_selfsim_matrix_and_image(ctx, monkeypatch, decim, corr_len, warp, ceil, inv, kernel, tw):
-    """Both tile kernels (products of half-precision pairs with measured residuals; plain fp32, SGZ_SELFSIM_KERNEL=f32)
+    """Both tile kernels (exact integer products of three 8-bit digits per value; plain fp32, SGZ_SELFSIM_KERNEL=f32)
     and the one-group cases (temporal weight 0 or 1: the other channel group is not read)."""
     frames = _frames(260)
     norms = norms_default()
@@ -74,18 +74,42 @@ def test_selfsim_matrix_and_image(ctx, monkeypatch, decim, corr_len, warp, ceil,
     assert np.array_equal(img & 0xFF, (img >> 8) & 0xFF) and np.array_equal(img & 0xFF, (img >> 16) & 0xFF)
 
 
-def test_selfsim_image_when_the_fix_list_overflows(ctx, monkeypatch):
+@pytest.mark.parametrize("kernel", ["limbs", "f32"])
+def test_selfsim_image_when_the_fix_list_overflows(ctx, monkeypatch, kernel):
     """More uncertain pixels than their list holds (here: a list of 3 entries, SGZ_SELFSIM_FIX_CAP): the whole
-    raster is evaluated in the reference's order instead."""
+    raster is evaluated in the reference's order instead.  (The integer kernel's own error bounds leave next to no
+    pixel uncertain at this size: SGZ_SELFSIM_SLACK widens them.)"""
     frames = _frames(300)
     norms = norms_default()
     cfg = O.SelfSimConfig(0, 0, 0, 0, 2 * STEP, 1, 0.5, 0, 1.0, 1.0, 0, 1, STEP, NUM_CH - 1)
     ext, d, af_start, _ = O.selfsim_geometry(cfg, frames.shape[0], frames.shape[0])
     want_sim, want_img = O.selfsim_run(cfg, frames, None, norms)
     monkeypatch.setenv("SGZ_SELFSIM_FIX_CAP", "3")
+    if kernel == "f32":
+        monkeypatch.setenv("SGZ_SELFSIM_KERNEL", "f32")
+    else:
+        monkeypatch.setenv("SGZ_SELFSIM_SLACK", "1e-4")
     sim, img = ctx.selfsim(frames, None, norms, af_start, 2, d, ext, 0.5)
     assert np.array_equal(img, want_img)
     assert np.array_equal(sim, want_sim)  # (then the similarities are the reference-order ones as well)
+
+
+@pytest.mark.parametrize("slack", ["1e-4", "3e-3"])
+def test_selfsim_uncertain_pixels_listed_by_the_tile_kernel(ctx, monkeypatch, slack):
+    """With widened error bounds (SGZ_SELFSIM_SLACK) a few per cent of the pixels -- with the larger value most of them,
+    more than a tile collects before it appends them one by one -- go through the list and the exact evaluation:
+    raster unchanged."""
+    frames = _frames(700, 5)
+    norms = norms_default()
+    cfg = O.SelfSimConfig(0, 0, 0, 0, 8 * STEP, 1, 0.5, 0, 1.0, 1.0, 0, 1, STEP, NUM_CH - 1)
+    ext, d, af_start, _ = O.selfsim_geometry(cfg, frames.shape[0], frames.shape[0])
+    want_sim, want_img = O.selfsim_run(cfg, frames, None, norms)
+    monkeypatch.setenv("SGZ_SELFSIM_SLACK", slack)
+    sim, img = ctx.selfsim(frames, None, norms, af_start, 8, d, ext, 0.5)
+    assert np.array_equal(img, want_img)
+    np.testing.assert_allclose(sim, want_sim, rtol=0, atol=1e-5)
+    _, img_only = ctx.selfsim(frames, None, norms, af_start, 8, d, ext, 0.5, want_sim=False)
+    assert np.array_equal(img_only, want_img)
 
 
 @pytest.mark.parametrize("knob,corr_frames,num_frames,decim", [("force", 6, 300, 1), ("force,5", 6, 300, 1),
@@ -94,13 +118,15 @@ def test_selfsim_pixels_that_need_the_sequential_order(ctx, monkeypatch, knob, c
     """A quotient too close to an fp32 rounding boundary is evaluated in the reference's order of additions by a
     kernel of its own (through LDS; from global memory when the window is larger than LDS, here 700 frames; by
     the first kernel itself when their list is full, here 5 entries).  Rare on real data, so forced here for every
-    pixel (SGZ_SELFSIM_SEQ, with a fix list of 3 entries so that every pixel is looked at)."""
+    pixel (SGZ_SELFSIM_SEQ, with error bounds widened until most pixels count as uncertain, SGZ_SELFSIM_SLACK, and a
+    fix list of 3 entries that they overflow, so that every pixel is looked at)."""
     frames = _frames(num_frames)
     norms = norms_default()
     cfg = O.SelfSimConfig(0, 0, 0, 0, corr_frames * STEP, decim, 0.5, 0, 1.0, 1.0, 0, 1, STEP, NUM_CH - 1)
     ext, d, af_start, _ = O.selfsim_geometry(cfg, frames.shape[0], frames.shape[0])
     want_sim, want_img = O.selfsim_run(cfg, frames, None, norms)
     monkeypatch.setenv("SGZ_SELFSIM_FIX_CAP", "3")
+    monkeypatch.setenv("SGZ_SELFSIM_SLACK", "3e-3")
     monkeypatch.setenv("SGZ_SELFSIM_SEQ", knob)
     sim, img = ctx.selfsim(frames, None, norms, af_start, corr_frames, d, ext, 0.5)
     assert ext > 50 and np.array_equal(img, want_img)
