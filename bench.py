@@ -108,7 +108,7 @@ def _cpu_baseline_pinned(O, L: int, frames_per_file: int, budget_s: float) -> di
     rate = (probe_frames - L + 1) / dt
     want = max(1000, int(rate * budget_s))
     frames = min(frames_per_file, L + want - 1)
-    nfiles = max(1, min(8, int(round(want / (frames - L + 1)))))
+    nfiles = max(1, min(64, int(round(want / (frames - L + 1)))))
     db = [O.synth_file(SEED, f, frames, NUM_CH) for f in range(nfiles)]
     t0 = time.perf_counter()
     O.correlation_run(cfg, tgt, norms, db, dense=False)
