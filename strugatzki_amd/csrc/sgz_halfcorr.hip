@@ -15,6 +15,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include <cstring>
 #include <vector>
 
@@ -573,38 +574,42 @@ __global__ __launch_bounds__(256) void selfsim_gather_limbs_kernel(const float *
     }
 }
 
-// Similarity of one pixel's channel group from the product sum of the integers (already divided by the two windows'
+// Similarity of one pixel's channel group from the product sum P of the integers (already divided by the two windows'
 // powers of two) and the windows' statistics, or the mark for the exact evaluation: selfsim_pixel with the error
-// terms of the header comment.  (ra, rb: 1e-7 of the windows' raw sums of squares, the guard of the fp64
-// cancellation as there.)  `bound`: how far the returned similarity can be from the exact quotient because of the
-// product sum's error -- at most 8e-6, for ordinary windows a few 1e-7.
-__device__ __forceinline__ float selfsim_pixel8(double Sa, double mua, double SaR, double QaR, float sqa, float rhoa,
-                                                float lamMa, float lamLa, float ra, double mub, double SbR, double QbR,
-                                                float sqb, float rhob, float lamMb, float lamLb, float rb, double pSum,
-                                                double inv2n, float unsure, float &bound)
+// terms of the header comment.  With SR, QR the windows' raw sums, mu their shifts, S their shifted sums:
+//     sum (v - m)^2        = QaR + QbR - (SaR + SbR)^2 / 2n                  = Aa + Ab - Ua SbR
+//     2 sum (a - m)(b - m) = 2 (mua SbR + mub Sa + P) - (SaR + SbR)^2 / 2n   = 2 P + Ca SbR + Db Sa - (Ba + Bb)
+// with what depends on one window alone formed once per window and tile (selfsim_window_terms): A = QR - SR^2 / 2n,
+// B = SR^2 / 2n, U = SR / n, C = 2 mu - U, D = 2 mu.  (ra, rb: 1e-7 of the windows' raw sums of squares, the guard of
+// the fp64 cancellation as in selfsim_pixel.)  The quotient is a product with the reciprocal (v_rcp_f32, one unit of
+// the last place): kSsMixErr has room for it.  `bound`: how far the returned similarity can be from the exact quotient
+// because of the product sum's error -- at most 8e-6, for ordinary windows about 2e-6.
+__device__ __forceinline__ float selfsim_pixel8(double Sa, double Aa, double Ba, double Ca, double Ua, float sqa,
+                                                float rhoa, float lamMa, float lamLa, float ra, double SbR, double Ab,
+                                                double Bb, double Db, float sqb, float rhob, float lamMb, float lamLb,
+                                                float rb, double P, float unsure, float &bound)
 {
-    const double S = SaR + SbR;
-    const double s2 = S * S * inv2n;
-    const double varsum = (QaR + QbR) - s2;
-    const double cross2 = 2.0 * (fma(mua, SbR, fma(mub, Sa, pSum))) - s2;  // twice the centred product sum
+    const double varsum = fma(-Ua, SbR, Aa + Ab);
+    const double cross2 = fma(P, 2.0, fma(Ca, SbR, fma(Db, Sa, -(Ba + Bb))));  // twice the centred product sum
     const float v = (float)varsum;
     // digits left out, what the integers leave of the values, and the fp64 roundings of the sum's three terms
     const float err = fmaf(lamMa, lamLb, fmaf(lamLa, lamMb, fmaf(lamLa, lamLb, fmaf(rhoa, sqb, fmaf(rhob, sqa,
                       fmaf(3.0f * rhoa, rhob, 1.0e-14f * sqa * sqb))))));
     // 2 err <= 8e-6 varsum (both tests fail for NaN as well)
     const bool sure = err * 1.0001f <= 4.0e-6f * v && ra + rb <= v;
-    bound = 2.0003f * err * __builtin_amdgcn_rcpf(v);
-    return sure ? (float)cross2 / v : unsure;
+    const float rv = __builtin_amdgcn_rcpf(v);
+    bound = 2.0003f * err * rv;
+    return sure ? (float)cross2 * rv : unsure;
 }
 
 // What the fp32 steps add to the distance between a pixel's similarity and the reference's: the reference rounds each
 // group's fp64 quotient to fp32 once, multiplies by the weight and adds (impl/SelfSimilarityImpl.scala:143-146); here a
-// group's part is fl(fl(cross) / fl(var)), three roundings against one, then the same two products and one sum with
-// arguments that differ by the bounds: with u = 2^-24 and similarities of magnitude 1 at most that is 4 u for the
-// parts, 2 u for the products and 2 u for the sum, 8 u = 4.8e-7.
-constexpr float kSsMixErr = 6.0e-7f;
+// group's part is fl(cross) * rcp(fl(var)), four roundings and the reciprocal's unit of the last place against one,
+// then the same two products and one sum with arguments that differ by the bounds: with u = 2^-24 and similarities
+// of magnitude 1 at most that is 7 u for the parts, 2 u for the products and 2 u for the sum, 11 u = 6.6e-7.
+constexpr float kSsMixErr = 7.0e-7f;
 constexpr int kSfErrBytes = 32 * kSfThreads * 4;  // the first group's error bounds: a float per pixel
-constexpr int kSfHits = 4096;                     // uncertain pixels a tile collects before it appends them one by one
+constexpr int kSfHits = 2048;                     // uncertain pixels a tile collects before it appends them one by one
 
 __global__ __launch_bounds__(kSfThreads, 2) void selfsim_tile8_kernel(SelfSimArgs g)
 {
@@ -628,13 +633,15 @@ __global__ __launch_bounds__(kSfThreads, 2) void selfsim_tile8_kernel(SelfSimArg
     constexpr int kRow = kSsTile + 1;
     const float kUnsure = __int_as_float(0x7fc0beef);  // marks a pixel for the exact evaluation
     // behind the similarities of half a tile (64 rows): the statistics of the tile's 128 + 128 windows
-    double *stS = reinterpret_cast<double *>(lds + 64 * kRow), *stMu = stS + 2 * kSsTile, *stSR = stMu + 2 * kSsTile,
-           *stQR = stSR + 2 * kSsTile, *stF = stQR + 2 * kSsTile;
+    // (S: shifted sum, SR: raw sum, A, B, C, D, U: see selfsim_pixel8, F: the window's power of two)
+    double *stS = reinterpret_cast<double *>(lds + 64 * kRow), *stSR = stS + 2 * kSsTile, *stA = stSR + 2 * kSsTile,
+           *stB = stA + 2 * kSsTile, *stC = stB + 2 * kSsTile, *stD = stC + 2 * kSsTile, *stU = stD + 2 * kSsTile,
+           *stF = stU + 2 * kSsTile;
     float *stSq = reinterpret_cast<float *>(stF + 2 * kSsTile), *stRho = stSq + 2 * kSsTile, *stLamM = stRho + 2 * kSsTile,
           *stLamL = stLamM + 2 * kSsTile, *stR7 = stLamL + 2 * kSsTile;
     // behind the statistics: the tile's uncertain pixels (x | y << 8 within the tile)
     int *hits = reinterpret_cast<int *>(stR7 + 2 * kSsTile);
-    static_assert((64 * kRow) % 2 == 0 && (64 * kRow + (10 + 5) * 2 * kSsTile + kSfHits) * 4 <= kSfFrontBytes &&
+    static_assert((64 * kRow) % 2 == 0 && (64 * kRow + (16 + 5) * 2 * kSsTile + kSfHits) * 4 <= kSfFrontBytes &&
                       2 * kSfStageBytes <= kSfFrontBytes,
                   "stages resp. similarities, statistics and the uncertain pixels must fit the front memory");
     // the temporal group's part, later the pixel's similarity -- or, where only the raster is asked for, its colour
@@ -647,7 +654,6 @@ __global__ __launch_bounds__(kSfThreads, 2) void selfsim_tile8_kernel(SelfSimArg
     for (int group = g.doT ? 0 : 1; group < (g.doS ? 2 : 1); group++) {
         const int nkg = group == 0 ? g.kgT : g.kgS;  // units of 16 products: a multiple of 2
         const long long kg0 = group == 0 ? 0 : g.kgT;
-        const int n = H * (group == 0 ? 1 : g.numCh - 1);
         const long long plane = ((long long)g.kgT + g.kgS) * g.stride;
         const unsigned bytes = (unsigned)(((long long)(nkg - 1) * g.stride + kSsTile) * 16);
         // [side][digit]
@@ -719,10 +725,15 @@ __global__ __launch_bounds__(kSfThreads, 2) void selfsim_tile8_kernel(SelfSimArg
             const int wdw = min((tid < kSsTile ? X0 + tid : Y0 + tid - kSsTile), g.imgExt - 1);
             const SelfSimStat st = (tid < kSsTile ? g.st1 : g.st2)[2 * (long long)wdw + group];
             const SelfSimLimbs sp = (tid < kSsTile ? g.sp1 : g.sp2)[2 * (long long)wdw + group];
+            const double nn = (double)(H * (group == 0 ? 1 : g.numCh - 1));
+            const double b = st.SR * st.SR / (2.0 * nn), u = st.SR / nn;
             stS[tid] = st.S;
-            stMu[tid] = st.mu;
             stSR[tid] = st.SR;
-            stQR[tid] = st.QR;
+            stA[tid] = st.QR - b;
+            stB[tid] = b;
+            stC[tid] = 2.0 * st.mu - u;
+            stD[tid] = 2.0 * st.mu;
+            stU[tid] = u;
             stF[tid] = ldexp(1.0, 8 - sp.exp2);  // (2^16 of the sum's common factor, half on either side)
             stSq[tid] = sp.sq;
             stRho[tid] = sp.rho;
@@ -731,11 +742,10 @@ __global__ __launch_bounds__(kSfThreads, 2) void selfsim_tile8_kernel(SelfSimArg
             stR7[tid] = (float)(1.0e-7 * st.QR);
         }
         __syncthreads();
-        const double inv2n = 1.0 / (2.0 * (double)n);
         const int c0 = group == 0 ? 0 : 1, c1 = group == 0 ? 1 : g.numCh;
         const float wThis = group == 0 ? g.wT : 1.0f - g.wT;
         const int pyl = 32 * wy + l32, yb = kSsTile + pyl, py = Y0 + pyl;
-        const double mub = stMu[yb], SbR = stSR[yb], QbR = stQR[yb], fb = stF[yb];
+        const double SbR = stSR[yb], Ab = stA[yb], Bb = stB[yb], Db = stD[yb], fb = stF[yb];
         const float sqb = stSq[yb], rhob = stRho[yb], lamMb = stLamM[yb], lamLb = stLamL[yb], rb = stR7[yb];
         const bool both = g.doT && g.doS, lastGroup = group == (g.doS ? 1 : 0);
 #pragma unroll
@@ -746,9 +756,9 @@ __global__ __launch_bounds__(kSfThreads, 2) void selfsim_tile8_kernel(SelfSimArg
                 // sum qa qb / 2^16 (every term an integer below 2^53: exact)
                 const double t = fma((double)acc[0][i][v], 65536.0, fma((double)acc[1][i][v], 256.0, (double)acc[2][i][v]));
                 float bound;
-                float part = selfsim_pixel8(stS[pxl], stMu[pxl], stSR[pxl], stQR[pxl], stSq[pxl], stRho[pxl], stLamM[pxl],
-                                            stLamL[pxl], stR7[pxl], mub, SbR, QbR, sqb, rhob, lamMb, lamLb, rb,
-                                            t * stF[pxl] * fb, inv2n, kUnsure, bound);
+                float part = selfsim_pixel8(stS[pxl], stA[pxl], stB[pxl], stC[pxl], stU[pxl], stSq[pxl], stRho[pxl],
+                                            stLamM[pxl], stLamL[pxl], stR7[pxl], SbR, Ab, Bb, Db, sqb, rhob, lamMb, lamLb,
+                                            rb, t * stF[pxl] * fb, kUnsure, bound);
                 const bool inside = px < g.imgExt && py < g.imgExt && py >= px;
                 if (__float_as_int(part) == __float_as_int(kUnsure)) {
                     part = 0.0f;
@@ -805,30 +815,45 @@ __global__ __launch_bounds__(kSfThreads, 2) void selfsim_tile8_kernel(SelfSimArg
         }
         __syncthreads();
         const int XH = X0 + 32 * half;
-        // rows of the matrix: neighbouring lanes = neighbouring y
-        for (int idx = tid; idx < 64 * kSsTile; idx += kSfThreads) {
-            const int pxl = idx >> 7, pyl = idx & (kSsTile - 1);
-            const int px = XH + 64 * (pxl >> 5) + (pxl & 31), py = Y0 + pyl;
-            if (px >= g.imgExt || py >= g.imgExt || py < px) continue;
-            const float sim = lds[pxl * kRow + pyl];  // (the colour, where no similarities are asked for)
-            if (g.wantSim) g.simOut[(long long)px * g.imgExt + py] = sim;
-            // (the raster's row is imgExt - 1 - y: of the two pixels that show this value, the one whose
-            // neighbours along y lie in the same row)
-            if (g.imgOut)
-                g.imgOut[(long long)(g.imgExt - 1 - px) * g.imgExt + py] =
-                    g.wantSim ? gray_color(sim, g.warp, g.scale, g.inv) : __float_as_int(sim);
-        }
-        // rows of the mirror image: neighbouring lanes = neighbouring x
-        for (int idx = tid; idx < 64 * kSsTile; idx += kSfThreads) {
-            const int pxl = idx & 63, pyl = idx >> 6;
-            const int px = XH + 64 * (pxl >> 5) + (pxl & 31), py = Y0 + pyl;
-            if (px >= g.imgExt || py >= g.imgExt || py <= px) continue;
-            const float sim = lds[pxl * kRow + pyl];
-            if (g.wantSim) g.simOut[(long long)py * g.imgExt + px] = sim;
-            if (g.imgOut)
-                g.imgOut[(long long)(g.imgExt - 1 - py) * g.imgExt + px] =
-                    g.wantSim ? gray_color(sim, g.warp, g.scale, g.inv) : __float_as_int(sim);
-        }
+        // (kColour: only the raster is asked for and the staged values are colours already)
+        auto store = [&](auto colourOnly) {
+            constexpr bool kColour = decltype(colourOnly)::value;
+            // rows of the matrix: neighbouring lanes = neighbouring y
+            {
+                const int pyl = tid & (kSsTile - 1), py = Y0 + pyl;
+#pragma unroll
+                for (int it = 0; it < 64 * kSsTile / kSfThreads; it++) {
+                    const int pxl = (tid >> 7) + it * (kSfThreads / kSsTile);
+                    const int px = XH + 64 * (pxl >> 5) + (pxl & 31);
+                    if (px < g.imgExt && py < g.imgExt && py >= px) {
+                        const float sim = lds[pxl * kRow + pyl];
+                        if (!kColour) g.simOut[(long long)px * g.imgExt + py] = sim;
+                        // (the raster's row is imgExt - 1 - y: of the two pixels that show this value, the one whose
+                        // neighbours along y lie in the same row)
+                        if (g.imgOut)
+                            g.imgOut[(long long)(g.imgExt - 1 - px) * g.imgExt + py] =
+                                kColour ? __float_as_int(sim) : gray_color(sim, g.warp, g.scale, g.inv);
+                    }
+                }
+            }
+            // rows of the mirror image: neighbouring lanes = neighbouring x
+            {
+                const int pxl = tid & 63, px = XH + 64 * (pxl >> 5) + (pxl & 31);
+#pragma unroll
+                for (int it = 0; it < 64 * kSsTile / kSfThreads; it++) {
+                    const int pyl = (tid >> 6) + it * (kSfThreads / 64), py = Y0 + pyl;
+                    if (px < g.imgExt && py < g.imgExt && py > px) {
+                        const float sim = lds[pxl * kRow + pyl];
+                        if (!kColour) g.simOut[(long long)py * g.imgExt + px] = sim;
+                        if (g.imgOut)
+                            g.imgOut[(long long)(g.imgExt - 1 - py) * g.imgExt + px] =
+                                kColour ? __float_as_int(sim) : gray_color(sim, g.warp, g.scale, g.inv);
+                    }
+                }
+            }
+        };
+        if (g.wantSim) store(std::false_type{});
+        else store(std::true_type{});
     }
 }
 
