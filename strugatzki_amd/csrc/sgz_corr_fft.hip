@@ -61,6 +61,8 @@ using namespace sgz;
 
 namespace {
 
+constexpr int kTgtDqParts = 4;  // parts the target's rounding sums are kept in, per channel (sgz_context::d_tgtdq)
+
 // Deterministic sum of one float per thread over the workgroup (fixed order); result valid in thread 0.
 template <int T>
 __device__ __forceinline__ float block_sum(float v, float *scratch /* T / 64 floats */)
@@ -232,50 +234,28 @@ __global__ __launch_bounds__(N / 16) void fft_spectra_kernel(const FileDesc *__r
 }
 
 // fft_target_kernel: workgroup = channel pair of the target; the conjugated spectra divided by N (the inverse
-// transform's factor), packed like the database spectra.
+// transform's factor), packed like the database spectra, from the centred fp32 target (the first search after the
+// layout changed; a new target for a standing layout goes through fft_target_sub_kernel / fft_target_encode_kernel).
 // Q16: as 16-bit integers like the database's (q16_encode_band), with the scales and per channel the squared
 // distance of what was stored to what was computed.
-// FUSED: launched right behind the first pass of the target preparation, before the centred target exists: the
-// workgroups behind the channel pairs' carry out the centring pass (target_centre_body, whose report the host waits
-// for), while these form their centred values themselves from the normalised target and the means -- the same two
-// operations, so the same bits.
-template <int N, bool Q16, bool FUSED>
+template <int N, bool Q16>
 __global__ __launch_bounds__(N / 16) void fft_target_kernel(const float *__restrict__ aprime, int Lpad, int L, int numCh,
                                                             const float2 *__restrict__ tab, float2 *__restrict__ aspec,
-                                                            float *__restrict__ ascale, float *__restrict__ tgtdq,
-                                                            TargetCentreArgs ca)
+                                                            float *__restrict__ ascale, float *__restrict__ tgtdq)
 {
     constexpr int T = N / 16, NH = N / 2;
     extern __shared__ __attribute__((aligned(16))) float2 buf[];
     __shared__ float red[16];
     const int tid = threadIdx.x;
-    const int numPairs = (numCh + 1) / 2;
-    if constexpr (FUSED) {
-        if ((int)blockIdx.x >= numPairs) {
-            target_centre_body<T>((int)blockIdx.x - numPairs, (int)gridDim.x - numPairs, ca.L, ca.numCh, ca.Lpad, ca.tnorm,
-                                  ca.aprime, ca.aprimeF, ca.state, ca.counter, ca.hflags, ca.numFiles, ca.report, ca.seq);
-            return;
-        }
-    }
     const int c0 = 2 * blockIdx.x, c1 = c0 + 1;
     const bool two = c1 < numCh;
-    double mean0 = 0.0, mean1 = 0.0;
-    if constexpr (FUSED) {
-        mean0 = c0 == 0 ? ca.state[2] : ca.state[3];
-        mean1 = ca.state[3];
-    }
 #pragma unroll 4
     for (int m = 0; m < 16; m++) {
         const int n = tid + m * T;
         float a = 0.0f, b = 0.0f;
         if (n < L) {
-            if constexpr (FUSED) {
-                a = (float)((double)ca.tnorm[(size_t)n * numCh + c0] - mean0);
-                if (two) b = (float)((double)ca.tnorm[(size_t)n * numCh + c1] - mean1);
-            } else {
-                a = aprime[(size_t)c0 * Lpad + n];
-                if (two) b = aprime[(size_t)c1 * Lpad + n];
-            }
+            a = aprime[(size_t)c0 * Lpad + n];
+            if (two) b = aprime[(size_t)c1 * Lpad + n];
         }
         buf[fft_phys(n)] = make_float2(a, b);
     }
@@ -313,9 +293,161 @@ __global__ __launch_bounds__(N / 16) void fft_target_kernel(const float *__restr
     if constexpr (Q16) {
         const float e0 = block_sum<T>(dq0, red);
         const float e1 = block_sum<T>(dq1, red);
+        if (tid < kTgtDqParts) {  // (one workgroup: its sum is the first part, the others are empty)
+            tgtdq[kTgtDqParts * c0 + tid] = tid == 0 ? e0 : 0.0f;
+            if (two) tgtdq[kTgtDqParts * c1 + tid] = tid == 0 ? e1 : 0.0f;
+        }
+    }
+}
+
+// The target's spectra for a target that has just been normalised (the launch behind the first pass of the target
+// preparation): what fft_target_kernel<., ., true> does, cut into many small workgroups and a short second launch,
+// because a query waits for it.  The N-point transform of a channel pair is decimated in frequency by 16: with
+// n = n1 + M n2, M = N / 16, and k = 16 k1 + k2,
+//     Z[16 k1 + k2] = sum_n1 W_M^(n1 k1) { W_N^(n1 k2) sum_n2 z[n1 + M n2] W_16^(n2 k2) },
+// sixteen independent M-point transforms (fft_wave: one wave each), and of the sum over n2 only the first
+// ceil(L / M) terms are there -- the rest of the padded target is zero.  A pass like any other in the error account
+// (fft_eps: a sum of at most 16 terms with a table factor each and one more factor, against four butterfly levels
+// with their factors).
+// fft_target_sub_kernel: workgroups [0, 4 numPairs): four waves = four values of k2 of one pair, centred values
+// formed from the normalised target and the means, Z to memory as [k2][k1]; the other
+// workgroups carry the centring pass (target_centre_body).  fft_target_encode_kernel: a workgroup per pair, what
+// fft_target_kernel does after its transform.
+template <int N>
+__global__ __launch_bounds__(256) void fft_target_sub_kernel(int L, int numCh, const float2 *__restrict__ tab,
+                                                             float2 *__restrict__ zbuf, TargetCentreArgs ca)
+{
+    constexpr int M = N / 16, B = M / 16;
+    extern __shared__ __attribute__((aligned(16))) float2 dyn[];  // [4][M] exchange buffers, the pair's L values, 16 roots
+    const int numPairs = (numCh + 1) / 2;
+    if ((int)blockIdx.x >= 4 * numPairs) {
+        target_centre_body<256>((int)blockIdx.x - 4 * numPairs, (int)gridDim.x - 4 * numPairs, ca.L, ca.numCh, ca.Lpad,
+                                ca.tnorm, ca.aprime, ca.aprimeF, ca.state, ca.counter, ca.hflags, ca.numFiles, ca.report,
+                                ca.seq);
+        return;
+    }
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pair = blockIdx.x >> 2, k2 = 4 * (blockIdx.x & 3) + wave;
+    const int c0 = 2 * pair, c1 = c0 + 1;
+    const bool two = c1 < numCh;
+    // (the means through the vector memory path -- an index the compiler cannot see through -- so that they travel with
+    // the loads below instead of ahead of them on the scalar path)
+    const double *stv = ca.state + threadIdx.y;
+    const double mean0 = c0 == 0 ? stv[2] : stv[3], mean1 = stv[3];
+    // the pair's centred values, once per workgroup (its four waves sum over the same ones): a frame's two channels
+    // are neighbours in the normalised target; twelve frames per thread in flight at a time (a 30 s target: all of
+    // them -- what the first pass of the preparation wrote has to come from memory, a round trip of microseconds)
+    const int terms = (L + M - 1) / M;  // of the sum over n2; the values are padded with zeros to terms * M
+    float2 *wb = dyn + wave * M, *cin = dyn + 4 * M, *w16 = cin + terms * M;
+    constexpr int U = 12;
+    const bool packed = (numCh & 1) == 0;  // a frame's two channels as one 8-byte load
+    for (int n0 = threadIdx.x; n0 < terms * M; n0 += U * 256) {
+        float2 x[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int n = n0 + 256 * u;
+            x[u] = make_float2(0.0f, 0.0f);
+            if (n < L) {
+                const float *src = ca.tnorm + (size_t)n * numCh + c0;
+                if (packed) x[u] = *reinterpret_cast<const float2 *>(src);
+                else x[u] = make_float2(src[0], two ? src[1] : 0.0f);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int n = n0 + 256 * u;
+            if (n < terms * M)
+                cin[n] = n < L ? make_float2((float)((double)x[u].x - mean0), two ? (float)((double)x[u].y - mean1) : 0.0f)
+                               : make_float2(0.0f, 0.0f);
+        }
+    }
+    if (threadIdx.x < 16) w16[threadIdx.x] = c_dir<-1>(tab[threadIdx.x * (kFftTab / 16)]);  // the sixteenth roots
+    FftWaveFactors<M> wf;
+    fft_wave_factors<M>(wf, tab, lane);
+    float2 wn[16];
+    if (lane < B) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) wn[r] = tab[((lane + r * B) * k2) * (kFftTab / N)];
+    }
+    __syncthreads();
+    float2 v[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) v[r] = make_float2(0.0f, 0.0f);
+    if (lane < B) {
+        for (int n2 = 0; n2 < terms; n2++) {
+            const float2 w = w16[(n2 * k2) & 15];
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                v[r] = c_add(v[r], c_mul(cin[lane + r * B + M * n2], w));
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) v[r] = c_mul(v[r], c_dir<-1>(wn[r]));
+    }
+    fft_wave<M, -1>(v, wb, wf, lane);
+    float2 *z = zbuf + (size_t)pair * N + (size_t)k2 * M;  // Z[16 k1 + k2] at [k2][k1]
+#pragma unroll
+    for (int m = 0; m < M / 64; m++) {
+        const int k1 = lane + 64 * m;
+        z[k1] = wb[fft_phys(k1)];
+    }
+}
+
+template <int N, bool Q16>
+__global__ __launch_bounds__(N / 64) void fft_target_encode_kernel(const float2 *__restrict__ zbuf, int numCh,
+                                                                   float2 *__restrict__ aspec, float *__restrict__ ascale,
+                                                                   float *__restrict__ tgtdq)
+{
+    // kTgtDqParts workgroups per pair, each a quarter of the half spectrum: eight bins per thread
+    constexpr int T = N / 64, NH = N / 2;
+    static_assert(kTgtDqParts == 4 && T % 64 == 0, "a quarter of the bins per workgroup, whole bands per wave");
+    __shared__ float red[16];
+    const int tid = threadIdx.x;
+    const int pair = blockIdx.x / kTgtDqParts, part = blockIdx.x % kTgtDqParts;
+    const int c0 = 2 * pair, c1 = c0 + 1;
+    const bool two = c1 < numCh;
+    const float2 *z = zbuf + (size_t)pair * N;
+    constexpr float rN = 1.0f / (float)N;
+    float2 zj[8], zm[8];
+#pragma unroll
+    for (int m = 0; m < 8; m++) {  // all loads first
+        const int j = part * (NH / kTgtDqParts) + tid + m * T, jm = (N - j) & (N - 1);
+        zj[m] = z[(j & 15) * (N / 16) + (j >> 4)];  // (the sub-transforms' order: [k mod 16][k / 16])
+        zm[m] = z[(jm & 15) * (N / 16) + (jm >> 4)];
+    }
+    const float2 zn = z[(NH & 15) * (N / 16) + (NH >> 4)];
+    float dq0 = 0.0f, dq1 = 0.0f;
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+        const int j = part * (NH / kTgtDqParts) + tid + m * T;
+        float2 xa, xb;
+        untangle(zj[m], zm[m], xa, xb);
+        xa = make_float2(xa.x * rN, -xa.y * rN);
+        xb = make_float2(xb.x * rN, -xb.y * rN);
+        if (j == 0) {
+            xa = make_float2(zj[m].x * rN, zn.x * rN);
+            xb = make_float2(zj[m].y * rN, zn.y * rN);
+        }
+        if constexpr (Q16) {
+            unsigned int *aq = reinterpret_cast<unsigned int *>(aspec);
+            float sa, sb;
+            aq[(size_t)c0 * NH + j] = q16_encode_band(xa, sa, dq0);
+            if ((tid & 63) == 0) ascale[(size_t)c0 * (NH / 64) + (j >> 6)] = sa;
+            if (two) {
+                aq[(size_t)c1 * NH + j] = q16_encode_band(xb, sb, dq1);
+                if ((tid & 63) == 0) ascale[(size_t)c1 * (NH / 64) + (j >> 6)] = sb;
+            }
+        } else {
+            aspec[(size_t)c0 * NH + j] = xa;
+            if (two) aspec[(size_t)c1 * NH + j] = xb;
+        }
+    }
+    if constexpr (Q16) {
+        const float e0 = block_sum<T>(dq0, red);
+        const float e1 = block_sum<T>(dq1, red);
         if (tid == 0) {
-            tgtdq[c0] = e0;
-            if (two) tgtdq[c1] = e1;
+            tgtdq[kTgtDqParts * c0 + part] = e0;
+            if (two) tgtdq[kTgtDqParts * c1 + part] = e1;
         }
     }
 }
@@ -434,10 +566,14 @@ __global__ __launch_bounds__(N / 16, 4) void corr_fft_kernel(const FileDesc *__r
         // and the target's -- a target spectrum off by d (half spectrum) moves a cross term by at most
         // sqrt(2) |d| |X| = sqrt(2 N) |d| |x_block|
         const float2 bq = blkq[blockIdx.x];
+        // (per channel in kTgtDqParts parts, one per workgroup that encoded a share of the spectrum)
+        auto dqOf = [&](int c) {
+            return (tgtdq[kTgtDqParts * c] + tgtdq[kTgtDqParts * c + 1]) + (tgtdq[kTgtDqParts * c + 2] + tgtdq[kTgtDqParts * c + 3]);
+        };
         float tqS = 0.0f;
-        for (int c = 1; c < numCh; c++) tqS += tgtdq[c];
+        for (int c = 1; c < numCh; c++) tqS += dqOf(c);
         const float tscale = __builtin_amdgcn_sqrtf(2.0f * (float)N) * 1.001f;
-        const float tqT = __builtin_amdgcn_sqrtf(tgtdq[0]) * tscale;
+        const float tqT = __builtin_amdgcn_sqrtf(dqOf(0)) * tscale;
         tqS = __builtin_amdgcn_sqrtf(tqS) * tscale;
         absT += (fg.aT * bq.x + tqT * bn.x) * 1.0001f * fg.kT;
         absS += (fg.aS * bq.y + tqS * bn.y) * 1.0001f * fg.kS;
@@ -749,29 +885,45 @@ int fft_target_launch(sgz_context *ctx, hipStream_t stream, const TargetCentreAr
     const bool q16 = fg.q16 != 0;
     if (q16) {
         if ((rc = ensure(ctx, ctx->d_aspecscale, ctx->aspecscale_cap, (size_t)numCh * (N / 128)))) return rc;
-        if ((rc = ensure(ctx, ctx->d_tgtdq, ctx->tgtdq_cap, (size_t)numCh))) return rc;
+        if ((rc = ensure(ctx, ctx->d_tgtdq, ctx->tgtdq_cap, (size_t)numCh * kTgtDqParts))) return rc;
     }
     const size_t lds = sizeof(float2) * fft_lds_elems(N);
     const int Lpad = ctx->cp.S * kR;
-    const TargetCentreArgs ca = centre ? *centre : TargetCentreArgs{};
-    // the workgroups of the centring pass: N / 16 threads, four elements per thread
-    const int extra = centre ? (int)(((size_t)numCh * Lpad + (size_t)(N / 16) * kTpPer - 1) / ((size_t)(N / 16) * kTpPer)) : 0;
+    if (centre) {
+        // behind the first pass of the target preparation: sixteen sub-transforms per pair and the centring pass in
+        // one launch, the encoding of the spectra in a second one
+        if ((rc = ensure(ctx, ctx->d_tgt_z, ctx->tgt_z_cap, (size_t)numPairs * N))) return rc;
+        const int extra = fft_target_centre_workgroups(ctx, numCh, Lpad);
+        auto both = [&](auto subK, auto encK) -> int {
+            const size_t subLds = sizeof(float2) * ((size_t)4 * (N / 16) + (size_t)((L + N / 16 - 1) / (N / 16)) * (N / 16) + 16);
+            if ((rc = set_lds(ctx, subK, subLds))) return rc;
+            hipLaunchKernelGGL(subK, dim3(4 * numPairs + extra), dim3(256), subLds, stream, L, numCh, ctx->d_fft_tab,
+                               ctx->d_tgt_z, *centre);
+            SGZ_HIP(ctx, hipGetLastError());
+            hipLaunchKernelGGL(encK, dim3(numPairs * kTgtDqParts), dim3(N / 64), 0, stream, ctx->d_tgt_z, numCh, ctx->d_aspec,
+                               q16 ? ctx->d_aspecscale : nullptr, q16 ? ctx->d_tgtdq : nullptr);
+            SGZ_HIP(ctx, hipGetLastError());
+            return SGZ_OK;
+        };
+        if (N == 4096)
+            return q16 ? both(fft_target_sub_kernel<4096>, fft_target_encode_kernel<4096, true>)
+                       : both(fft_target_sub_kernel<4096>, fft_target_encode_kernel<4096, false>);
+        if (N == 8192)
+            return q16 ? both(fft_target_sub_kernel<8192>, fft_target_encode_kernel<8192, true>)
+                       : both(fft_target_sub_kernel<8192>, fft_target_encode_kernel<8192, false>);
+        return q16 ? both(fft_target_sub_kernel<16384>, fft_target_encode_kernel<16384, true>)
+                   : both(fft_target_sub_kernel<16384>, fft_target_encode_kernel<16384, false>);
+    }
     auto launch = [&](auto kern) -> int {
         if ((rc = set_lds(ctx, kern, lds))) return rc;
-        hipLaunchKernelGGL(kern, dim3(numPairs + extra), dim3(N / 16), lds, stream, ctx->d_aprime_f, Lpad, L, numCh,
-                           ctx->d_fft_tab, ctx->d_aspec, q16 ? ctx->d_aspecscale : nullptr, q16 ? ctx->d_tgtdq : nullptr,
-                           ca);
+        hipLaunchKernelGGL(kern, dim3(numPairs), dim3(N / 16), lds, stream, ctx->d_aprime_f, Lpad, L, numCh,
+                           ctx->d_fft_tab, ctx->d_aspec, q16 ? ctx->d_aspecscale : nullptr, q16 ? ctx->d_tgtdq : nullptr);
         SGZ_HIP(ctx, hipGetLastError());
         return SGZ_OK;
     };
-    auto pick = [&](auto n_) -> int {
-        constexpr int kN = decltype(n_)::value;
-        if (centre) return q16 ? launch(fft_target_kernel<kN, true, true>) : launch(fft_target_kernel<kN, false, true>);
-        return q16 ? launch(fft_target_kernel<kN, true, false>) : launch(fft_target_kernel<kN, false, false>);
-    };
-    if (N == 4096) return pick(std::integral_constant<int, 4096>{});
-    if (N == 8192) return pick(std::integral_constant<int, 8192>{});
-    return pick(std::integral_constant<int, 16384>{});
+    if (N == 4096) return q16 ? launch(fft_target_kernel<4096, true>) : launch(fft_target_kernel<4096, false>);
+    if (N == 8192) return q16 ? launch(fft_target_kernel<8192, true>) : launch(fft_target_kernel<8192, false>);
+    return q16 ? launch(fft_target_kernel<16384, true>) : launch(fft_target_kernel<16384, false>);
 }
 
 // The target-dependent factors of the error bound, from the target's statistics (host arithmetic).
@@ -824,8 +976,9 @@ int fft_target_spectra(sgz_context *ctx, hipStream_t stream, const void *centre_
 
 int fft_target_centre_workgroups(const sgz_context *ctx, int numCh, int Lpad)
 {
-    const size_t per = (size_t)(ctx->fg.N / 16) * kTpPer;
-    return per ? (int)(((size_t)numCh * Lpad + per - 1) / per) : 0;
+    // workgroups of 256 threads (fft_target_sub_kernel), four elements per thread
+    const size_t per = (size_t)256 * kTpPer;
+    return ctx->fg.N > 0 ? (int)(((size_t)numCh * Lpad + per - 1) / per) : 0;
 }
 
 void fft_target_ready(sgz_context *ctx)
@@ -837,7 +990,7 @@ void fft_target_ready(sgz_context *ctx)
 void fft_screen_free(sgz_context *ctx)
 {
     void *bufs[] = {ctx->d_fblocks, ctx->d_spec, ctx->d_aspec, ctx->d_fft_tab, ctx->d_blksq, ctx->d_blknorm, ctx->d_blklnmin, ctx->d_prelist, ctx->d_precount,
-                    ctx->d_specscale, ctx->d_blkdq, ctx->d_blkq, ctx->d_aspecscale, ctx->d_tgtdq};
+                    ctx->d_specscale, ctx->d_blkdq, ctx->d_blkq, ctx->d_aspecscale, ctx->d_tgtdq, ctx->d_tgt_z};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
 }

@@ -187,6 +187,98 @@ __device__ __forceinline__ void fft_lds(float2 *buf, const float2 *__restrict__ 
         __syncthreads();
     }
 }
+
+// A transform of M = 256, 512 or 1024 points by ONE wave (lane = butterfly of the radix-16 passes; with M < 1024 the
+// upper lanes idle), for the decimated sub-transforms of a longer one: two radix-16 passes (strides 1, 16) and one of
+// radix M / 256 at stride 256.  `v` holds the input of the lane's first butterfly, element r = point lane + r M / 16
+// (the caller forms it in registers); buf takes the exchanges and, on return (synchronised), the result in natural
+// order.  Every wave of the workgroup must call it (the barriers are the workgroup's).
+// The table factors are fetched by fft_wave_factors, which the caller places ahead of its own memory work: between
+// the barriers of the transform every such load would be a round trip of its own.
+template <int M>
+struct FftWaveFactors {
+    float2 p2[4];      // second pass: powers 1, 2, 4, 8 of the butterfly's factor
+    float2 last[4][3]; // last pass: butterflies lane + 64 m, elements 1 .. M / 256 - 1
+};
+
+template <int M>
+__device__ __forceinline__ void fft_wave_factors(FftWaveFactors<M> &f, const float2 *__restrict__ tab, int lane)
+{
+    const int k = lane & 15;
+    constexpr int s2 = kFftTab / (16 * 16);
+    f.p2[0] = tab[k * s2];
+    f.p2[1] = tab[2 * k * s2];
+    f.p2[2] = tab[4 * k * s2];
+    f.p2[3] = tab[8 * k * s2];
+    constexpr int R = M / 256, stride = kFftTab / M;
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int r = 1; r < R; r++) f.last[m][r - 1] = tab[r * (lane + 64 * m) * stride];
+}
+
+template <int M, int DIR>
+__device__ __forceinline__ void fft_wave(float2 (&v)[16], float2 *buf, const FftWaveFactors<M> &f, int lane)
+{
+    static_assert(M == 256 || M == 512 || M == 1024, "sub-transform length");
+    constexpr int B = M / 16;  // butterflies of a radix-16 pass
+    const bool act = lane < B;
+    if (act) {
+        dft16<DIR>(v);  // first pass: stride 1, no factors
+        fft16_store<1>(buf, lane, v);
+    }
+    __syncthreads();
+    if (act) {
+        fft16_load<M>(buf, lane, v);
+        // second pass, stride 16: the factors' powers as fft16_math forms them
+        float2 w[16];
+        w[1] = c_dir<DIR>(f.p2[0]);
+        w[2] = c_dir<DIR>(f.p2[1]);
+        w[4] = c_dir<DIR>(f.p2[2]);
+        w[8] = c_dir<DIR>(f.p2[3]);
+        w[3] = c_mul(w[1], w[2]);
+        w[5] = c_mul(w[1], w[4]);
+        w[6] = c_mul(w[2], w[4]);
+        w[9] = c_mul(w[1], w[8]);
+        w[10] = c_mul(w[2], w[8]);
+        w[12] = c_mul(w[4], w[8]);
+        w[7] = c_mul(w[3], w[4]);
+        w[11] = c_mul(w[3], w[8]);
+        w[13] = c_mul(w[5], w[8]);
+        w[14] = c_mul(w[6], w[8]);
+        w[15] = c_mul(w[7], w[8]);
+#pragma unroll
+        for (int r = 1; r < 16; r++) v[r] = c_mul(v[r], w[r]);
+        dft16<DIR>(v);
+    }
+    __syncthreads();
+    if (act) fft16_store<16>(buf, lane, v);
+    __syncthreads();
+    constexpr int R = M / 256;
+    if constexpr (R > 1) {
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const int j = lane + 64 * m;  // butterfly j < 256: elements j + 256 r, factors exp(DIR 2 pi i r j / M)
+            if constexpr (R == 2) {
+                const float2 a = buf[fft_phys(j)];
+                const float2 b = c_mul(buf[fft_phys(j + 256)], c_dir<DIR>(f.last[m][0]));
+                buf[fft_phys(j)] = c_add(a, b);
+                buf[fft_phys(j + 256)] = c_sub(a, b);
+            } else {
+                float2 a = buf[fft_phys(j)];
+                float2 b = c_mul(buf[fft_phys(j + 256)], c_dir<DIR>(f.last[m][0]));
+                float2 c = c_mul(buf[fft_phys(j + 512)], c_dir<DIR>(f.last[m][1]));
+                float2 d = c_mul(buf[fft_phys(j + 768)], c_dir<DIR>(f.last[m][2]));
+                dft4<DIR>(a, b, c, d);
+                buf[fft_phys(j)] = a;
+                buf[fft_phys(j + 256)] = b;
+                buf[fft_phys(j + 512)] = c;
+                buf[fft_phys(j + 768)] = d;
+            }
+        }
+        __syncthreads();
+    }
+}
 #endif
 
 }  // namespace sgz

@@ -274,7 +274,9 @@ struct sgz_context {
     size_t blkdq_cap = 0;
     float *d_aspecscale = nullptr;           // 16-bit spectra: the target's scales [numCh][N / 128]
     size_t aspecscale_cap = 0;
-    float *d_tgtdq = nullptr;                // 16-bit spectra: [numCh] sum of squares of the target spectra's rounding
+    float2 *d_tgt_z = nullptr;               // a new target's transforms before they are encoded: [pair][N]
+    size_t tgt_z_cap = 0;
+    float *d_tgtdq = nullptr;                // 16-bit spectra: [numCh][4] sums of squares of the target spectra's rounding, in four parts
     size_t tgtdq_cap = 0;
     float2 *d_blkq = nullptr;                // per block: that rounding as a norm of time-domain values, loudness / others
     size_t blkq_cap = 0;
