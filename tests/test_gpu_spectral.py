@@ -132,6 +132,29 @@ def test_a_new_target_for_a_resident_database(spectral, monkeypatch, n):
         assert [(g.sim, g.file, g.start, g.stop) for g in got] == [(w.sim, w.file, w.start, w.stop) for w in want]
 
 
+@pytest.mark.parametrize("L,n,num_ch", [(700, 4096, 14), (3000, 4096, 14), (1500, 8192, 5), (2584, 16384, 14),
+                                         (5168, 16384, 14), (900, 16384, 3)])
+def test_bounds_with_a_target_set_on_a_standing_layout(spectral, monkeypatch, L, n, num_ch):
+    """The second target of a length goes through other kernels than the first (its transform is cut into sixteen
+    sub-transforms per channel pair, with one to six terms in the first stage here, and an odd channel count leaves
+    the last pair half empty): the bounds it gives must enclose the oracle's similarities like the first one's."""
+    ctx = spectral
+    monkeypatch.setenv("SGZ_FFT_N", str(n))
+    nf, frames = 3, L + 2500
+    tfile = O.synth_file(SEED, -1, 2 * L + 100, num_ch)
+    db = [O.synth_file(SEED, g, frames, num_ch) for g in range(nf)]
+    norms = norms_default(num_ch)
+    _load(ctx, db, norms)
+    for ts in (7, L + 50):  # first target: the layout is built behind it; second: beside a standing layout
+        db_t = tfile[ts:ts + L]
+        cfg = corr_config(ts, L, num_matches=2, num_ch=num_ch)
+        _, sims, boosts = O.correlation_run(cfg, tfile, norms, db)
+        ctx.corr_set_target(db_t, 0.5, 8.0)
+        ctx.corr_run_screen_f16(0, nf)
+        assert ctx.screen_kernel_in_use == "spectral" and ctx.screen_geometry[0] == n
+        _check_upper(ctx, sims, boosts)
+
+
 @pytest.mark.parametrize("weight", [0.0, 1.0, 0.25])
 def test_weights(spectral, weight):
     """temporalWeight 0 and 1 leave one channel group out (impl/FeatureCorrelationImpl.scala:201-206)."""
