@@ -186,11 +186,11 @@ def main() -> int:
                          "loop at N=1 for roofline.exact; 0 disables")
     ap.add_argument("--num-matches", type=int, default=10)
     ap.add_argument("--settle-ms", type=float, default=100.0,
-                    help="untimed steps for about this long (counted as 0.3 ms each) before the warm-up steps, so that the "
-                         "clocks have settled")
+                    help="untimed steps for about this long (counted as 0.1 ms each at N = 1, 0.3 ms at N > 1) before the "
+                         "warm-up steps, so that the clocks have settled")
     ap.add_argument("--timing-every", type=int, default=32,
                     help="HIP events with one launch in n of the dominant kernel, at most; with few timed steps n is "
-                         "lowered so that at least four launches of the timed region carry them.  A launch that "
+                         "lowered so that at least two launches of the timed region carry them.  A launch that "
                          "carries events costs the host about 20 us more than one that does not (measured: "
                          "tools/search_loop.cpp), so the kernel's average duration over the timed region comes from "
                          "a sample of its launches")
@@ -329,9 +329,9 @@ def main() -> int:
     gc.freeze()
 
     # HIP events travel with one launch in timing_every of the dominant kernel: at most --timing-every, and few
-    # enough that four launches of the timed region carry them
+    # enough that two launches of the timed region carry them (such a launch costs the host 20 us more)
     def every_for(steps):
-        return max(1, min(args.timing_every, steps // 4)) if mode == "f16" else 1
+        return max(1, min(args.timing_every, steps // 2)) if mode == "f16" else 1
 
     def timed_leg(fn, steps):
         """`steps` calls of fn between two synchronisations: (seconds, kernel times of the sampled launches)."""
@@ -354,13 +354,14 @@ def main() -> int:
     # Clock settling, untimed and reported as such: after an idle period the chip needs some tens of
     # milliseconds of load before it holds its clocks; the first steps then run 5-10 % slower than the rest.
     # (a fixed count, the same on every rank: the sharded step holds a collective)
-    ctx.set_kernel_timing(0)
+    # (the untimed steps carry timing events like the timed ones: the library creates its events on first use)
+    ctx.set_kernel_timing(every_for(args.steps))
     matches = step()
     # which kernel the layout of this database and target uses for the bounds
     spectral = mode == "f16" and ctx.screen_kernel_in_use == "spectral"
     fft_n, fft_hop, fft_blocks = ctx.screen_geometry
     spectra_q16 = ctx.spectra_format_in_use == "q16"
-    settle_steps = int(args.settle_ms / 0.3)
+    settle_steps = int(args.settle_ms / (0.3 if world > 1 else 0.1))  # (a step: about 0.1 ms at N = 1, 0.57 at N > 1)
     for _ in range(settle_steps):
         step()
     for _ in range(args.warmup):
