@@ -1413,8 +1413,9 @@ __global__ __launch_bounds__(256) void rescore_final_kernel(const FileDesc *__re
 // flight at once; the first kernel reads the raw frames from where the host left them, pinned host memory: 145 KB
 // for a 30 s target, cheaper to read in place than to copy first).  Every sum is taken in a fixed order that
 // depends on nothing but the target's shape -- a thread adds its four elements in index order, the 64 lanes of a
-// wave are folded by a butterfly, the 4 waves of a workgroup added in wave order, and the workgroup that finishes
-// last adds the workgroups' sums in workgroup order -- so a target always gets the same statistics; they differ
+// wave are folded by a butterfly, the 4 waves of a workgroup added in wave order, and the workgroups' sums are added
+// in workgroup order (by every workgroup of the second pass for itself; the second pass' by the workgroup that
+// finishes last) -- so a target always gets the same statistics; they differ
 // from a sequential summation in the reference's order by a few units of the last place of the fp64 sums.
 // The scalars go to pinned host memory, followed by a sequence word the host polls: the host needs them as
 // kernel arguments of everything that follows.
@@ -1424,8 +1425,7 @@ constexpr int kTpTile = kTpThreads * kTpPer;     // elements per workgroup
 
 __global__ __launch_bounds__(kTpThreads) void target_norm_kernel(const float *__restrict__ frames, int L, int numCh,
                                                                  const float *__restrict__ normTab, int normEnabled,
-                                                                 float *__restrict__ tnorm, double *__restrict__ state,
-                                                                 unsigned int *__restrict__ counter)
+                                                                 float *__restrict__ tnorm, double *__restrict__ state)
 {
     __shared__ double red[(kTpThreads / 64) * 2];
     // elements in the order of the interleaved frames (e = frame * numCh + channel): reads and writes of a wave are
@@ -1450,23 +1450,14 @@ __global__ __launch_bounds__(kTpThreads) void target_norm_kernel(const float *__
             s1[c > 0] += (double)v;
         }
     }
+    // (the launch ends here, with the workgroups' partial sums: the second pass adds them up itself)
     tp_wg_sums<kTpThreads, 2>(s1, red, state + 4 + (size_t)blockIdx.x * kTpSums);
-    __shared__ int lastFlag;
-    if (!tp_last_workgroup(counter, (int)gridDim.x, &lastFlag)) return;
-    __shared__ double rows[(kTpThreads / kTpSums) * kTpSums];
-    const double s = tp_final_sum<kTpThreads, 2>(state, rows, (int)gridDim.x);
-    if (threadIdx.x < 2) {
-        state[threadIdx.x] = s;
-        const double cnt = threadIdx.x == 0 ? (double)L : (double)L * (double)(numCh - 1);
-        state[2 + threadIdx.x] = s / cnt;  // MathUtil.stat: mean = sum / n
-    }
-    if (threadIdx.x == 0) *counter = 0u;
 }
 
 __global__ __launch_bounds__(kTpThreads) void target_centre_kernel(TargetCentreArgs a)
 {
     target_centre_body<kTpThreads>((int)blockIdx.x, (int)gridDim.x, a.L, a.numCh, a.Lpad, a.tnorm, a.aprime, a.aprimeF,
-                                   a.state, a.counter, a.hflags, a.numFiles, a.report, a.seq);
+                                   a.state, a.normWgs, a.hflags, a.numFiles, a.report, a.seq);
 }
 
 // ---------------------------------------------------------------------------
@@ -1990,7 +1981,11 @@ int sgz_corr_set_target(sgz_context *ctx, const float *frames, int num_frames, f
     const size_t Lpad = (size_t)S * kR;
     const size_t nTb = (size_t)numCh * L, nAp = (size_t)numCh * Lpad;
     auto up256 = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    const size_t offRaw = 0, offRep = up256(offRaw + sizeof(float) * nTb), offAp = up256(offRep + sizeof(TargetReport));
+    // (the report: the first pass' two sums, the second pass' partial sums per unit of 1024 elements, a sequence word
+    // per workgroup)
+    const size_t tpUnits = (nAp + kTpTile - 1) / kTpTile;
+    const size_t repBytes = sizeof(double) * (2 + tpUnits * kTpSums) + sizeof(unsigned long long) * tpUnits;
+    const size_t offRaw = 0, offRep = up256(offRaw + sizeof(float) * nTb), offAp = up256(offRep + repBytes);
     const size_t offImg = up256(offAp + sizeof(double) * nAp);
     const size_t imgHalfwords = sgz::half_image_halfwords(L, numCh);
     const size_t stageBytes = up256(offImg + sizeof(uint16_t) * imgHalfwords);
@@ -2005,35 +2000,28 @@ int sgz_corr_set_target(sgz_context *ctx, const float *frames, int num_frames, f
         ctx->tgt_stage_cap = 0;
         SGZ_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_tgt_stage), stageBytes, hipHostMallocDefault));
         ctx->tgt_stage_cap = stageBytes;
-        std::memset(ctx->h_tgt_stage + offRep, 0, sizeof(TargetReport));
     }
     std::memcpy(ctx->h_tgt_stage + offRaw, frames, sizeof(float) * nTb);
-    TargetReport *rep = reinterpret_cast<TargetReport *>(ctx->h_tgt_stage + offRep);
+    TargetReportLayout repl;
+    repl.sum1 = reinterpret_cast<double *>(ctx->h_tgt_stage + offRep);
+    repl.rows = repl.sum1 + 2;
+    repl.flags = reinterpret_cast<unsigned long long *>(repl.rows + tpUnits * kTpSums);
     int rc;
     if ((rc = ensure(ctx, ctx->d_aprime, ctx->aprime_cap, nAp))) return rc;
     if ((rc = ensure(ctx, ctx->d_tnorm, ctx->tnorm_cap, nTb))) return rc;
     if ((rc = ensure(ctx, ctx->d_aprime_f, ctx->aprime_f_cap, nAp))) return rc;
     const unsigned long long seq = ++ctx->tgt_seq;
-    // (the report may sit at another offset than last time: the word the host polls must not hold this number yet)
-    __atomic_store_n(&rep->seq, 0ull, __ATOMIC_RELEASE);
+    // (the report may sit at another offset than last time: the words the host polls must not hold this number yet)
+    for (size_t w = 0; w < tpUnits; w++) __atomic_store_n(repl.flags + w, 0ull, __ATOMIC_RELEASE);
     // (the second pass runs over the padded copies, in workgroups of 256 threads or -- carried along by the launch
     // that transforms the target -- of more: the larger grid sizes the buffer of partial sums)
     const int tpGridA = (int)((nTb + kTpTile - 1) / kTpTile), tpGrid = (int)((nAp + kTpTile - 1) / kTpTile);
-    {
-        const size_t need = (size_t)4 + (size_t)tpGrid * kTpSums + 1;
-        const bool fresh = !ctx->d_tgt_state || need > ctx->tgt_state_cap;  // (a new buffer may get the old address)
-        if ((rc = ensure(ctx, ctx->d_tgt_state, ctx->tgt_state_cap, need))) return rc;
-        if (fresh) {  // the last double of the buffer is the workgroup counter: starts at zero
-            ctx->tgt_counter_off = ctx->tgt_state_cap - 1;
-            SGZ_HIP(ctx, hipMemsetAsync(ctx->d_tgt_state + ctx->tgt_counter_off, 0, sizeof(double), ctx->stream));
-        }
-    }
-    unsigned int *tpCounter = reinterpret_cast<unsigned int *>(ctx->d_tgt_state + ctx->tgt_counter_off);
+    if ((rc = ensure(ctx, ctx->d_tgt_state, ctx->tgt_state_cap, (size_t)4 + (size_t)tpGridA * kTpSums))) return rc;
     // the marks of the previous target's screening runs go with it (a layout that is rebuilt clears all marks itself)
     const int nfMarks = ctx->d_hflags && ctx->hflags_cap >= ctx->files.size() && !ctx->layout_dirty ? (int)ctx->files.size() : 0;
     hipLaunchKernelGGL(target_norm_kernel, dim3(tpGridA), dim3(kTpThreads), 0, ctx->stream,
                        reinterpret_cast<const float *>(ctx->h_tgt_stage + offRaw), L, numCh, ctx->d_normtab,
-                       ctx->norm.enabled, ctx->d_tnorm, ctx->d_tgt_state, tpCounter);
+                       ctx->norm.enabled, ctx->d_tnorm, ctx->d_tgt_state);
     SGZ_HIP(ctx, hipGetLastError());
     CorrParams &cp = ctx->cp;
     const int oldL = ctx->have_target ? cp.L : -1;
@@ -2055,10 +2043,10 @@ int sgz_corr_set_target(sgz_context *ctx, const float *frames, int num_frames, f
     ca.aprime = ctx->d_aprime;
     ca.aprimeF = ctx->d_aprime_f;
     ca.state = ctx->d_tgt_state;
-    ca.counter = tpCounter;
+    ca.normWgs = tpGridA;
     ca.hflags = ctx->d_hflags;
     ca.numFiles = nfMarks;
-    ca.report = rep;
+    ca.report = repl;
     ca.seq = seq;
     // Where the spectral kernel screens and the layout stays, the launch that transforms the target needs nothing of
     // the report: it is queued now and carries the second pass along, so that the host's wait for the scalars, the
@@ -2071,20 +2059,46 @@ int sgz_corr_set_target(sgz_context *ctx, const float *frames, int num_frames, f
         SGZ_HIP(ctx, hipGetLastError());
     }
     {
+        // every workgroup of the second pass reports by itself (those of the fused launch are 256 threads as well: a
+        // workgroup per unit)
         const auto t0 = std::chrono::steady_clock::now();
+        auto allThere = [&]() {
+            for (size_t w = 0; w < tpUnits; w++)
+                if (__atomic_load_n(repl.flags + w, __ATOMIC_ACQUIRE) != seq) return false;
+            return true;
+        };
         bool arrived = false;
         for (unsigned long long spins = 0;; spins++) {
-            if (__atomic_load_n(&rep->seq, __ATOMIC_ACQUIRE) == seq) {
+            if (allThere()) {
                 arrived = true;
                 break;
             }
-            if ((spins & 0xffff) == 0xffff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) break;
+            if ((spins & 0xfff) == 0xfff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) break;
         }
         if (!arrived) {  // something is wrong on the device: the stream says what
             SGZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            if (__atomic_load_n(&rep->seq, __ATOMIC_ACQUIRE) != seq)
-                return ctx->fail(SGZ_E_HIP, "the target preparation kernel did not report");
+            if (!allThere()) return ctx->fail(SGZ_E_HIP, "the target preparation kernel did not report");
         }
+    }
+    // the units' sums in unit order
+    TargetReport repSums{};
+    TargetReport *rep = &repSums;
+    {
+        double fin[kTpSums] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        for (size_t u = 0; u < tpUnits; u++)
+            for (int j = 0; j < kTpSums; j++) fin[j] += repl.rows[u * kTpSums + j];
+        rep->sum1[0] = repl.sum1[0];
+        rep->sum1[1] = repl.sum1[1];
+        rep->sum2[0] = fin[0];
+        rep->sum2[1] = fin[1];
+        rep->csum[0] = fin[2];
+        rep->csum[1] = fin[3];
+        rep->fsum[0] = fin[4];
+        rep->fsum[1] = fin[5];
+        rep->fsq[0] = fin[6];
+        rep->fsq[1] = fin[7];
+        rep->fsq1 = fin[8];
+        rep->inRange = fin[9] == 0.0 ? 1ull : 0ull;
     }
     // MathUtil.stat: mean = sum / n, sd = sqrt(sum of squared deviations / n)
     const double nT = (double)L, nS = (double)L * (double)(numCh - 1);

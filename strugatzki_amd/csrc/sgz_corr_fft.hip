@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) void fft_target_sub_kernel(int L, int numCh, c
     const int numPairs = (numCh + 1) / 2;
     if ((int)blockIdx.x >= 4 * numPairs) {
         target_centre_body<256>((int)blockIdx.x - 4 * numPairs, (int)gridDim.x - 4 * numPairs, ca.L, ca.numCh, ca.Lpad,
-                                ca.tnorm, ca.aprime, ca.aprimeF, ca.state, ca.counter, ca.hflags, ca.numFiles, ca.report,
+                                ca.tnorm, ca.aprime, ca.aprimeF, ca.state, ca.normWgs, ca.hflags, ca.numFiles, ca.report,
                                 ca.seq);
         return;
     }
@@ -330,10 +330,7 @@ __global__ __launch_bounds__(256) void fft_target_sub_kernel(int L, int numCh, c
     const int pair = blockIdx.x >> 2, k2 = 4 * (blockIdx.x & 3) + wave;
     const int c0 = 2 * pair, c1 = c0 + 1;
     const bool two = c1 < numCh;
-    // (the means through the vector memory path -- an index the compiler cannot see through -- so that they travel with
-    // the loads below instead of ahead of them on the scalar path)
-    const double *stv = ca.state + threadIdx.y;
-    const double mean0 = c0 == 0 ? stv[2] : stv[3], mean1 = stv[3];
+    __shared__ double rows1[256], sum1[2];
     // the pair's centred values, once per workgroup (its four waves sum over the same ones): a frame's two channels
     // are neighbours in the normalised target; twelve frames per thread in flight at a time (a 30 s target: all of
     // them -- what the first pass of the preparation wrote has to come from memory, a round trip of microseconds)
@@ -341,6 +338,7 @@ __global__ __launch_bounds__(256) void fft_target_sub_kernel(int L, int numCh, c
     float2 *wb = dyn + wave * M, *cin = dyn + 4 * M, *w16 = cin + terms * M;
     constexpr int U = 12;
     const bool packed = (numCh & 1) == 0;  // a frame's two channels as one 8-byte load
+    double mean0 = 0.0, mean1 = 0.0;
     for (int n0 = threadIdx.x; n0 < terms * M; n0 += U * 256) {
         float2 x[U];
 #pragma unroll
@@ -352,6 +350,14 @@ __global__ __launch_bounds__(256) void fft_target_sub_kernel(int L, int numCh, c
                 if (packed) x[u] = *reinterpret_cast<const float2 *>(src);
                 else x[u] = make_float2(src[0], two ? src[1] : 0.0f);
             }
+        }
+        if (n0 == (int)threadIdx.x) {
+            // the means, from the first pass' partial sums (behind the loads above, so that both travel together;
+            // MathUtil.stat: mean = sum / n)
+            tp_first_pass_sums<256>(ca.state, ca.normWgs, rows1, sum1);
+            const double mT = sum1[0] / (double)L, mS = sum1[1] / ((double)L * (double)(numCh - 1));
+            mean0 = c0 == 0 ? mT : mS;
+            mean1 = mS;
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {

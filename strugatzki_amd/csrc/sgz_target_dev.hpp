@@ -4,9 +4,10 @@
 //
 // Every sum is taken in a fixed order that depends on nothing but the target's shape --
 // a thread adds its four elements in index order, the 64 lanes of a wave are folded by a butterfly, the four waves
-// of a unit of 1024 elements added in wave order, and the workgroup that finishes last adds the units' sums in
-// order -- so a target always gets the same statistics; they differ from MathUtil.stat's sequential sums
-// (impl/MathUtil.scala:29-62) by a few units of the last place of a double.
+// of a unit of 1024 elements added in wave order, and the units' sums in unit order (the first pass' by every
+// workgroup of the second pass for itself, the second pass' by the host) -- so a target always gets the same
+// statistics; they differ from MathUtil.stat's sequential sums (impl/MathUtil.scala:29-62) by a few units of the
+// last place of a double.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -18,7 +19,17 @@ namespace sgz {
 constexpr int kTpPer = 4;     // elements per thread
 constexpr int kTpSums = 10;   // doubles a workgroup of the centring pass hands on
 
-// What the centring pass reports to the host (pinned memory; `seq` is written last).
+// What the centring pass reports to the host, in pinned memory: every workgroup writes the partial sums of its units
+// (kTpSums doubles a unit), the first one also the first pass' sums, and then its own sequence word; the host waits
+// for all of them and adds the units' sums in order (sgz_corr_set_target) -- a last workgroup that adds them on the
+// device costs the launch a fence, an atomic and two more trips to memory.
+struct TargetReportLayout {
+    double *sum1;               // [2]
+    double *rows;               // [units][kTpSums]
+    unsigned long long *flags;  // [workgroups]
+};
+
+// The sums of a target as the host puts them together.
 struct TargetReport {
     double sum1[2];   // sums of the normalised values: loudness row, other rows
     double sum2[2];   // sums of the squared deviations from the group's mean
@@ -30,9 +41,10 @@ struct TargetReport {
     unsigned long long seq;
 };
 
-// Device-side state of the two passes: [0..1] the sums of the first pass, [2..3] the means, then the workgroups'
-// partial sums (kTpSums doubles each); a counter beside it counts the workgroups that are done (reset by the
-// last one).
+// Device-side state: four doubles that are not in use, then the partial sums of the first pass' workgroups (kTpSums
+// doubles a row, two of them used).  The first pass ends with them: whoever needs the means adds them up
+// (tp_first_pass_sums), which costs a few hundred cycles where a last workgroup that adds them for all costs the
+// launch a fence, an atomic and a trip to memory (measured: 5 of the kernel's 12 us).
 #if defined(__HIPCC__)
 template <int T, int K>
 __device__ __forceinline__ void tp_wg_sums(double (&v)[K], double *red /* (T / 64) * K doubles */, double *__restrict__ out)
@@ -52,35 +64,23 @@ __device__ __forceinline__ void tp_wg_sums(double (&v)[K], double *red /* (T / 6
     }
 }
 
-// Column j < K of the workgroups' sums, added in workgroup order; valid in thread j.  The rows are fetched by the
-// whole workgroup, T / kTpSums at a time (a thread per column reading them one after the other from memory would
-// wait for every one of them in turn).
-template <int T, int K>
-__device__ __forceinline__ double tp_final_sum(const double *__restrict__ state, double *rows /* (T / kTpSums) * kTpSums */,
-                                               int wgCount)
+// The first pass' sums (loudness row, other rows) from its workgroups' partial sums, added in workgroup order, for
+// every thread of the workgroup: fin2[0..1] (LDS).  rows: T doubles of LDS.
+template <int T>
+__device__ __forceinline__ void tp_first_pass_sums(const double *__restrict__ state, int normWgs, double *rows, double *fin2)
 {
-    constexpr int kRows = T / kTpSums;
     double s = 0.0;
-    for (int w0 = 0; w0 < wgCount; w0 += kRows) {
-        const int nrows = min(kRows, wgCount - w0);
-        if ((int)threadIdx.x < nrows * kTpSums) rows[threadIdx.x] = state[4 + (size_t)w0 * kTpSums + threadIdx.x];
+    for (int w0 = 0; w0 < normWgs; w0 += T / 2) {
+        const int nrows = min(T / 2, normWgs - w0);
+        if ((int)threadIdx.x < 2 * nrows)
+            rows[threadIdx.x] = state[4 + (size_t)(w0 + (threadIdx.x >> 1)) * kTpSums + (threadIdx.x & 1)];
         __syncthreads();
-        if ((int)threadIdx.x < K)
-            for (int r = 0; r < nrows; r++) s += rows[r * kTpSums + threadIdx.x];
+        if (threadIdx.x < 2)
+            for (int r = 0; r < nrows; r++) s += rows[2 * r + threadIdx.x];
         __syncthreads();
     }
-    return s;
-}
-
-// True in every thread of the one workgroup (of wgCount) that finishes last, whose reads then see all the others' sums.
-__device__ __forceinline__ bool tp_last_workgroup(unsigned int *counter, int wgCount, int *lastShared)
-{
-    __threadfence();
+    if (threadIdx.x < 2) fin2[threadIdx.x] = s;
     __syncthreads();
-    if (threadIdx.x == 0) *lastShared = atomicAdd(counter, 1u) == (unsigned int)(wgCount - 1);
-    __syncthreads();
-    if (*lastShared) __threadfence();
-    return *lastShared != 0;
 }
 
 // The second pass of MathUtil.stat and the centred copies, by workgroup `wg` of `wgCount` workgroups of T threads:
@@ -95,18 +95,16 @@ template <int T>
 __device__ __forceinline__ void target_centre_body(int wg, int wgCount, int L, int numCh, int Lpad,
                                                    const float *__restrict__ tnorm, double *__restrict__ aprime,
                                                    float *__restrict__ aprimeF, double *__restrict__ state,
-                                                   unsigned int *__restrict__ counter, int *__restrict__ hflags,
-                                                   int numFiles, TargetReport *report, unsigned long long seq)
+                                                   int normWgs, int *__restrict__ hflags, int numFiles,
+                                                   TargetReportLayout report, unsigned long long seq)
 {
     static_assert(T % kTpUnitThreads == 0, "whole units per workgroup");
     constexpr int kSub = T / kTpUnitThreads;  // units per workgroup
     __shared__ double red[(T / 64) * kTpSums];
-    __shared__ double rows[(T / kTpSums) * kTpSums];
-    __shared__ double fin[kTpSums];
-    __shared__ int lastFlag;
+    __shared__ double rows[T];
+    __shared__ double sum1[2];
     const unsigned int n = (unsigned int)Lpad * (unsigned int)numCh;
     const int units = (int)((n + kTpUnit - 1) / kTpUnit);
-    const double meanT = state[2], meanS = state[3];
     const int sub = threadIdx.x / kTpUnitThreads, lt = threadIdx.x % kTpUnitThreads;
     const int unit = wg * kSub + sub;
     const unsigned int q0 = (unsigned int)unit * kTpUnit + lt;
@@ -117,6 +115,9 @@ __device__ __forceinline__ void target_centre_body(int wg, int wgCount, int L, i
         const unsigned int c = q / (unsigned int)Lpad, i = q - c * (unsigned int)Lpad;
         x[k] = q < n && i < (unsigned int)L ? tnorm[i * (unsigned int)numCh + c] : 0.0f;
     }
+    // (behind the loads above, so that both travel together) MathUtil.stat: mean = sum / n
+    tp_first_pass_sums<T>(state, normWgs, rows, sum1);
+    const double meanT = sum1[0] / (double)L, meanS = sum1[1] / ((double)L * (double)(numCh - 1));
     // sum2 T/S, csum T/S, fsum T/S, fsq T/S, fsq1, count of values outside the half-precision range
     double acc[kTpSums] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -158,29 +159,15 @@ __device__ __forceinline__ void target_centre_body(int wg, int wgCount, int L, i
     if (lt < kTpSums && unit < units) {
         double s = 0.0;
         for (int w = 0; w < kTpUnitThreads / 64; w++) s += red[(sub * (kTpUnitThreads / 64) + w) * kTpSums + lt];
-        state[4 + (size_t)unit * kTpSums + lt] = s;
-    }
-    if (!tp_last_workgroup(counter, wgCount, &lastFlag)) return;
-    const double total = tp_final_sum<T, kTpSums>(state, rows, units);
-    if (threadIdx.x < kTpSums) fin[threadIdx.x] = total;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        *counter = 0u;
-        report->sum1[0] = state[0];
-        report->sum1[1] = state[1];
-        report->sum2[0] = fin[0];
-        report->sum2[1] = fin[1];
-        report->csum[0] = fin[2];
-        report->csum[1] = fin[3];
-        report->fsum[0] = fin[4];
-        report->fsum[1] = fin[5];
-        report->fsq[0] = fin[6];
-        report->fsq[1] = fin[7];
-        report->fsq1 = fin[8];
-        report->inRange = fin[9] == 0.0 ? 1ull : 0ull;
+        report.rows[(size_t)unit * kTpSums + lt] = s;
         __threadfence_system();
-        __hip_atomic_store(&report->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    if (wg == 0 && threadIdx.x < 2) {
+        report.sum1[threadIdx.x] = sum1[threadIdx.x];
+        __threadfence_system();
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(report.flags + wg, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 #endif
 
@@ -191,10 +178,10 @@ struct TargetCentreArgs {
     double *aprime;
     float *aprimeF;
     double *state;
-    unsigned int *counter;
+    int normWgs;     // workgroups of the first pass (rows of partial sums it left)
     int *hflags;
     int numFiles;
-    TargetReport *report;
+    TargetReportLayout report;
     unsigned long long seq;
 };
 
