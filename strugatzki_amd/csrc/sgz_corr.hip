@@ -1347,9 +1347,16 @@ __global__ __launch_bounds__(256) void rescore_final_kernel(const FileDesc *__re
                                                             const double *__restrict__ part, HostReport hr)
 {
     const long long n = listed_records(*count, capacity, truncatedOk);
+    // The workgroups that have records (the first one in any case) take part; a search's few dozen records are one
+    // workgroup's, which then reports without the fence, the counter and the wait that finding the last of several
+    // costs (about 3 us of a launch of 7).
+    const unsigned int busy = (unsigned int)max(1ll, min((long long)gridDim.x, (n + blockDim.x - 1) / blockDim.x));
+    if (blockIdx.x >= busy) return;
+    // (the headers the report starts with, asked for now: they were written before this launch)
+    unsigned long long head = 0ull;
+    if (hr.host && (int)threadIdx.x < hr.headWords) head = hr.dev[threadIdx.x];
     const double nT = (double)cp.L, nS = (double)cp.L * (double)(cp.numCh - 1);
-    for (long long ci = (long long)blockIdx.x * blockDim.x + threadIdx.x; ci < n;
-         ci += (long long)gridDim.x * blockDim.x) {
+    for (long long ci = (long long)blockIdx.x * blockDim.x + threadIdx.x; ci < n; ci += (long long)busy * blockDim.x) {
         double t[kRsSums] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         for (int k = 0; k < rg.slices; k++)
 #pragma unroll
@@ -1384,21 +1391,21 @@ __global__ __launch_bounds__(256) void rescore_final_kernel(const FileDesc *__re
     if (!hr.host) return;
     __shared__ int isLast;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence_system();  // one release for the workgroup's records (a fence per thread costs a cache
-                                 // write-back each)
-        isLast = atomicAdd(hr.done, 1u) == gridDim.x - 1;
+    if (busy > 1) {
+        if (threadIdx.x == 0) {
+            __threadfence_system();  // one release for the workgroup's records (a fence per thread costs a cache
+                                     // write-back each)
+            isLast = atomicAdd(hr.done, 1u) == busy - 1;
+        }
+        __syncthreads();
+        if (!isLast) return;
     }
-    __syncthreads();
-    if (!isLast) return;
     // the last workgroup adds the headers and then the sequence number the host polls for
-    if ((int)threadIdx.x < hr.headWords) {
-        hr.host[threadIdx.x] = hr.dev[threadIdx.x];
-        __threadfence_system();
-    }
+    if ((int)threadIdx.x < hr.headWords) hr.host[threadIdx.x] = head;
     __syncthreads();
     if (threadIdx.x == 0) {
-        *hr.done = 0u;
+        if (busy > 1) *hr.done = 0u;
+        __threadfence_system();  // records and headers before the sequence word
         __hip_atomic_store(hr.host + hr.maxWords, hr.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }

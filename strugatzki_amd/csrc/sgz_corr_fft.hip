@@ -338,6 +338,37 @@ __global__ __launch_bounds__(256) void fft_target_sub_kernel(int L, int numCh, c
     float2 *wb = dyn + wave * M, *cin = dyn + 4 * M, *w16 = cin + terms * M;
     constexpr int U = 12;
     const bool packed = (numCh & 1) == 0;  // a frame's two channels as one 8-byte load
+    // every table factor of the workgroup is asked for here, ahead of the first barrier: what is asked for behind a
+    // barrier waits for a trip to memory of its own (and right after a launch nothing is in the cache)
+    const float2 root = tab[(threadIdx.x & 15) * (kFftTab / 16)];
+    FftWaveFactors<M> wf;
+    fft_wave_factors<M>(wf, tab, lane);
+    // the factors W_N^(n1 k2) of the sixteen points n1 = lane + r B: the lane's own (r = 0) times powers of W_N^(B k2),
+    // which is the same for all lanes -- the powers 1, 2, 4, 8 from the table, the others by at most three
+    // multiplications (a gather per point would be sixteen loads of 64 cache lines each)
+    float2 wn[16];
+    {
+        const float2 base = tab[((lane & (B - 1)) * k2) * (kFftTab / N)];
+        float2 p[16];
+        p[1] = tab[((B * k2) & (N - 1)) * (kFftTab / N)];
+        p[2] = tab[((2 * B * k2) & (N - 1)) * (kFftTab / N)];
+        p[4] = tab[((4 * B * k2) & (N - 1)) * (kFftTab / N)];
+        p[8] = tab[((8 * B * k2) & (N - 1)) * (kFftTab / N)];
+        p[3] = c_mul(p[1], p[2]);
+        p[5] = c_mul(p[1], p[4]);
+        p[6] = c_mul(p[2], p[4]);
+        p[9] = c_mul(p[1], p[8]);
+        p[10] = c_mul(p[2], p[8]);
+        p[12] = c_mul(p[4], p[8]);
+        p[7] = c_mul(p[3], p[4]);
+        p[11] = c_mul(p[3], p[8]);
+        p[13] = c_mul(p[5], p[8]);
+        p[14] = c_mul(p[6], p[8]);
+        p[15] = c_mul(p[7], p[8]);
+        wn[0] = base;
+#pragma unroll
+        for (int r = 1; r < 16; r++) wn[r] = c_mul(base, p[r]);
+    }
     double mean0 = 0.0, mean1 = 0.0;
     for (int n0 = threadIdx.x; n0 < terms * M; n0 += U * 256) {
         float2 x[U];
@@ -367,14 +398,7 @@ __global__ __launch_bounds__(256) void fft_target_sub_kernel(int L, int numCh, c
                                : make_float2(0.0f, 0.0f);
         }
     }
-    if (threadIdx.x < 16) w16[threadIdx.x] = c_dir<-1>(tab[threadIdx.x * (kFftTab / 16)]);  // the sixteenth roots
-    FftWaveFactors<M> wf;
-    fft_wave_factors<M>(wf, tab, lane);
-    float2 wn[16];
-    if (lane < B) {
-#pragma unroll
-        for (int r = 0; r < 16; r++) wn[r] = tab[((lane + r * B) * k2) * (kFftTab / N)];
-    }
+    if (threadIdx.x < 16) w16[threadIdx.x] = c_dir<-1>(root);  // the sixteenth roots
     __syncthreads();
     float2 v[16];
 #pragma unroll

@@ -201,6 +201,10 @@ struct FftWaveFactors {
     float2 last[4][3]; // last pass: butterflies lane + 64 m, elements 1 .. M / 256 - 1
 };
 
+// (A lane's table entries lie far apart -- a gather of 64 cache lines per load of a wave --, so as few as possible are
+// read: the last pass' factors exp(2 pi i r (lane + 64 m) / M) are the one of m = 0 times a power of exp(2 pi i 64 r / M),
+// which is the same for all lanes; two multiplications at most, within the ten units of the last place the error
+// account grants a derived factor.)
 template <int M>
 __device__ __forceinline__ void fft_wave_factors(FftWaveFactors<M> &f, const float2 *__restrict__ tab, int lane)
 {
@@ -212,9 +216,13 @@ __device__ __forceinline__ void fft_wave_factors(FftWaveFactors<M> &f, const flo
     f.p2[3] = tab[8 * k * s2];
     constexpr int R = M / 256, stride = kFftTab / M;
 #pragma unroll
-    for (int m = 0; m < 4; m++)
-#pragma unroll
-        for (int r = 1; r < R; r++) f.last[m][r - 1] = tab[r * (lane + 64 * m) * stride];
+    for (int r = 1; r < R; r++) {
+        const float2 base = tab[r * lane * stride], step = tab[r * 64 * stride], step2 = tab[r * 128 * stride];
+        f.last[0][r - 1] = base;
+        f.last[1][r - 1] = c_mul(base, step);
+        f.last[2][r - 1] = c_mul(base, step2);
+        f.last[3][r - 1] = c_mul(f.last[1][r - 1], step2);
+    }
 }
 
 template <int M, int DIR>
