@@ -301,7 +301,7 @@ __global__ __launch_bounds__(N / 16) void fft_target_kernel(const float *__restr
 }
 
 // The target's spectra for a target that has just been normalised (the launch behind the first pass of the target
-// preparation): what fft_target_kernel<., ., true> does, cut into many small workgroups and a short second launch,
+// preparation): what fft_target_kernel does, cut into many small workgroups and a short second launch,
 // because a query waits for it.  The N-point transform of a channel pair is decimated in frequency by 16: with
 // n = n1 + M n2, M = N / 16, and k = 16 k1 + k2,
 //     Z[16 k1 + k2] = sum_n1 W_M^(n1 k1) { W_N^(n1 k2) sum_n2 z[n1 + M n2] W_16^(n2 k2) },

@@ -183,9 +183,8 @@ struct sgz_context {
     size_t tnorm_cap = 0;
     double aMeanT = 0.0, aMeanS = 0.0;
     unsigned long long tgt_seq = 0;          // sequence number of the latest report of the target preparation
-    double *d_tgt_state = nullptr;           // its device-side sums (see target_norm_kernel); the last element holds
-    size_t tgt_state_cap = 0;                // the counter of finished workgroups
-    size_t tgt_counter_off = 0;
+    double *d_tgt_state = nullptr;           // the partial sums its first pass leaves on the device (target_norm_kernel)
+    size_t tgt_state_cap = 0;
     unsigned long long tgt_serial = 0;       // targets set so far
     float *d_aprime_f = nullptr;  // the same, rounded to fp32 (screening path)
     size_t aprime_f_cap = 0;
