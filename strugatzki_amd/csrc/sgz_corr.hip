@@ -1969,8 +1969,10 @@ int sgz_set_norms(sgz_context *ctx, const float *norms)
     return SGZ_OK;
 }
 
-int sgz_corr_set_target(sgz_context *ctx, const float *frames, int num_frames, float temporal_weight,
-                        float max_boost)
+// frames_on_device: the raw frames are in memory of the context's GPU already (what a query's feature extraction
+// leaves there); the first kernel then reads them where they are.
+static int set_target_impl(sgz_context *ctx, const float *frames, int num_frames, float temporal_weight, float max_boost,
+                           bool frames_on_device)
 {
     if (!ctx) return SGZ_E_ARG;
     if (ctx->numCh == 0) return ctx->fail(SGZ_E_STATE, "sgz_db_reset has not been called");
@@ -2008,7 +2010,7 @@ int sgz_corr_set_target(sgz_context *ctx, const float *frames, int num_frames, f
         SGZ_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_tgt_stage), stageBytes, hipHostMallocDefault));
         ctx->tgt_stage_cap = stageBytes;
     }
-    std::memcpy(ctx->h_tgt_stage + offRaw, frames, sizeof(float) * nTb);
+    if (!frames_on_device) std::memcpy(ctx->h_tgt_stage + offRaw, frames, sizeof(float) * nTb);
     TargetReportLayout repl;
     repl.sum1 = reinterpret_cast<double *>(ctx->h_tgt_stage + offRep);
     repl.rows = repl.sum1 + 2;
@@ -2027,7 +2029,8 @@ int sgz_corr_set_target(sgz_context *ctx, const float *frames, int num_frames, f
     // the marks of the previous target's screening runs go with it (a layout that is rebuilt clears all marks itself)
     const int nfMarks = ctx->d_hflags && ctx->hflags_cap >= ctx->files.size() && !ctx->layout_dirty ? (int)ctx->files.size() : 0;
     hipLaunchKernelGGL(target_norm_kernel, dim3(tpGridA), dim3(kTpThreads), 0, ctx->stream,
-                       reinterpret_cast<const float *>(ctx->h_tgt_stage + offRaw), L, numCh, ctx->d_normtab,
+                       frames_on_device ? frames : reinterpret_cast<const float *>(ctx->h_tgt_stage + offRaw), L, numCh,
+                       ctx->d_normtab,
                        ctx->norm.enabled, ctx->d_tnorm, ctx->d_tgt_state);
     SGZ_HIP(ctx, hipGetLastError());
     CorrParams &cp = ctx->cp;
@@ -2149,6 +2152,18 @@ int sgz_corr_set_target(sgz_context *ctx, const float *frames, int num_frames, f
     if (oldL != L || hadHalf != (ctx->hg.S2 > 0)) ctx->layout_dirty = true;
     if (early && !ctx->layout_dirty) fft_target_ready(ctx);
     return SGZ_OK;
+}
+
+int sgz_corr_set_target(sgz_context *ctx, const float *frames, int num_frames, float temporal_weight,
+                        float max_boost)
+{
+    return set_target_impl(ctx, frames, num_frames, temporal_weight, max_boost, false);
+}
+
+int sgz_corr_set_target_device(sgz_context *ctx, const float *device_frames, int num_frames, float temporal_weight,
+                               float max_boost)
+{
+    return set_target_impl(ctx, device_frames, num_frames, temporal_weight, max_boost, true);
 }
 
 int sgz_corr_target_stats(const sgz_context *ctx, double *stats_out)

@@ -152,6 +152,13 @@ class Context:
         self._check(lib.sgz_corr_set_target(self._h, N.ptr(a), a.shape[0], temporal_weight, max_boost))
         self.target_frames = a.shape[0]
 
+    def corr_set_target_device(self, device_ptr: int, num_frames: int, temporal_weight: float, max_boost: float) -> None:
+        """corr_set_target for raw frames [num_frames][channels] (fp32) that are in the GPU's memory already
+        (sgz_corr_set_target_device): `device_ptr` is their address there."""
+        self._check(lib.sgz_corr_set_target_device(self._h, C.c_void_p(device_ptr), num_frames, temporal_weight,
+                                                   max_boost))
+        self.target_frames = num_frames
+
     def corr_target_stats(self) -> np.ndarray:
         """(mean, std-dev) of the loudness row, (mean, std-dev) of the other rows, ln(average loudness) of the target."""
         out = np.zeros(5, dtype=np.float64)

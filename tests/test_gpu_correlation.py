@@ -7,7 +7,7 @@ against the Scala reference (see oracle/strugatzki_oracle.c).
 import numpy as np
 import pytest
 
-from common import (NUM_CH, SEED, STEP, O, corr_config, make_plants, native_plants, norms_default, synth_db,
+from common import (NUM_CH, SEED, STEP, HipMem, O, corr_config, make_plants, native_plants, norms_default, synth_db,
                     synth_target)
 
 pytestmark = pytest.mark.gpu
@@ -91,6 +91,35 @@ def test_target_statistics_from_the_device(ctx, L, num_ch, normalize):
     # the same target again gives the same bits (fixed summation order)
     ctx.corr_set_target(tgt, 0.5, 8.0)
     assert np.array_equal(ctx.corr_target_stats(), got)
+
+
+def test_target_from_device_memory_is_the_target_from_host_memory(ctx):
+    """sgz_corr_set_target_device: raw frames that are on the GPU already (a query's extraction leaves them there) give
+    the statistics and the search of the same frames handed over in host memory, bit for bit."""
+    import strugatzki_amd as S
+    L, ts, nf, frames = 300, 9, 4, 2000
+    db = synth_db(nf, frames, make_plants(2, L, nf, frames, ts))
+    tgt = np.ascontiguousarray(synth_target(ts, L)[ts:ts + L])
+    ctx.db_reset(NUM_CH)
+    for f in db:
+        ctx.db_add_file(f)
+    ctx.set_norms(norms_default())
+    ctx.corr_set_target(tgt, 0.5, 8.0)
+    want_stats = ctx.corr_target_stats()
+    want = S.search(ctx, S.SearchParams(3, 1, 0, STEP))
+    other = np.ascontiguousarray(synth_target(ts + 40, L)[ts + 40:ts + 40 + L])
+    ctx.corr_set_target(other, 0.5, 8.0)  # (something else in between)
+    hip = HipMem()
+    try:
+        dev = hip.alloc(tgt.nbytes)
+        hip.upload(dev, tgt)
+        ctx.corr_set_target_device(dev, L, 0.5, 8.0)
+        assert np.array_equal(ctx.corr_target_stats(), want_stats)
+        got = S.search(ctx, S.SearchParams(3, 1, 0, STEP))
+    finally:
+        ctx.synchronize()
+        hip.free_all()
+    assert [(g.sim, g.file, g.start, g.stop) for g in got] == [(w.sim, w.file, w.start, w.stop) for w in want]
 
 
 @pytest.mark.parametrize("weight", [0.0, 1.0, 0.25])

@@ -4,50 +4,9 @@ the second with a smaller input; sizes beyond the array are refused."""
 import numpy as np
 import pytest
 
-from common import NUM_CH, STEP, O, corr_config, make_plants, norms_default, synth_db, synth_target
+from common import NUM_CH, STEP, HipMem, O, corr_config, make_plants, norms_default, synth_db, synth_target
 
 pytestmark = pytest.mark.gpu
-
-
-class _Hip:
-    """Device memory for the test from the HIP runtime the library itself is linked to: the symbols are looked
-    up through the library's handle (a process that has also loaded torch holds a second copy of the runtime,
-    which knows nothing of the library's device state)."""
-
-    def __init__(self):
-        import ctypes as C
-        from strugatzki_amd import _native as N
-        self.C = C
-        self.lib = N.lib
-        self.lib.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
-        self.lib.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-        self.lib.hipFree.argtypes = [C.c_void_p]
-        self.lib.hipMemGetInfo.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
-        self.bufs = []
-
-    def free_bytes(self):
-        free, total = self.C.c_size_t(), self.C.c_size_t()
-        assert self.lib.hipMemGetInfo(self.C.byref(free), self.C.byref(total)) == 0
-        return free.value
-
-    def alloc(self, nbytes):
-        p = self.C.c_void_p()
-        assert self.lib.hipMalloc(self.C.byref(p), max(nbytes, 16)) == 0
-        self.bufs.append(p)
-        return p.value
-
-    def upload(self, dptr, arr):
-        arr = np.ascontiguousarray(arr)
-        assert self.lib.hipMemcpy(dptr, arr.ctypes.data, arr.nbytes, 1) == 0  # hipMemcpyHostToDevice
-
-    def download(self, dptr, arr):
-        assert self.lib.hipMemcpy(arr.ctypes.data, dptr, arr.nbytes, 2) == 0  # hipMemcpyDeviceToHost
-        return arr
-
-    def free_all(self):
-        for p in self.bufs:
-            self.lib.hipFree(p)
-        self.bufs = []
 
 
 def _device_list(hip, cap):
@@ -77,7 +36,7 @@ def test_rescore_noalloc_equals_rescore(ctx):
     import strugatzki_amd as S
     from strugatzki_amd import _native as N
 
-    hip = _Hip()
+    hip = HipMem()
     ts, norms = 9, norms_default()
     try:
         # first call: long target (several slices per window), many candidates; second: shorter target, fewer
