@@ -436,6 +436,24 @@ SGZ_API int sgz_corr_search(sgz_context *ctx, int target_frames, int num_matches
                             int64_t min_spacing, int step_size, int screen_mode, int over_bounds, int64_t capacity,
                             float margin, sgz_match *matches_out, int out_capacity, int *count_out);
 
+/* Several queries in flight at once on one GPU: num_queries times sgz_corr_set_target (targets_on_device = 0:
+ * targets[q] in host memory) or sgz_corr_set_target_device (1: in the memory of the contexts' GPU) followed by
+ * sgz_corr_search with the arguments given -- each query one FeatureCorrelation run (impl/FeatureCorrelationImpl.scala
+ * :83-98 the target, :152-246 and :399-411 the search) -- dealt over num_ctx contexts that are replicas of one
+ * another: the caller has given every one the same files, in the same order, and the same norms.  A host thread per
+ * context takes the next query as soon as its context is free, so the short kernels and host waits of one query
+ * run beside the chip-filling kernel of another (a query alone leaves the GPU idle for about half of its
+ * duration).  All targets have target_frames frames.  Query q's matches go to matches_out[q * out_capacity ...],
+ * their count to counts_out[q]; every result is what sgz_corr_search on a single context returns.  The first failure
+ * ends the batch and is returned (sgz_last_error of the contexts says more); results of the queries completed
+ * until then stay valid.  The reference runs one search at a time; its counterpart is a caller that starts
+ * several FeatureCorrelation processors concurrently. */
+SGZ_API int sgz_corr_search_batch(sgz_context *const *ctxs, int num_ctx, const float *const *targets,
+                                  int targets_on_device, int num_queries, int target_frames, float temporal_weight,
+                                  float max_boost, int num_matches, int num_per_file, int64_t min_spacing,
+                                  int step_size, int screen_mode, int over_bounds, int64_t capacity, float margin,
+                                  sgz_match *matches_out, int out_capacity, int *counts_out);
+
 /* sgz_corr_search over a database that is spread over several contexts, one per GPU of the node (the loop over
  * all files of impl/FeatureCorrelationImpl.scala:152-246, cut by file; one host thread drives each context).
  * Every context holds its own files, has the same norms and the same target set; global_ids[c][i] = position of

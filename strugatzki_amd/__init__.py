@@ -6,4 +6,4 @@ and fails if it is absent; there is no CPU implementation in here.
 """
 from ._native import LIB_PATH, NativeError  # noqa: F401
 from .engine import Context, Selector, ring_runs, search_multi, segm_select  # noqa: F401
-from .search import SearchParams, search, search_punch, search_sharded  # noqa: F401
+from .search import SearchParams, search, search_batch, search_punch, search_sharded  # noqa: F401

@@ -88,6 +88,9 @@ SIGNATURES = {
     "sgz_norm_zero_frame": (C.c_int, [_vp, _vp]),
     "sgz_corr_search_multi": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int,
                                         C.c_int64, _vp, C.c_int, _vp]),
+    "sgz_corr_search_batch": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int,
+                                        C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_float, _vp,
+                                        C.c_int, _vp]),
     "sgz_set_norms": (C.c_int, [_vp, _vp]),
     "sgz_corr_set_target": (C.c_int, [_vp, _vp, C.c_int, C.c_float, C.c_float]),
     "sgz_corr_set_target_device": (C.c_int, [_vp, _vp, C.c_int, C.c_float, C.c_float]),

@@ -2,7 +2,9 @@
 // replay of the reference's match bookkeeping in file order (impl/FeatureCorrelationImpl.scala:113-150, 234,
 // 399-411) -- as one call through the fine-grained entry points of strugatzki_amd.h.
 #include <algorithm>
+#include <atomic>
 #include <cstdint>
+#include <thread>
 #include <vector>
 
 #include "strugatzki_amd.h"
@@ -138,4 +140,53 @@ extern "C" int sgz_corr_search(sgz_context *ctx, int target_frames, int num_matc
     }
     *count_out = sgz_sel_result(sel, matches_out, std::min(out_capacity, num_matches));
     return *count_out < 0 ? *count_out : SGZ_OK;
+}
+
+// sgz_corr_search_batch: queries in flight at once on one GPU.  One query is a chain of dependent launches -- the
+// target's preparation and spectra, the screening kernel, three short kernels that filter and re-score a handful
+// of candidates -- of which only the screening kernel fills the chip; the host waits twice per query.  With
+// several queries in flight, each on a context (stream, target state, result buffers) of its own, the short
+// kernels and the host's waits of one query run beside the screening kernel of another.  The contexts are
+// replicas: every one holds the same files and norms.  A thread per context takes queries off a shared counter.
+extern "C" int sgz_corr_search_batch(sgz_context *const *ctxs, int num_ctx, const float *const *targets,
+                                     int targets_on_device, int num_queries, int target_frames, float temporal_weight,
+                                     float max_boost, int num_matches, int num_per_file, int64_t min_spacing,
+                                     int step_size, int screen_mode, int over_bounds, int64_t capacity, float margin,
+                                     sgz_match *matches_out, int out_capacity, int *counts_out)
+{
+    if (!ctxs || num_ctx < 1 || num_queries < 0 || (num_queries > 0 && (!targets || !counts_out))) return SGZ_E_ARG;
+    if (out_capacity < 0 || (out_capacity > 0 && !matches_out)) return SGZ_E_ARG;
+    for (int c = 0; c < num_ctx; c++)
+        if (!ctxs[c]) return SGZ_E_ARG;
+    for (int q = 0; q < num_queries; q++) {
+        if (!targets[q]) return SGZ_E_ARG;
+        counts_out[q] = 0;
+    }
+    std::atomic<int> next{0}, failed{SGZ_OK};
+    auto lane = [&](int c) {
+        sgz_context *ctx = ctxs[c];
+        for (;;) {
+            const int q = next.fetch_add(1, std::memory_order_relaxed);
+            if (q >= num_queries || failed.load(std::memory_order_relaxed) != SGZ_OK) return;
+            int rc = targets_on_device
+                         ? sgz_corr_set_target_device(ctx, targets[q], target_frames, temporal_weight, max_boost)
+                         : sgz_corr_set_target(ctx, targets[q], target_frames, temporal_weight, max_boost);
+            if (rc == SGZ_OK)
+                rc = sgz_corr_search(ctx, target_frames, num_matches, num_per_file, min_spacing, step_size, screen_mode,
+                                     over_bounds, capacity, margin,
+                                     out_capacity > 0 ? matches_out + (size_t)q * (size_t)out_capacity : nullptr,
+                                     out_capacity, counts_out + q);
+            if (rc != SGZ_OK) {
+                int none = SGZ_OK;
+                failed.compare_exchange_strong(none, rc);  // (the first failure is the one reported)
+                return;
+            }
+        }
+    };
+    const int lanes = std::min(num_ctx, std::max(num_queries, 1));
+    std::vector<std::thread> others;
+    for (int c = 1; c < lanes; c++) others.emplace_back(lane, c);
+    lane(0);
+    for (auto &t : others) t.join();
+    return failed.load();
 }

@@ -24,6 +24,7 @@ list as a single-GPU run.
 from __future__ import annotations
 
 from dataclasses import dataclass
+import ctypes as C
 from typing import Sequence
 
 import numpy as np
@@ -88,6 +89,46 @@ def search(ctx: Context, p: SearchParams) -> list[N.Match]:
     return ctx.corr_search(p.num_matches, p.num_per_file, p.min_spacing, p.step_size, mode,
                            over_bounds=p.screen and p.screen_head, capacity=p.capacity,
                            margin=-1.0 if p.margin is None else p.margin)
+
+
+def search_batch(contexts: Sequence[Context], p: SearchParams, targets, temporal_weight: float, max_boost: float,
+                 target_frames: int | None = None) -> list[list[N.Match]]:
+    """Several queries in flight on one GPU (sgz_corr_search_batch): `contexts` are replicas (the same files in
+    the same order, the same norms), `targets` either arrays [frames][channels] in host memory or addresses (int)
+    of such frames in the GPU's memory (then `target_frames` says how many).  A query is corr_set_target + search();
+    the result of query q is what search() on one context returns for targets[q]."""
+    if p.screen_mode not in _SCREEN_CODES:
+        raise ValueError(f"unknown screen_mode {p.screen_mode!r}")
+    mode = _SCREEN_CODES[p.screen_mode] if p.screen else N.SGZ_SCREEN_NONE
+    nq = len(targets)
+    if nq == 0:
+        return []
+    on_device = isinstance(targets[0], int)
+    if on_device:
+        if target_frames is None:
+            raise ValueError("target_frames is needed with targets in GPU memory")
+        ptrs = (C.c_void_p * nq)(*targets)
+        keep = None
+    else:
+        keep = [np.ascontiguousarray(t, dtype=np.float32) for t in targets]
+        target_frames = keep[0].shape[0]
+        if any(k.shape != keep[0].shape for k in keep):
+            raise ValueError("the targets of a batch have the same length")
+        ptrs = (C.c_void_p * nq)(*[k.ctypes.data for k in keep])
+    n = len(contexts)
+    handles = (C.c_void_p * n)(*[c._h for c in contexts])
+    cap = max(p.num_matches, 1)
+    out = (N.Match * (cap * nq))()
+    counts = (C.c_int * nq)()
+    rc = N.lib.sgz_corr_search_batch(handles, n, ptrs, 1 if on_device else 0, nq, target_frames, temporal_weight,
+                                     max_boost, p.num_matches, p.num_per_file, p.min_spacing, p.step_size, mode,
+                                     1 if (p.screen and p.screen_head) else 0, p.capacity,
+                                     -1.0 if p.margin is None else p.margin, out, cap, counts)
+    for c in contexts:
+        c.target_frames = target_frames
+    if rc != N.SGZ_OK:
+        raise N.NativeError(rc, "; ".join(N.lib.sgz_last_error(c._h).decode() for c in contexts))
+    return [[out[q * cap + i] for i in range(counts[q])] for q in range(nq)]
 
 
 def search_punch(ctx: Context, p: SearchParams, target_in: np.ndarray, weight_in: float, target_out: np.ndarray,
