@@ -174,6 +174,9 @@ def main() -> int:
     ap.add_argument("--file-seconds", type=float, default=300.0)
     ap.add_argument("--target-seconds", type=float, default=None,
                     help="target length (default: 30 at N=1, 60 at N>1)")
+    ap.add_argument("--in-flight", type=int, default=4,
+                    help="contexts of the leg with several queries in flight (N = 1; 0 or 1: no such leg)")
+    ap.add_argument("--in-flight-steps", type=int, default=12000, help="queries of that leg")
     ap.add_argument("--targets", type=int, default=8,
                     help="distinct targets of the same length the timed steps rotate through (each step sets the next "
                          "one: a search includes the preparation of its target); 1: the target is set once, before "
@@ -445,6 +448,46 @@ def main() -> int:
             h_elapsed = float(t.item())
         host_leg = (h_elapsed / args.same_target_steps, h_kms)
 
+    # Several queries in flight (sgz_corr_search_batch): the headline step dealt over replica contexts, a host thread
+    # each.  A query alone is a chain of dependent launches that leaves the chip idle for about half of its
+    # duration; the kernels of several queries fill each other's gaps.  Reported next to the headline, not as it:
+    # `value` stays the rate of queries answered one after another.
+    in_flight = None
+    if not sharded and world == 1 and args.in_flight > 1 and args.in_flight_steps > 0 and mode == "f16" \
+            and targets_dev is not None:
+        replicas = [ctx]
+        for _ in range(args.in_flight - 1):
+            r = S.Context(local_rank)
+            r.db_reset(NUM_CH)
+            for g in head_global + tail_global:
+                r.db_add_synthetic(SEED, g, frames_per_file, by_file.get(g, []))
+            r.set_norms(norms_default())
+            r.set_screen_kernel(args.screen_kernel)
+            replicas.append(r)
+        ctx.set_kernel_timing(0)
+        nq = args.in_flight_steps
+        ptrs = [targets_dev[q % n_tgt].data_ptr() for q in range(nq)]
+        S.search_batch(replicas, params, ptrs[:min(nq, 2000)], 0.5, 8.0, target_frames=L)  # layouts built, clocks held
+        sync()
+        tb = time.perf_counter()
+        res = S.search_batch(replicas, params, ptrs, 0.5, 8.0, target_frames=L)
+        b_elapsed = time.perf_counter() - tb
+        ok = sum(1 for q in range(nq) if keys(res[q]) == [(p["file"], p["offset"]) for p in plants_of[q % n_tgt]])
+        in_flight = {
+            "what": "the headline step (a new target per search) with several queries in flight: replica contexts "
+                    "(each with its own copy of the database, stream and target state), a host thread per context, "
+                    "one sgz_corr_search_batch call over all queries",
+            "contexts": args.in_flight,
+            "queries": nq,
+            "ms_per_query": b_elapsed / nq * 1e3,
+            "windows_per_s": unique_windows / (b_elapsed / nq),
+            "queries_verified": ok,
+            "verified": ok == nq,
+        }
+        for r in replicas[1:]:
+            r.close()
+        ctx.corr_set_target(targets[0], 0.5, 8.0)
+
     # The collective alone (sharded runs): the all-gather of the candidate blocks, their copy to pinned memory and
     # the event behind it, as the search queues them, without the kernels in front.
     collective_ms = None
@@ -707,6 +750,8 @@ def main() -> int:
                                        "max": max(rank_elapsed) / args.steps * 1e3}
             out["collective_ms_per_step"] = collective_ms
             out["collective_share_of_step"] = collective_ms / ms_per_step if collective_ms is not None else None
+        if in_flight is not None:
+            out["queries_in_flight"] = in_flight
         if exact is not None:
             out["roofline"]["exact"] = exact
         if world == 1 and args.cpu_seconds > 0:
