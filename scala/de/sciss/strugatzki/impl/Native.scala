@@ -37,10 +37,34 @@ private[strugatzki] object Native {
     * extent.  `xBegin == xEnd`: the extent alone (`sims` may be null).  sgz_run_selfsimilarity_rows_xml. */
   @native def selfSimilarityRows(ctx: Long, configXML: String, xBegin: Int, xEnd: Int, sims: java.nio.FloatBuffer): Int
 
-  /** Runs `fun` with one context per configured GPU and releases them afterwards. */
+  /** Contexts live as long as the JVM: a context keeps the database of its last search resident (the library skips
+    * reading and uploading feature files it already holds, `sgz_db_tag`), and several processors that run at the
+    * same time -- each on a context set of its own -- overlap on the GPU, where a search alone leaves the chip idle
+    * for about half of its duration.  `-Dstrugatzki.contextSets=n` (default 4) sets of one context per requested
+    * GPU exist per device list; a processor waits for a free one. */
+  private val setsPerKey: Int = sys.props.get("strugatzki.contextSets").fold(4)(_.toInt max 1)
+  private val pools = new java.util.concurrent.ConcurrentHashMap[Seq[Int], java.util.concurrent.LinkedBlockingDeque[Array[Long]]]()
+  private val made  = new java.util.concurrent.ConcurrentHashMap[Seq[Int], java.util.concurrent.atomic.AtomicInteger]()
+
+  sys.addShutdownHook {
+    val it = pools.values.iterator()
+    while (it.hasNext) { val q = it.next(); var c = q.poll(); while (c != null) { c.foreach(destroy); c = q.poll() } }
+  }
+
+  /** Runs `fun` with one context per GPU of `devs`: a set that is free now (the one used last first: its database
+    * is the likeliest to be the one asked for again), a new one while fewer than `contextSets` exist, else the next
+    * to be returned. */
   def withContexts[A](devs: Array[Int])(fun: Array[Long] => A): A = {
-    val ctx = devs.map(create)
-    try fun(ctx) finally ctx.foreach(destroy)
+    val key: Seq[Int] = devs.toList
+    pools.putIfAbsent(key, new java.util.concurrent.LinkedBlockingDeque[Array[Long]]())
+    made .putIfAbsent(key, new java.util.concurrent.atomic.AtomicInteger(0))
+    val free = pools.get(key)
+    var ctx  = free.pollFirst()
+    if (ctx == null) {
+      if (made.get(key).incrementAndGet() <= setsPerKey) ctx = devs.map(create)
+      else { made.get(key).decrementAndGet(); ctx = free.takeFirst() }
+    }
+    try fun(ctx) finally free.addFirst(ctx)
   }
 
   /** Progress and abort of a `ProcessorImpl` as the callback of a native run; a run that the callback aborted
