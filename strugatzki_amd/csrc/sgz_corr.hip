@@ -158,12 +158,9 @@ __global__ __launch_bounds__(256) void prep_kernel(const FileDesc *__restrict__ 
                     for (int j = 0; j < 4; j++) {
                         float val = xv[j];
                         if (nrm.enabled && e0 + j < validElems) {
-                            // the half-precision image and its bounds do not need the reference's exact fp32
-                            // quotient (re-scoring recomputes it): reciprocal multiply there
-                            if constexpr (std::is_same<T, _Float16>::value)
-                                val = (val - nrm.mn[c]) * __builtin_amdgcn_rcpf(nrm.d[c]);
-                            else
-                                val = (val - nrm.mn[c]) / nrm.d[c];
+                            // (the reference's fp32 quotient, impl/MathUtil.scala:132-152, for every element type: one
+                            // arithmetic for the normalised value wherever it is formed)
+                            val = (val - nrm.mn[c]) / nrm.d[c];
                         }
                         xs[c * cstride + (fr & (kR - 1)) * jstride + (fr >> 4)] = val;
                         if (++c == numCh) {
@@ -405,20 +402,20 @@ __global__ __launch_bounds__(256) void prep_half_kernel(const FileDesc *__restri
     const float kTf = fd.cT, kSf = fd.cS;  // the file's own mean levels (file_const_kernel)
     float peak = 0.0f;
     float mom[2][4];
-    // the half-precision image and its bounds do not need the reference's exact fp32 quotient (re-scoring
-    // recomputes it): reciprocal multiply; (x - 0) * 1 leaves x as it is where normalisation is off
-    float mn[NCH], rc[NCH];
+    // the reference's fp32 quotient (impl/MathUtil.scala:132-152), as the exact path and the spectra form it: this
+    // kernel runs once per layout; (x - 0) / 1 leaves x as it is where normalisation is off
+    float mn[NCH], dv[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
         mn[c] = nrm.enabled ? nrm.mn[c] : 0.0f;
-        rc[c] = nrm.enabled ? __builtin_amdgcn_rcpf(nrm.d[c]) : 1.0f;
+        dv[c] = nrm.enabled ? nrm.d[c] : 1.0f;
     }
 #pragma unroll
     for (int k = 0; k < 2; k++) {
         float f1 = 0.0f, f2 = 0.0f;
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
-            float val = (v[k * NCH + c] - mn[c]) * rc[c];
+            float val = (v[k * NCH + c] - mn[c]) / dv[c];
             val = ok[k] ? val - (c == 0 ? kTf : kSf) : 0.0f;  // frames past the end are 0
             peak = fmaxf(peak, fabsf(val));                   // NaN stays NaN, as in the exact path
             if (c > 0) {

@@ -167,8 +167,8 @@ __global__ __launch_bounds__(N / 16) void fft_spectra_kernel(const FileDesc *__r
     const int c0 = 2 * p, c1 = 2 * p + 1;
     const bool two = c1 < numCh;
     const float mn0 = nrm.enabled ? nrm.mn[c0] : 0.0f, mn1 = nrm.enabled && two ? nrm.mn[c1] : 0.0f;
-    const float rc0 = nrm.enabled ? __builtin_amdgcn_rcpf(nrm.d[c0]) : 1.0f;
-    const float rc1 = nrm.enabled && two ? __builtin_amdgcn_rcpf(nrm.d[c1]) : 1.0f;
+    // (the reference's fp32 quotient, impl/MathUtil.scala:132-152, as the exact path and the window records form it)
+    const float d0 = nrm.enabled ? nrm.d[c0] : 1.0f, d1 = nrm.enabled && two ? nrm.d[c1] : 1.0f;
     const float k0 = c0 == 0 ? fd.cT : fd.cS, k1 = fd.cS;
     float sq0 = 0.0f, sq1 = 0.0f;
 #pragma unroll 4
@@ -178,8 +178,8 @@ __global__ __launch_bounds__(N / 16) void fft_spectra_kernel(const FileDesc *__r
         float a = 0.0f, b = 0.0f;
         if (fr < fd.frames) {
             const float *src = fd.raw + fr * numCh;
-            a = (src[c0] - mn0) * rc0 - k0;
-            if (two) b = (src[c1] - mn1) * rc1 - k1;
+            a = (src[c0] - mn0) / d0 - k0;
+            if (two) b = (src[c1] - mn1) / d1 - k1;
         }
         buf[fft_phys(n)] = make_float2(a, b);
         sq0 = fmaf(a, a, sq0);

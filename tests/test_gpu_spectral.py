@@ -247,7 +247,7 @@ def test_bounds_hold_on_awkward_data(spectral, case):
             db[f] = (np.float32(0.4) + r) * (norms[:, 1] - norms[:, 0]) + norms[:, 0]
         elif case == "far_level" and f >= 2:
             # normalised values near 300 with a spread of 0.05: the fp32 normalisation rounds at 3e-5, a thousandth
-            # of the spread, and differently in the kernel (multiplication by a reciprocal) than in the exact path
+            # of the spread, before the file's level is taken off
             r = (rng.standard_normal((frames, NUM_CH)) * 0.05).astype(np.float32)
             db[f] = (np.float32(300.0) + r) * (norms[:, 1] - norms[:, 0]) + norms[:, 0]
     tgt = synth_target(ts, L)
