@@ -402,7 +402,13 @@ __global__ __launch_bounds__(64 * kFastWaves) void extract1024_kernel(const floa
     //    it and has a falling weight of 0 here)
     float rise = 0.0f, fall = 0.0f;
     {
+        // SGZ_EX_PROBE (timing builds of tools/extract_phase_probe.sh only; results are wrong): 1 leaves out the walk
+        // over the bins, 2 the DCT's sums, 3 both
+#if defined(SGZ_EX_PROBE) && (SGZ_EX_PROBE & 1)
+        const int b0 = st.b0[lane], cnt = 0;
+#else
         const int b0 = st.b0[lane], cnt = st.cnt[lane];
+#endif
         const float *Pb = P + b0;
         const f2 *wb = wgt + b0;
 #pragma unroll 4
@@ -443,7 +449,11 @@ __global__ __launch_bounds__(64 * kFastWaves) void extract1024_kernel(const floa
         const int c = c0 + (lane & 15), q = lane >> 4;
         float part = 0.0f;
         if (c < p.numCoeffs) {
+#if defined(SGZ_EX_PROBE) && (SGZ_EX_PROBE & 2)
+            const int j0 = 11 * q, j1 = j0;
+#else
             const int j0 = 11 * q, j1 = min(j0 + 11, kBands);
+#endif
             for (int j = j0; j < j1; j++) part = fmaf(dctL[c * kBands + j], P[kFastM + 8 + j], part);
         }
         part += __shfl_xor(part, 16, 64);
