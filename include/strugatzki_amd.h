@@ -440,7 +440,8 @@ SGZ_API int sgz_corr_search(sgz_context *ctx, int target_frames, int num_matches
  * targets[q] in host memory) or sgz_corr_set_target_device (1: in the memory of the contexts' GPU) followed by
  * sgz_corr_search with the arguments given -- each query one FeatureCorrelation run (impl/FeatureCorrelationImpl.scala
  * :83-98 the target, :152-246 and :399-411 the search) -- dealt over num_ctx contexts that are replicas of one
- * another: the caller has given every one the same files, in the same order, and the same norms.  A host thread per
+ * another: the caller has given every one the same files, in the same order, and the same norms (the same context
+ * twice is refused: SGZ_E_ARG).  A host thread per
  * context takes the next query as soon as its context is free, so the short kernels and host waits of one query
  * run beside the chip-filling kernel of another (a query alone leaves the GPU idle for about half of its
  * duration).  All targets have target_frames frames.  Query q's matches go to matches_out[q * out_capacity ...],

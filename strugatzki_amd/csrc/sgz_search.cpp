@@ -156,8 +156,11 @@ extern "C" int sgz_corr_search_batch(sgz_context *const *ctxs, int num_ctx, cons
 {
     if (!ctxs || num_ctx < 1 || num_queries < 0 || (num_queries > 0 && (!targets || !counts_out))) return SGZ_E_ARG;
     if (out_capacity < 0 || (out_capacity > 0 && !matches_out)) return SGZ_E_ARG;
-    for (int c = 0; c < num_ctx; c++)
+    for (int c = 0; c < num_ctx; c++) {
         if (!ctxs[c]) return SGZ_E_ARG;
+        for (int d = 0; d < c; d++)
+            if (ctxs[d] == ctxs[c]) return SGZ_E_ARG;  // (a context serves one thread at a time)
+    }
     for (int q = 0; q < num_queries; q++) {
         if (!targets[q]) return SGZ_E_ARG;
         counts_out[q] = 0;

@@ -76,6 +76,18 @@ def test_batch_equals_single_queries_and_oracle(L, frames, lanes, on_device):
             c.close()
 
 
+def test_batch_refuses_the_same_context_twice():
+    import strugatzki_amd as S
+    c = S.Context(0)
+    try:
+        _load(c, synth_db(2, 600), norms_default())
+        t = synth_target(10, 64)[10:74]
+        with pytest.raises(S.NativeError):
+            S.search_batch([c, c], S.SearchParams(3, 1, 0, STEP), [t, t], 0.5, 8.0)
+    finally:
+        c.close()
+
+
 def test_batch_reports_a_failing_query():
     import strugatzki_amd as S
     db = synth_db(3, 600)
