@@ -748,13 +748,19 @@ __global__ __launch_bounds__(kSfThreads, 2) void selfsim_tile8_kernel(SelfSimArg
         const double SbR = stSR[yb], Ab = stA[yb], Bb = stB[yb], Db = stD[yb], fb = stF[yb];
         const float sqb = stSq[yb], rhob = stRho[yb], lamMb = stLamM[yb], lamLb = stLamL[yb], rb = stR7[yb];
         const bool both = g.doT && g.doS, lastGroup = group == (g.doS ? 1 : 0);
-#pragma unroll
+        // (the two matrix-core tiles of a thread one after the other in a loop, not side by side in the code: the
+        // accumulators and similarities of tile i are picked by selects.  With both tiles' 32 pixels unrolled the
+        // kernel was 57 KB of code and spilled 124 registers per thread; so: 37 KB, none, 14.5 -> 13.1 ms for the
+        // matrix of a 30-minute file.  Four pixels per pass of the loop: 13.4 ms.)
+#pragma unroll 1
         for (int i = 0; i < 2; i++)
 #pragma unroll
             for (int v = 0; v < 16; v++) {
                 const int pxl = 64 * wx + 32 * i + 8 * (v >> 2) + 4 * lhi + (v & 3), px = X0 + pxl;
                 // sum qa qb / 2^16 (every term an integer below 2^53: exact)
-                const double t = fma((double)acc[0][i][v], 65536.0, fma((double)acc[1][i][v], 256.0, (double)acc[2][i][v]));
+                const int e0 = i ? acc[0][1][v] : acc[0][0][v], e1 = i ? acc[1][1][v] : acc[1][0][v],
+                          e2 = i ? acc[2][1][v] : acc[2][0][v];
+                const double t = fma((double)e0, 65536.0, fma((double)e1, 256.0, (double)e2));
                 float bound;
                 float part = selfsim_pixel8(stS[pxl], stA[pxl], stB[pxl], stC[pxl], stU[pxl], stSq[pxl], stRho[pxl],
                                             stLamM[pxl], stLamL[pxl], stR7[pxl], SbR, Ab, Bb, Db, sqb, rhob, lamMb, lamLb,
@@ -769,8 +775,8 @@ __global__ __launch_bounds__(kSfThreads, 2) void selfsim_tile8_kernel(SelfSimArg
                 }
                 // sim = temporal * w + spectral * (1 - w), impl/SelfSimilarityImpl.scala:146
                 const float term = part * wThis;
-                const float sim = (group == 0 || !g.doT) ? term : simv[i][v] + term;
-                simv[i][v] = sim;
+                const float sim = (group == 0 || !g.doT) ? term : (i ? simv[1][v] : simv[0][v]) + term;
+                float keep = sim;  // (what simv[i][v] becomes)
                 // The gray level is integer work: it is certain when both ends of the similarity's error interval map
                 // to the same level (the colour map is monotonic); the other pixels are listed for
                 // selfsim_fix_kernel, which evaluates them as the reference does.  (Only where a raster is asked for.)
@@ -779,7 +785,7 @@ __global__ __launch_bounds__(kSfThreads, 2) void selfsim_tile8_kernel(SelfSimArg
                     float e = fmaf(bound, wThis, kSsMixErr + g.slack);
                     if (both) e += errLds[(16 * i + v) * kSfThreads + tid];
                     const int cLo = gray_color(sim - e, g.warp, g.scale, g.inv), cHi = gray_color(sim + e, g.warp, g.scale, g.inv);
-                    if (!g.wantSim) simv[i][v] = __int_as_float(cLo);
+                    if (!g.wantSim) keep = __int_as_float(cLo);
                     if (cLo != cHi && inside) {
                         const int mine = atomicAdd(&hitCount, 1);
                         if (mine < kSfHits) {
@@ -790,6 +796,8 @@ __global__ __launch_bounds__(kSfThreads, 2) void selfsim_tile8_kernel(SelfSimArg
                         }
                     }
                 }
+                simv[0][v] = i ? simv[0][v] : keep;
+                simv[1][v] = i ? keep : simv[1][v];
             }
     }
     if (g.fixList) {  // the tile's uncertain pixels: one place in the list for all of them
