@@ -246,7 +246,8 @@ __device__ __forceinline__ void fft8(f2 (&v)[8])
 }
 
 constexpr int kFastFft = 1024, kFastM = 512;
-constexpr int kFastWaves = 7;                   // frames per workgroup: 4 workgroups of 39 KB LDS per CU
+constexpr int kFastWaves = 4;                   // frames per workgroup: 6 workgroups of 25 KB LDS per CU (measured: 2: 0.223,
+                                                // 3: 0.21, 4: 0.191, 5: 0.213, 6: 0.199, 7: 0.204, 8: 0.199 ms per 20 min of audio)
 // A frame's exchange buffer: 8 points of padding per 64 (index i sits at i + 8 (i / 64)), and one more slot
 // that holds a second copy of Z[0] (see the unpack step).
 constexpr int kFastZ = kFastM + 8 * 8 + 8;
