@@ -898,11 +898,10 @@ int set_lds(sgz_context *ctx, K kern, size_t bytes)
 int ensure_tab(sgz_context *ctx)
 {
     if (ctx->d_fft_tab) return SGZ_OK;
-    std::vector<float2> tab(kFftTab);
-    const double step = 2.0 * 3.14159265358979323846 / kFftTab;
-    for (int j = 0; j < kFftTab; j++) tab[(size_t)j] = make_float2((float)std::cos(step * j), (float)std::sin(step * j));
-    SGZ_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_fft_tab), sizeof(float2) * kFftTab));
-    SGZ_HIP(ctx, hipMemcpy(ctx->d_fft_tab, tab.data(), sizeof(float2) * kFftTab, hipMemcpyHostToDevice));
+    std::vector<float2> tab(kFftTabAll);
+    fft_fill_table(tab.data());
+    SGZ_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_fft_tab), sizeof(float2) * kFftTabAll));
+    SGZ_HIP(ctx, hipMemcpy(ctx->d_fft_tab, tab.data(), sizeof(float2) * kFftTabAll, hipMemcpyHostToDevice));
     return SGZ_OK;
 }
 
@@ -1358,9 +1357,8 @@ int sgz_corr_screen_geometry(const sgz_context *ctx, int *n_out, int *hop_out, l
 int sgz_fft_reference_host(int n, int inverse, const float *in, float *out)
 {
     if (!in || !out || (n != 4096 && n != 8192 && n != 16384)) return SGZ_E_ARG;
-    std::vector<float2> tab(kFftTab);
-    const double step = 2.0 * 3.14159265358979323846 / kFftTab;
-    for (int j = 0; j < kFftTab; j++) tab[(size_t)j] = make_float2((float)std::cos(step * j), (float)std::sin(step * j));
+    std::vector<float2> tab(kFftTabAll);
+    fft_fill_table(tab.data());
     std::vector<float2> buf((size_t)fft_lds_elems(n));
     for (int i = 0; i < n; i++) buf[(size_t)fft_phys(i)] = make_float2(in[2 * i], in[2 * i + 1]);
     auto run = [&](auto N_, auto DIR_) {

@@ -23,12 +23,30 @@
 // Twiddle factors come from a table tab[j] = (cos, sin)(2 pi j / kFftTab) rounded from fp64; per butterfly the
 // powers 1, 2, 4, 8 are read and the other eleven formed by at most three multiplications (error <= 10 ulp).
 #pragma once
+#include <cmath>
 
 #include <hip/hip_runtime.h>
 
 namespace sgz {
 
 constexpr int kFftTab = 16384;  // entries of the twiddle table == the largest transform
+// Behind the table: for the radix-16 passes with strides 16 and 256, per k < stride the four entries a butterfly
+// reads -- tab[k s], tab[2 k s], tab[4 k s], tab[8 k s], s = kFftTab / (16 stride) -- side by side, so that a lane
+// fetches its four in one 32-byte piece and a wave's lanes in a few cache lines (taken one by one out of the table
+// they lie up to eight times as far apart as the lanes' k: 240 lines per wave and transform instead of 20).
+constexpr int kFftPack16 = kFftTab, kFftPack256 = kFftTab + 4 * 16, kFftTabAll = kFftTab + 4 * 16 + 4 * 256;
+// Fills the table: tab has kFftTabAll entries.
+inline void fft_fill_table(float2 *tab)
+{
+    const double step = 2.0 * 3.14159265358979323846 / kFftTab;
+    for (int j = 0; j < kFftTab; j++) tab[j] = make_float2((float)std::cos(step * j), (float)std::sin(step * j));
+    for (int Ns : {16, 256}) {
+        float2 *pk = tab + (Ns == 16 ? kFftPack16 : kFftPack256);
+        const int stride = kFftTab / (16 * Ns);
+        for (int k = 0; k < Ns; k++)
+            for (int p = 0; p < 4; p++) pk[4 * k + p] = tab[(k << p) * stride];
+    }
+}
 
 __host__ __device__ constexpr int fft_phys(int i) { return i ^ ((i >> 4) & 15); }
 __host__ __device__ constexpr int fft_lds_elems(int N) { return N; }
@@ -103,10 +121,22 @@ __host__ __device__ inline void fft16_math(float2 (&v)[16], int j, const float2 
         const int k = j & (Ns - 1);
         constexpr int stride = kFftTab / (16 * Ns);  // table steps per unit angle 2 pi / (16 Ns)
         float2 w[16];
-        w[1] = c_dir<DIR>(tab[k * stride]);
-        w[2] = c_dir<DIR>(tab[2 * k * stride]);
-        w[4] = c_dir<DIR>(tab[4 * k * stride]);
-        w[8] = c_dir<DIR>(tab[8 * k * stride]);
+        static_assert(Ns == 16 || Ns == 256, "packed factors exist for these strides");
+        const float2 *pk2 = tab + (Ns == 16 ? kFftPack16 : kFftPack256) + 4 * k;  // tab[k s], [2 k s], [4 k s], [8 k s]
+        (void)stride;
+#if defined(__HIP_DEVICE_COMPILE__)
+        const float4 *pk = reinterpret_cast<const float4 *>(pk2);  // (32-byte aligned on the device)
+        const float4 p01 = pk[0], p23 = pk[1];
+        w[1] = c_dir<DIR>(make_float2(p01.x, p01.y));
+        w[2] = c_dir<DIR>(make_float2(p01.z, p01.w));
+        w[4] = c_dir<DIR>(make_float2(p23.x, p23.y));
+        w[8] = c_dir<DIR>(make_float2(p23.z, p23.w));
+#else
+        w[1] = c_dir<DIR>(pk2[0]);
+        w[2] = c_dir<DIR>(pk2[1]);
+        w[4] = c_dir<DIR>(pk2[2]);
+        w[8] = c_dir<DIR>(pk2[3]);
+#endif
         w[3] = c_mul(w[1], w[2]);
         w[5] = c_mul(w[1], w[4]);
         w[6] = c_mul(w[2], w[4]);
