@@ -535,6 +535,48 @@ __global__ __launch_bounds__(256) void fft_blklnmin_kernel(const FftBlock *__res
     if (threadIdx.x == 0) blklnmin[blockIdx.x] = fminf(fminf(part[0], part[1]), fminf(part[2], part[3]));
 }
 
+// What a search's launch of the spectral kernel reads per window is cut to 8 bytes: the two 1 / sd of the window.  The
+// other four numbers of a window's record -- g (how far the rounding of the prefix sums can move the sd, relative) and
+// u (mean offset over sd, plus what the sums can move the mean by) of either channel group, which only widen the
+// error term -- are replaced by their largest values over the block's windows: every term they enter grows with them,
+// so a bound formed with the block's maxima encloses the one formed with the window's own.  A window whose g or u
+// is not finite or lies above kBlkGCap / kBlkUCap is left out of the maxima and gets 1 / sd = +inf, which makes its
+// bounds -inf .. +inf (a certain candidate: what its own large g did before), so that a stretch without spread does not
+// widen the bounds of the thousands of ordinary windows around it.  One workgroup of 256 threads per block.
+constexpr float kBlkGCap = 1.0e-4f, kBlkUCap = 32.0f;
+__global__ __launch_bounds__(256) void fft_blkgu_kernel(const FftBlock *__restrict__ blocks, float *wstat,
+                                                        long long totalWindows, float4 *__restrict__ blkgu,
+                                                        float2 *__restrict__ rec2)
+{
+    __shared__ float4 part[4];
+    const FftBlock bd = blocks[blockIdx.x];
+    const SpectralStatics st = spectral_statics(wstat, totalWindows);
+    float4 m = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // gT, uT, gS, uS
+    for (int k = threadIdx.x; k < bd.valid; k += 256) {
+        const float4 r = st.rec[bd.win + k];
+        const unsigned int guT = __float_as_uint(r.z), guS = __float_as_uint(r.w);
+        const float gT = half_from_bits(guT & 0xffffu), uT = half_from_bits(guT >> 16);
+        const float gS = half_from_bits(guS & 0xffffu), uS = half_from_bits(guS >> 16);
+        const bool ok = gT <= kBlkGCap && gS <= kBlkGCap && uT <= kBlkUCap && uS <= kBlkUCap;  // (false for NaN)
+        if (ok) m = make_float4(fmaxf(m.x, gT), fmaxf(m.y, uT), fmaxf(m.z, gS), fmaxf(m.w, uS));
+        rec2[bd.win + k] = ok ? make_float2(r.x, r.y) : make_float2(INFINITY, INFINITY);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        m.x = fmaxf(m.x, __shfl_xor(m.x, off, 64));
+        m.y = fmaxf(m.y, __shfl_xor(m.y, off, 64));
+        m.z = fmaxf(m.z, __shfl_xor(m.z, off, 64));
+        m.w = fmaxf(m.w, __shfl_xor(m.w, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 4; i++)
+            m = make_float4(fmaxf(m.x, part[i].x), fmaxf(m.y, part[i].y), fmaxf(m.z, part[i].z), fmaxf(m.w, part[i].w));
+        blkgu[blockIdx.x] = m;
+    }
+}
+
 // Boosts of a run of windows from their statics: what the spectral kernel leaves out of its output (see
 // sgz_context::boost_lazy).
 __global__ __launch_bounds__(256) void boost_fill_kernel(float *wstat, long long totalWindows, long long w0, long long n,
@@ -564,6 +606,8 @@ __global__ __launch_bounds__(N / 16, 4) void corr_fft_kernel(const FileDesc *__r
                                                           const float *__restrict__ ascale,
                                                           const float *__restrict__ tgtdq,
                                                           const float *__restrict__ blklnmin,
+                                                          const float4 *__restrict__ blkgu,
+                                                          const float2 *__restrict__ rec2,
                                                           float *__restrict__ wstat, long long totalWindows,
                                                           CorrParams cp, FftGeom fg,
                                                           float *__restrict__ simOut, float *__restrict__ boostOut,
@@ -749,6 +793,11 @@ __global__ __launch_bounds__(N / 16, 4) void corr_fft_kernel(const FileDesc *__r
         const float mT = fabsf((float)cpf.sumAT) / ((float)cp.aStdT * nT) * 1.0001f;
         const float mS = fabsf((float)cpf.sumAS) / ((float)cp.aStdS * nS) * 1.0001f;
         const float wT = cp.w, wS = 1.0f - cp.w, relErr = fg.relErr;
+        // g and u of the block (fft_blkgu_kernel): errX = mX uX + (1 + ehX) gX + ehX with ehX = absX / sd + relErr (1 + uX),
+        // everything that does not depend on the window formed here
+        const float4 gu = blkgu[blockIdx.x];
+        const float ehT0 = relErr * (1.0f + gu.y), ehS0 = relErr * (1.0f + gu.w);
+        const float erT0 = mT * gu.y + gu.x, erS0 = mS * gu.w + gu.z, erT1 = 1.0f + gu.x, erS1 = 1.0f + gu.z;
         // (the records of G windows per thread are on their way at a time; 8 instead of 4 changes nothing measurable)
         constexpr int G = 4;
 #pragma unroll
@@ -756,24 +805,19 @@ __global__ __launch_bounds__(N / 16, 4) void corr_fft_kernel(const FileDesc *__r
 #pragma unroll
             for (int u = 0; u < G; u++) ups[m0 + u] = -INFINITY;
             if (m0 * T < bd.valid) {  // (uniform over the workgroup)
-                float4 rec[G];
+                float2 rec[G];
 #pragma unroll
                 for (int u = 0; u < G; u++) {
                     const int k = tid + (m0 + u) * T;
-                    rec[u] = st.rec[bd.win + (k < bd.valid ? k : 0)];
+                    rec[u] = rec2[bd.win + (k < bd.valid ? k : 0)];
                 }
 #pragma unroll
                 for (int u = 0; u < G; u++) {
                     const int k = tid + (m0 + u) * T;
                     const bool live = k < bd.valid;
                     const float2 y = buf[fft_phys(live ? k : 0)];
-                    const unsigned int guT = __float_as_uint(rec[u].z), guS = __float_as_uint(rec[u].w);
-                    const float gT = half_from_bits(guT & 0xffffu), uT = half_from_bits(guT >> 16);
-                    const float gS = half_from_bits(guS & 0xffffu), uS = half_from_bits(guS >> 16);
-                    const float ehT = fmaf(absT, rec[u].x, relErr * (1.0f + uT));
-                    const float ehS = fmaf(absS, rec[u].y, relErr * (1.0f + uS));
-                    const float errT = fmaf(mT, uT, fmaf(1.0f + ehT, gT, ehT));
-                    const float errS = fmaf(mS, uS, fmaf(1.0f + ehS, gS, ehS));
+                    const float ehT = fmaf(absT, rec[u].x, ehT0), ehS = fmaf(absS, rec[u].y, ehS0);
+                    const float errT = fmaf(ehT, erT1, erT0), errS = fmaf(ehS, erS1, erS0);
                     const float e = fmaf(errT, wT, errS * wS) + 1e-5f;
                     const float sim = fmaf(kA * rec[u].x, y.x, (kB * rec[u].y) * y.y);
                     const bool eFin = e < INFINITY, fin = eFin && fabsf(sim) < INFINITY;
@@ -1022,7 +1066,7 @@ void fft_target_ready(sgz_context *ctx)
 
 void fft_screen_free(sgz_context *ctx)
 {
-    void *bufs[] = {ctx->d_fblocks, ctx->d_spec, ctx->d_aspec, ctx->d_fft_tab, ctx->d_blksq, ctx->d_blknorm, ctx->d_blklnmin, ctx->d_prelist, ctx->d_precount,
+    void *bufs[] = {ctx->d_fblocks, ctx->d_spec, ctx->d_aspec, ctx->d_fft_tab, ctx->d_blksq, ctx->d_blknorm, ctx->d_blklnmin, ctx->d_blkgu, ctx->d_wrec2, ctx->d_prelist, ctx->d_precount,
                     ctx->d_specscale, ctx->d_blkdq, ctx->d_blkq, ctx->d_aspecscale, ctx->d_tgtdq, ctx->d_tgt_z};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
@@ -1114,6 +1158,8 @@ int fft_screen_layout(sgz_context *ctx)
     if ((rc = ensure(ctx, ctx->d_blksq, ctx->blksq_cap, nb * (size_t)numCh))) return rc;
     if ((rc = ensure(ctx, ctx->d_blknorm, ctx->blknorm_cap, nb))) return rc;
     if ((rc = ensure(ctx, ctx->d_blklnmin, ctx->blklnmin_cap, nb))) return rc;
+    if ((rc = ensure(ctx, ctx->d_blkgu, ctx->blkgu_cap, nb))) return rc;
+    if ((rc = ensure(ctx, ctx->d_wrec2, ctx->wrec2_cap, (size_t)std::max<long long>(ctx->total_windows, 1)))) return rc;
     SGZ_HIP(ctx, hipMemcpyAsync(ctx->d_fblocks, ctx->h_fblocks.data(), sizeof(FftBlock) * nb, hipMemcpyHostToDevice,
                                 ctx->stream));
     ctx->fg = fg;
@@ -1153,6 +1199,9 @@ int fft_screen_prepare(sgz_context *ctx, int file_begin, int file_end, hipStream
     SGZ_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(fft_blklnmin_kernel, dim3(b1 - b0), dim3(256), 0, stream, ctx->d_fblocks + b0, ctx->d_wstat_h,
                        ctx->total_windows, ctx->d_blklnmin + b0);
+    SGZ_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(fft_blkgu_kernel, dim3(b1 - b0), dim3(256), 0, stream, ctx->d_fblocks + b0, ctx->d_wstat_h,
+                       ctx->total_windows, ctx->d_blkgu + b0, ctx->d_wrec2);
     SGZ_HIP(ctx, hipGetLastError());
     ctx->fc_begin = file_begin;
     ctx->fc_end = file_end;
@@ -1274,12 +1323,12 @@ int fft_screen_launch(sgz_context *ctx, int file_begin, int file_end, hipStream_
         if ((rc = set_lds(ctx, kern, lds))) return rc;
         if (start || stop)
             hipExtLaunchKernelGGL(kern, dim3(b1 - b0), dim3(N / 16), lds, stream, start, stop, 0, ctx->d_files, ctx->d_fblocks + b0,
-                                  ctx->d_spec, ctx->d_aspec, ctx->d_fft_tab, ctx->d_blknorm + b0, scales, blkq, ctx->d_aspecscale, ctx->d_tgtdq, ctx->d_blklnmin + b0,
+                                  ctx->d_spec, ctx->d_aspec, ctx->d_fft_tab, ctx->d_blknorm + b0, scales, blkq, ctx->d_aspecscale, ctx->d_tgtdq, ctx->d_blklnmin + b0, ctx->d_blkgu + b0, ctx->d_wrec2,
                                   ctx->d_wstat_h, ctx->total_windows, ctx->cp, fg, simOut, (float *)nullptr,
                                   lokey, lokeyNext, ctx->d_hflags, pre);
         else
             hipLaunchKernelGGL(kern, dim3(b1 - b0), dim3(N / 16), lds, stream, ctx->d_files, ctx->d_fblocks + b0, ctx->d_spec,
-                               ctx->d_aspec, ctx->d_fft_tab, ctx->d_blknorm + b0, scales, blkq, ctx->d_aspecscale, ctx->d_tgtdq, ctx->d_blklnmin + b0,
+                               ctx->d_aspec, ctx->d_fft_tab, ctx->d_blknorm + b0, scales, blkq, ctx->d_aspecscale, ctx->d_tgtdq, ctx->d_blklnmin + b0, ctx->d_blkgu + b0, ctx->d_wrec2,
                                ctx->d_wstat_h, ctx->total_windows, ctx->cp, fg, simOut, (float *)nullptr,
                                lokey, lokeyNext, ctx->d_hflags, pre);
         SGZ_HIP(ctx, hipGetLastError());

@@ -283,6 +283,10 @@ struct sgz_context {
     int fc_begin = 0, fc_end = 0;            // files whose spectra are current
     float *d_blklnmin = nullptr;             // per block: smallest ln(average loudness) of its windows
     size_t blklnmin_cap = 0;
+    float4 *d_blkgu = nullptr;               // per block: largest g and u of both channel groups over its windows ...
+    size_t blkgu_cap = 0;
+    float2 *d_wrec2 = nullptr;               // ... and per window 1 / sd of both groups (fft_blkgu_kernel)
+    size_t wrec2_cap = 0;
     // The spectral kernel does not write the boosts of its windows (4 of the bytes it would move per window; a
     // search needs the boost of the few windows it re-scores only).  boost_lazy[f] != 0: d_boost of file f is not
     // filled in; whoever reads it (dense reads, compaction over a mix of files) has boost_materialize fill it first
