@@ -613,13 +613,13 @@ def main() -> int:
         def spectral_roofline(kms, windows, geom):
             n, hop, blocks = geom
             ach = windows * 64.0 / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
-            # what the kernel is built to move: the blocks' spectra and 16 B of cached statistics per window in (20 B in
+            # what the kernel is built to move: the blocks' spectra and 8 B of cached statistics per window in (20 B in
             # blocks where some window's boost comes near maxBoost: none in this workload); out only the list of the
             # few windows that can hold their file's maximum and one bound per file
             q16 = spectra_q16
             # (16-bit spectra: 4 bytes per complex bin and a 4-byte scale per band of 64 bins; every workgroup also
             # reads the target's spectra, which the caches serve)
-            moved = blocks * (2.0 * NUM_CH * n + NUM_CH * n / 32.0 if q16 else 4.0 * NUM_CH * n) + windows * 16.0
+            moved = blocks * (2.0 * NUM_CH * n + NUM_CH * n / 32.0 if q16 else 4.0 * NUM_CH * n) + windows * 8.0
             return {
                 "bound": "hbm", "kernel": "corr_fft_kernel", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "frac": ach / PEAK_HBM_GBS,
