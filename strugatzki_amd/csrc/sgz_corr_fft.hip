@@ -13,7 +13,7 @@
 // the frequency domain, and inverts ONE complex transform per block whose real part is the loudness cross term
 // and whose imaginary part the cross term of the other channels.  It is bound by memory traffic: per block
 // 2 N numCh bytes of spectra (16-bit integers with one scale per band of 64 bins; 4 N numCh as fp32, on request) and
-// as much again of the target's out of the cache, per window 16 bytes of cached statistics in (20 where a window's
+// as much again of the target's out of the cache, per window 8 bytes of cached statistics in (20 where a window's
 // boost comes near the gate) and, for a search, nothing out but the few windows that can hold their file's
 // maximum (the largest lower bound of a file is kept per file).
 //
@@ -591,7 +591,8 @@ __global__ __launch_bounds__(256) void boost_fill_kernel(float *wstat, long long
 //   1. per bin j < N / 2: Zt = A_0 X_0, Zs = sum_{c >= 1} A_c X_c (A: conjugated target spectra / N), and the two
 //      Hermitian spectra combined into one, W[j] = Zt + i Zs, W[N - j] = conj(Zt) + i conj(Zs), written to LDS;
 //   2. inverse transform in LDS: w[k] = crossT[k] + i crossS[k];
-//   3. per window the bounds from its cached statics (sgz::SpectralStatics, 20 bytes per window).
+//   3. per window the bounds from its cached statics: a search reads the window's two 1 / sd (8 bytes, rec2) and the
+//      block's largest g and u (blkgu); the general path the full record (sgz::SpectralStatics, 20 bytes per window).
 // Q16: the spectra are 16-bit integers with band scales (four bins per 16-byte load); `blkq` holds the block's
 // rounding terms.
 template <int N, int NCH, bool Q16>
