@@ -265,6 +265,39 @@ def test_bounds_hold_on_awkward_data(spectral, case):
     assert [(g.file, g.start, g.stop) for g in got] == [(w.file, w.start, w.stop) for w in want]
 
 
+def test_flat_stretches_do_not_widen_their_neighbours_bounds(spectral):
+    """A search's launch takes the error terms g and u of a window as their largest values over the block's windows;
+    windows without spread (g huge or not finite) are kept out of those maxima and made certain candidates instead.
+    So next to flat stretches the ordinary windows keep bounds as tight as in a file without any."""
+    ctx = spectral
+    L, ts, nf, frames = 200, 11, 2, 5000
+    rng = np.random.default_rng(7)
+    plain = synth_db(nf, frames, ())
+    flat = [x.copy() for x in plain]
+    starts = list(range(100, frames - 600, 700))
+    for x in flat:
+        for a in starts:
+            x[a:a + 450] = x[a] + (rng.random((450, x.shape[1])) * 1e-4).astype(np.float32)
+    # windows that touch no flat stretch: [a + 450, a + 500] behind every stretch
+    ordinary = np.array([o for a in starts for o in range(a + 450, a + 501)])
+    norms = norms_default()
+    tgt = synth_target(ts, L)
+    cfg = corr_config(ts, L, num_matches=4, num_per_file=1)
+    widths = []
+    for db in (plain, flat):
+        _, sims, boosts = O.correlation_run(cfg, tgt, norms, db)
+        _load(ctx, db, norms)
+        ctx.corr_set_target(tgt[ts:ts + L], 0.5, 8.0)
+        ctx.corr_run_screen_f16(0, nf)
+        assert ctx.screen_kernel_in_use == "spectral"
+        _check_upper(ctx, sims, boosts, slack=np.inf)
+        d = np.concatenate([ctx.corr_read_dense(f)[0].astype(np.float64)[ordinary] - sims[f][ordinary] for f in range(nf)])
+        assert np.all(d >= 0.0)
+        widths.append(float(np.max(d)))
+    assert widths[0] < 2e-3
+    assert widths[1] < 3.0 * widths[0] + 1e-4, widths
+
+
 @pytest.mark.parametrize("num_matches,num_per_file,min_spacing", [(6, 1, 0), (6, 2, 10 * STEP), (5, 3, 0)])
 def test_search_is_the_same_with_either_kernel(ctx, monkeypatch, num_matches, num_per_file, min_spacing):
     """numPerFile = 1 (search over bounds) and the general path (exact head, screened tail over a file range that
