@@ -543,7 +543,10 @@ __global__ __launch_bounds__(256) void fft_blklnmin_kernel(const FftBlock *__res
 // is not finite or lies above kBlkGCap / kBlkUCap is left out of the maxima and gets 1 / sd = +inf, which makes its
 // bounds -inf .. +inf (a certain candidate: what its own large g did before), so that a stretch without spread does not
 // widen the bounds of the thousands of ordinary windows around it.  One workgroup of 256 threads per block.
-constexpr float kBlkGCap = 1.0e-4f, kBlkUCap = 32.0f;
+// (The caps sit well above what windows with a usable spread show -- g about 1e-6 at a standard deviation of a tenth of
+// the normalised range, 1e-3 at a four-hundredth of it -- and bound what one odd window can add to the error term of
+// its block's other windows: 2e-3 of the weight through g, 2.5e-4 through u.)
+constexpr float kBlkGCap = 2.0e-3f, kBlkUCap = 1024.0f;
 __global__ __launch_bounds__(256) void fft_blkgu_kernel(const FftBlock *__restrict__ blocks, float *wstat,
                                                         long long totalWindows, float4 *__restrict__ blkgu,
                                                         float2 *__restrict__ rec2)
