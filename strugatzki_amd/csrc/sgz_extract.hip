@@ -263,7 +263,10 @@ struct FastTables {
     const float *dct;     // [numCoeffs][kBands]
 };
 
-template <bool kMono>
+// kS16 (mono only): `pcm` holds little-endian 16-bit samples as an audio file does; a lane's two samples are one
+// 32-bit word, turned into floats as pcm16_decode_kernel does (v / 32768), so the features are bit-identical to
+// those of the decoded samples -- without the pass that decodes them and the float copy of the whole signal.
+template <bool kMono, bool kS16 = false>
 __global__ __launch_bounds__(64 * kFastWaves) void extract1024_kernel(const float *__restrict__ pcm, FastTables tb,
                                                                     SegTable st, ExtractParams p,
                                                                     float *__restrict__ out)
@@ -293,13 +296,18 @@ __global__ __launch_bounds__(64 * kFastWaves) void extract1024_kernel(const floa
     // 1. load + mix down + window: point n = lane + 64 r holds x[2 n] + i x[2 n + 1]
     f2 v[8];
     if (analysed) {
-        const float *base = pcm + s0 * (kMono ? 1 : p.numChannels);  // scalar
+        static_assert(!kS16 || kMono, "16-bit samples are read directly from mono input only");
+        const float *base = kS16 ? pcm : pcm + s0 * (kMono ? 1 : p.numChannels);  // scalar
+        const unsigned int *base16 = reinterpret_cast<const unsigned int *>(reinterpret_cast<const short *>(pcm) + s0);
         const f2 *hw = reinterpret_cast<const f2 *>(tb.hann2);
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const int n = lane + 64 * r;
             f2 x;
-            if (kMono) {
+            if (kS16) {
+                const unsigned int w = base16[n];  // samples 2 n (low half) and 2 n + 1
+                x = f2{(float)(short)(w & 0xffffu) * (1.0f / 32768.0f), (float)(short)(w >> 16) * (1.0f / 32768.0f)};
+            } else if (kMono) {
                 x = *reinterpret_cast<const f2 *>(base + 2 * n);
             } else {
 #pragma unroll
@@ -775,7 +783,9 @@ int sgz_extract_pcm(sgz_context *ctx, const void *pcm, int sample_format, int64_
     const size_t rawBytes = (size_t)sampleBytes * (size_t)num_frames * num_channels;
     const bool native = sample_format == SGZ_PCM_F32;
     const size_t outBytes = sizeof(float) * (size_t)nOut * (num_coeffs + 1);
-    SGZ_HIP(ctx, hipMalloc(&dPcm.p, pcmBytes));
+    // 16-bit little-endian mono samples at the default FFT size: the extraction kernel reads them as they are
+    const bool direct16 = fast && num_channels == 1 && sample_format == SGZ_PCM_S16;
+    if (!direct16) SGZ_HIP(ctx, hipMalloc(&dPcm.p, pcmBytes));
     SGZ_HIP(ctx, hipMalloc(&dTw.p, sizeof(float2) * tw.size()));
     SGZ_HIP(ctx, hipMalloc(&dHann.p, sizeof(float) * hann.size()));
     SGZ_HIP(ctx, hipMalloc(&dDct.p, sizeof(float) * dct.size()));
@@ -790,9 +800,11 @@ int sgz_extract_pcm(sgz_context *ctx, const void *pcm, int sample_format, int64_
         SGZ_HIP(ctx, hipMalloc(&dRaw.p, rawBytes + 16));
         const int crc = sgz::copy_large(ctx, dRaw.p, pcm, rawBytes, false);
         if (crc) return crc;
-        const int drc = sgz::pcm_decode_launch(ctx, dRaw.p, (long long)num_frames * num_channels, sample_format,
-                                               (float *)dPcm.p, ctx->stream);
-        if (drc) return drc;
+        if (!direct16) {
+            const int drc = sgz::pcm_decode_launch(ctx, dRaw.p, (long long)num_frames * num_channels, sample_format,
+                                                   (float *)dPcm.p, ctx->stream);
+            if (drc) return drc;
+        }
     }
     SGZ_HIP(ctx, hipMemcpyAsync(dTw.p, tw.data(), sizeof(float2) * tw.size(), hipMemcpyHostToDevice, ctx->stream));
     SGZ_HIP(ctx, hipMemcpyAsync(dHann.p, hann.data(), sizeof(float) * hann.size(), hipMemcpyHostToDevice, ctx->stream));
@@ -826,7 +838,10 @@ int sgz_extract_pcm(sgz_context *ctx, const void *pcm, int sample_format, int64_
     }
     SGZ_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     const size_t fastLds = sizeof(float) * (size_t)num_coeffs * kBands;
-    if (fast && num_channels == 1)
+    if (direct16)
+        hipLaunchKernelGGL((extract1024_kernel<true, true>), dim3((unsigned)((nOut + kFastWaves - 1) / kFastWaves)),
+                           dim3(64 * kFastWaves), fastLds, ctx->stream, (const float *)dRaw.p, ft, st, p, (float *)dOut.p);
+    else if (fast && num_channels == 1)
         hipLaunchKernelGGL(extract1024_kernel<true>, dim3((unsigned)((nOut + kFastWaves - 1) / kFastWaves)),
                            dim3(64 * kFastWaves), fastLds, ctx->stream, (const float *)dPcm.p, ft, st, p, (float *)dOut.p);
     else if (fast)
