@@ -263,10 +263,12 @@ struct FastTables {
     const float *dct;     // [numCoeffs][kBands]
 };
 
-// kS16 (mono only): `pcm` holds little-endian 16-bit samples as an audio file does; a lane's two samples are one
-// 32-bit word, turned into floats as pcm16_decode_kernel does (v / 32768), so the features are bit-identical to
-// those of the decoded samples -- without the pass that decodes them and the float copy of the whole signal.
-template <bool kMono, bool kS16 = false>
+// kS16: `pcm` holds little-endian 16-bit samples as an audio file does (mono: a lane's two samples are one 32-bit
+// word), turned into floats as pcm16_decode_kernel does (v / 32768), so the features are bit-identical to those of
+// the decoded samples -- without the pass that decodes them and the float copy of the whole signal.
+// kCh: 1 = mono, 2 = two interleaved channels (one 16- or 8-byte load per lane, the channels taken as the general
+// path takes them: 0 + first + second for the mix), 0 = any number of channels.
+template <int kCh, bool kS16 = false>
 __global__ __launch_bounds__(64 * kFastWaves) void extract1024_kernel(const float *__restrict__ pcm, FastTables tb,
                                                                     SegTable st, ExtractParams p,
                                                                     float *__restrict__ out)
@@ -296,29 +298,42 @@ __global__ __launch_bounds__(64 * kFastWaves) void extract1024_kernel(const floa
     // 1. load + mix down + window: point n = lane + 64 r holds x[2 n] + i x[2 n + 1]
     f2 v[8];
     if (analysed) {
-        static_assert(!kS16 || kMono, "16-bit samples are read directly from mono input only");
-        const float *base = kS16 ? pcm : pcm + s0 * (kMono ? 1 : p.numChannels);  // scalar
-        const unsigned int *base16 = reinterpret_cast<const unsigned int *>(reinterpret_cast<const short *>(pcm) + s0);
+        const float *base = kS16 ? pcm : pcm + s0 * (kCh ? kCh : p.numChannels);  // scalar
+        const short *b16 = reinterpret_cast<const short *>(pcm) + s0 * (kCh ? kCh : p.numChannels);
+        const unsigned int *base16 = reinterpret_cast<const unsigned int *>(b16);  // mono: s0 is even
+        auto smp = [&](int j) -> float { return kS16 ? (float)b16[j] * (1.0f / 32768.0f) : base[j]; };
         const f2 *hw = reinterpret_cast<const f2 *>(tb.hann2);
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const int n = lane + 64 * r;
             f2 x;
-            if (kS16) {
+            if (kCh == 2) {  // frames 2 n and 2 n + 1: (first, second) each
+                float4 a;
+                if (kS16) {
+                    const uint2 w = *reinterpret_cast<const uint2 *>(b16 + 4 * n);
+                    a = make_float4((float)(short)(w.x & 0xffffu) * (1.0f / 32768.0f), (float)(short)(w.x >> 16) * (1.0f / 32768.0f),
+                                    (float)(short)(w.y & 0xffffu) * (1.0f / 32768.0f), (float)(short)(w.y >> 16) * (1.0f / 32768.0f));
+                } else {
+                    a = *reinterpret_cast<const float4 *>(base + 4 * n);
+                }
+                if (p.channels == 1) x = f2{a.x, a.z};
+                else if (p.channels == 2) x = f2{a.y, a.w};
+                else x = f2{(0.0f + a.x) + a.y, (0.0f + a.z) + a.w};
+            } else if (kS16 && kCh == 1) {
                 const unsigned int w = base16[n];  // samples 2 n (low half) and 2 n + 1
                 x = f2{(float)(short)(w & 0xffffu) * (1.0f / 32768.0f), (float)(short)(w >> 16) * (1.0f / 32768.0f)};
-            } else if (kMono) {
+            } else if (kCh == 1) {
                 x = *reinterpret_cast<const f2 *>(base + 2 * n);
             } else {
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
-                    const float *fr = base + (2 * n + h) * p.numChannels;
+                    const int fr = (2 * n + h) * p.numChannels;
                     float xs;
-                    if (p.channels == 1) xs = fr[0];
-                    else if (p.channels == 2) xs = fr[p.numChannels - 1];
+                    if (p.channels == 1) xs = smp(fr);
+                    else if (p.channels == 2) xs = smp(fr + p.numChannels - 1);
                     else {
                         xs = 0.0f;
-                        for (int c = 0; c < p.numChannels; c++) xs += fr[c];
+                        for (int c = 0; c < p.numChannels; c++) xs += smp(fr + c);
                     }
                     x[h] = xs;
                 }
@@ -783,8 +798,9 @@ int sgz_extract_pcm(sgz_context *ctx, const void *pcm, int sample_format, int64_
     const size_t rawBytes = (size_t)sampleBytes * (size_t)num_frames * num_channels;
     const bool native = sample_format == SGZ_PCM_F32;
     const size_t outBytes = sizeof(float) * (size_t)nOut * (num_coeffs + 1);
-    // 16-bit little-endian mono samples at the default FFT size: the extraction kernel reads them as they are
-    const bool direct16 = fast && num_channels == 1 && sample_format == SGZ_PCM_S16;
+    // 16-bit little-endian samples at the default FFT size: the extraction kernel reads them as they are
+    // (an odd hop -- fftOverlap = fftSize -- would put a lane's 32-bit word of two samples on an odd sample)
+    const bool direct16 = fast && sample_format == SGZ_PCM_S16 && p.step % 2 == 0;
     if (!direct16) SGZ_HIP(ctx, hipMalloc(&dPcm.p, pcmBytes));
     SGZ_HIP(ctx, hipMalloc(&dTw.p, sizeof(float2) * tw.size()));
     SGZ_HIP(ctx, hipMalloc(&dHann.p, sizeof(float) * hann.size()));
@@ -838,15 +854,17 @@ int sgz_extract_pcm(sgz_context *ctx, const void *pcm, int sample_format, int64_
     }
     SGZ_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     const size_t fastLds = sizeof(float) * (size_t)num_coeffs * kBands;
-    if (direct16)
-        hipLaunchKernelGGL((extract1024_kernel<true, true>), dim3((unsigned)((nOut + kFastWaves - 1) / kFastWaves)),
-                           dim3(64 * kFastWaves), fastLds, ctx->stream, (const float *)dRaw.p, ft, st, p, (float *)dOut.p);
-    else if (fast && num_channels == 1)
-        hipLaunchKernelGGL(extract1024_kernel<true>, dim3((unsigned)((nOut + kFastWaves - 1) / kFastWaves)),
-                           dim3(64 * kFastWaves), fastLds, ctx->stream, (const float *)dPcm.p, ft, st, p, (float *)dOut.p);
-    else if (fast)
-        hipLaunchKernelGGL(extract1024_kernel<false>, dim3((unsigned)((nOut + kFastWaves - 1) / kFastWaves)),
-                           dim3(64 * kFastWaves), fastLds, ctx->stream, (const float *)dPcm.p, ft, st, p, (float *)dOut.p);
+    const dim3 fastGrid((unsigned)((nOut + kFastWaves - 1) / kFastWaves)), fastBlock(64 * kFastWaves);
+    const int chK = num_channels == 1 ? 1 : (num_channels == 2 && p.step % 2 == 0) ? 2 : 0;  // the kernel's kCh
+    auto launchFast = [&](auto kernel, const void *src) {
+        hipLaunchKernelGGL(kernel, fastGrid, fastBlock, fastLds, ctx->stream, (const float *)src, ft, st, p, (float *)dOut.p);
+    };
+    if (direct16 && chK == 1) launchFast(extract1024_kernel<1, true>, dRaw.p);
+    else if (direct16 && chK == 2) launchFast(extract1024_kernel<2, true>, dRaw.p);
+    else if (direct16) launchFast(extract1024_kernel<0, true>, dRaw.p);
+    else if (fast && chK == 1) launchFast(extract1024_kernel<1, false>, dPcm.p);
+    else if (fast && chK == 2) launchFast(extract1024_kernel<2, false>, dPcm.p);
+    else if (fast) launchFast(extract1024_kernel<0, false>, dPcm.p);
     else
         hipLaunchKernelGGL(extract_kernel, dim3(grid), dim3(64 * kFramesPerBlock), lds, ctx->stream,
                            (const float *)dPcm.p, (const float2 *)dTw.p, (const float *)dHann.p, (const float *)dDct.p,

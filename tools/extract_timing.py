@@ -24,3 +24,10 @@ for it in range(3):
     dt = time.perf_counter() - t0
     k = N.lib.sgz_last_kernel_ms(ctx._h)
     print(f"int16: frames {f.shape[0]}  wall {dt*1e3:.1f} ms (incl. H2D of {x16.nbytes/1e6:.0f} MB)  kernel {k:.3f} ms")
+# twenty minutes of stereo, as floats and as 16-bit samples
+xs = (0.1 * rng.standard_normal((52_920_000, 2), dtype=np.float32))
+for name, a in (("stereo float", xs), ("stereo int16", np.round(xs * 32767).astype(np.int16))):
+    for it in range(2):
+        f = ctx.extract(a, 44100.0)
+        k = N.lib.sgz_last_kernel_ms(ctx._h)
+    print(f"{name}: frames {f.shape[0]}  kernel {k:.3f} ms")
