@@ -39,6 +39,7 @@ struct ExtractParams {
     int step, overlap;
     int numCoeffs;
     float norm;            // 1 / (fftSize / 4)^2
+    int swap16;            // 16-bit samples read in place are big-endian
 };
 
 struct BandTable {
@@ -263,7 +264,7 @@ struct FastTables {
     const float *dct;     // [numCoeffs][kBands]
 };
 
-// kS16: `pcm` holds little-endian 16-bit samples as an audio file does (mono: a lane's two samples are one 32-bit
+// kS16: `pcm` holds 16-bit samples as an audio file does, of either byte order (mono: a lane's two samples are one 32-bit
 // word), turned into floats as pcm16_decode_kernel does (v / 32768), so the features are bit-identical to those of
 // the decoded samples -- without the pass that decodes them and the float copy of the whole signal.
 // kCh: 1 = mono, 2 = two interleaved channels (one 16- or 8-byte load per lane, the channels taken as the general
@@ -301,7 +302,13 @@ __global__ __launch_bounds__(64 * kFastWaves) void extract1024_kernel(const floa
         const float *base = kS16 ? pcm : pcm + s0 * (kCh ? kCh : p.numChannels);  // scalar
         const short *b16 = reinterpret_cast<const short *>(pcm) + s0 * (kCh ? kCh : p.numChannels);
         const unsigned int *base16 = reinterpret_cast<const unsigned int *>(b16);  // mono: s0 is even
-        auto smp = [&](int j) -> float { return kS16 ? (float)b16[j] * (1.0f / 32768.0f) : base[j]; };
+        // two 16-bit samples in one word, each with its bytes in the order the file has them -> little-endian
+        auto le2 = [&](unsigned int w) -> unsigned int {
+            return p.swap16 ? ((w & 0x00ff00ffu) << 8) | ((w >> 8) & 0x00ff00ffu) : w;
+        };
+        auto smp = [&](int j) -> float {
+            return kS16 ? (float)(short)le2((unsigned short)b16[j]) * (1.0f / 32768.0f) : base[j];
+        };
         const f2 *hw = reinterpret_cast<const f2 *>(tb.hann2);
 #pragma unroll
         for (int r = 0; r < 8; r++) {
@@ -310,7 +317,9 @@ __global__ __launch_bounds__(64 * kFastWaves) void extract1024_kernel(const floa
             if (kCh == 2) {  // frames 2 n and 2 n + 1: (first, second) each
                 float4 a;
                 if (kS16) {
-                    const uint2 w = *reinterpret_cast<const uint2 *>(b16 + 4 * n);
+                    uint2 w = *reinterpret_cast<const uint2 *>(b16 + 4 * n);
+                    w.x = le2(w.x);
+                    w.y = le2(w.y);
                     a = make_float4((float)(short)(w.x & 0xffffu) * (1.0f / 32768.0f), (float)(short)(w.x >> 16) * (1.0f / 32768.0f),
                                     (float)(short)(w.y & 0xffffu) * (1.0f / 32768.0f), (float)(short)(w.y >> 16) * (1.0f / 32768.0f));
                 } else {
@@ -320,7 +329,7 @@ __global__ __launch_bounds__(64 * kFastWaves) void extract1024_kernel(const floa
                 else if (p.channels == 2) x = f2{a.y, a.w};
                 else x = f2{(0.0f + a.x) + a.y, (0.0f + a.z) + a.w};
             } else if (kS16 && kCh == 1) {
-                const unsigned int w = base16[n];  // samples 2 n (low half) and 2 n + 1
+                const unsigned int w = le2(base16[n]);  // samples 2 n (low half) and 2 n + 1
                 x = f2{(float)(short)(w & 0xffffu) * (1.0f / 32768.0f), (float)(short)(w >> 16) * (1.0f / 32768.0f)};
             } else if (kCh == 1) {
                 x = *reinterpret_cast<const f2 *>(base + 2 * n);
@@ -798,9 +807,10 @@ int sgz_extract_pcm(sgz_context *ctx, const void *pcm, int sample_format, int64_
     const size_t rawBytes = (size_t)sampleBytes * (size_t)num_frames * num_channels;
     const bool native = sample_format == SGZ_PCM_F32;
     const size_t outBytes = sizeof(float) * (size_t)nOut * (num_coeffs + 1);
-    // 16-bit little-endian samples at the default FFT size: the extraction kernel reads them as they are
+    // 16-bit samples at the default FFT size: the extraction kernel reads them as they are
     // (an odd hop -- fftOverlap = fftSize -- would put a lane's 32-bit word of two samples on an odd sample)
-    const bool direct16 = fast && sample_format == SGZ_PCM_S16 && p.step % 2 == 0;
+    const bool direct16 = fast && sampleBytes == 2 && p.step % 2 == 0;
+    p.swap16 = direct16 && bigEndian;
     if (!direct16) SGZ_HIP(ctx, hipMalloc(&dPcm.p, pcmBytes));
     SGZ_HIP(ctx, hipMalloc(&dTw.p, sizeof(float2) * tw.size()));
     SGZ_HIP(ctx, hipMalloc(&dHann.p, sizeof(float) * hann.size()));

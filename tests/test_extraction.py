@@ -215,16 +215,17 @@ def test_gpu_sample_layouts_decode_on_the_device(ctx, n, channels):
 @pytest.mark.parametrize("channels", [2, 3])
 @pytest.mark.parametrize("behavior", [0, 1, 2])
 def test_gpu_16_bit_samples_read_in_place_mix_like_floats(ctx, channels, behavior):
-    """Little-endian 16-bit input is read by the extraction kernel itself (no decoded copy): with every way of
+    """16-bit input of either byte order is read by the extraction kernel itself (no decoded copy): with every way of
     taking the channels (mix, first, last) the features are those of the same values as float32, bit for bit."""
     x = _signal(40000, seed=70 + channels, channels=2)
     if channels == 3:
         x = np.ascontiguousarray(np.concatenate([x, x[::-1, :1] * np.float32(0.5)], axis=1))
     raw, vals = _layouts(x)[2]
     want = ctx.extract(np.ascontiguousarray(vals, np.float32), SR, channels_behavior=behavior)
-    got = ctx.extract_pcm(raw, 2, x.shape[0], channels, SR, channels_behavior=behavior)
-    assert got.shape == want.shape and got.shape[0] > 70
-    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    for code in (2, 3):  # little- and big-endian
+        got = ctx.extract_pcm(_layouts(x)[code][0], code, x.shape[0], channels, SR, channels_behavior=behavior)
+        assert got.shape == want.shape and got.shape[0] > 70
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), code
     if channels == 2 and behavior != 2:
         # two channels have a load pattern of their own; a silent third channel sends the same samples down the
         # path for any number of channels
