@@ -77,7 +77,8 @@ def test_oracle_sine_peaks_in_the_right_band():
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,channels,behavior,fft,overlap,coeffs", [
     (30000, 1, 0, 1024, 2, 13), (30000, 2, 0, 1024, 2, 13), (20000, 2, 1, 1024, 2, 13), (20000, 2, 2, 1024, 2, 13),
-    (25000, 1, 0, 2048, 4, 20), (9000, 1, 0, 256, 1, 5), (700, 1, 0, 1024, 2, 13), (1025, 1, 0, 1024, 2, 13)])
+    (25000, 1, 0, 2048, 4, 20), (9000, 1, 0, 256, 1, 5), (700, 1, 0, 1024, 2, 13), (1025, 1, 0, 1024, 2, 13),
+    (2500, 1, 0, 1024, 1024, 13), (2500, 2, 0, 1024, 1024, 13), (9000, 2, 0, 1024, 8, 13), (9000, 3, 0, 1024, 4, 13)])
 def test_gpu_features_match_the_oracle(ctx, n, channels, behavior, fft, overlap, coeffs):
     x = _signal(n, seed=n, channels=channels)
     want = O.extract(x, SR, fft, overlap, coeffs, behavior)
@@ -231,6 +232,19 @@ def test_gpu_16_bit_samples_read_in_place_mix_like_floats(ctx, channels, behavio
         # path for any number of channels
         padded = np.ascontiguousarray(np.concatenate([vals, np.zeros_like(vals[:, :1])], axis=1))
         assert np.array_equal(ctx.extract(padded, SR, channels_behavior=behavior).view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("channels", [1, 2])
+def test_gpu_16_bit_samples_with_a_hop_of_one_sample(ctx, channels):
+    """fftOverlap = fftSize: windows start on odd samples, where no two 16-bit samples share an aligned word."""
+    x = _signal(2600, seed=5, channels=channels)
+    for code in (2, 3):
+        raw, vals = _layouts(x)[code]
+        want = ctx.extract(np.ascontiguousarray(vals, np.float32), SR, 1024, 1024)
+        got = ctx.extract_pcm(raw, code, x.shape[0], channels, SR, 1024, 1024)
+        assert got.shape == want.shape and got.shape[0] > 1500
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), code
 
 
 @pytest.mark.gpu
