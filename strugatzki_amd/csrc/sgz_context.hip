@@ -166,9 +166,15 @@ int sgz_synchronize(sgz_context *ctx)
 // ctx->stream is waited for first.
 int sgz::copy_large(sgz_context *ctx, void *dst, const void *src, size_t bytes, bool to_host)
 {
-    constexpr size_t kChunk = (size_t)16 << 20;  // half a staging buffer
+    // Half a staging buffer, and what a thread copies at a time.  To the device a thread's first transfer starts
+    // only after its first memcpy: 4 MB pieces instead of 16 take 318 MB up in 9.0 instead of 9.7-12 ms and make
+    // the pool worth its threads from 32 MB on (106 MB: 3.5 instead of 4.8 ms through one pageable copy); to the
+    // host 4 MB pieces are slower (a 6 GB raster: 0.26 instead of 0.16 s), so that direction keeps 16 MB.
+    constexpr size_t kHalf = (size_t)16 << 20;
     constexpr int kThreads = 8;
-    if (bytes < 16 * kChunk) {
+    const size_t kChunk = to_host ? kHalf : (size_t)4 << 20;
+    const size_t kMin = to_host ? 16 * kHalf : (size_t)32 << 20;
+    if (bytes < kMin) {
         SGZ_HIP(ctx, hipMemcpyAsync(dst, src, bytes, to_host ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice, ctx->stream));
         SGZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
         return SGZ_OK;
@@ -177,7 +183,7 @@ int sgz::copy_large(sgz_context *ctx, void *dst, const void *src, size_t bytes, 
     if (ctx->pin_pool.empty()) {
         for (int t = 0; t < kThreads; t++) {
             sgz_context::PinSlot slot;
-            if (hipHostMalloc(&slot.pin, 2 * kChunk, hipHostMallocDefault) != hipSuccess ||
+            if (hipHostMalloc(&slot.pin, 2 * kHalf, hipHostMallocDefault) != hipSuccess ||
                 hipStreamCreateWithFlags(&slot.stream, hipStreamNonBlocking) != hipSuccess ||
                 hipEventCreateWithFlags(&slot.done[0], hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&slot.done[1], hipEventDisableTiming) != hipSuccess) {
