@@ -248,6 +248,26 @@ def test_gpu_16_bit_samples_with_a_hop_of_one_sample(ctx, channels):
 
 
 @pytest.mark.gpu
+def test_gpu_random_layouts_channel_counts_and_hops(ctx):
+    """Random draws of length, channel count, way of taking the channels, hop and sample layout: the features from
+    the file's bytes are those from the float values they stand for, bit for bit."""
+    rng = np.random.default_rng(2024)
+    for case in range(60):
+        channels = int(rng.integers(1, 5))
+        n = int(rng.integers(0, 30000))
+        overlap = int(rng.choice([1, 2, 2, 2, 4, 8, 16, 64]))
+        behavior = int(rng.integers(0, 3))
+        code = int(rng.integers(0, 8))
+        x = (0.3 * rng.standard_normal((max(n, 1), channels))).astype(np.float32).clip(-1, 0.99999)[:n]
+        raw, vals = _layouts(x)[code]
+        want = ctx.extract(np.ascontiguousarray(vals, np.float32).reshape(n, channels), SR, 1024, overlap, 13, behavior)
+        got = ctx.extract_pcm(raw, code, n, channels, SR, 1024, overlap, 13, behavior)
+        what = (case, n, channels, overlap, behavior, code)
+        assert got.shape == want.shape, what
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), what
+
+
+@pytest.mark.gpu
 def test_gpu_integer_arrays_go_up_as_they_are(ctx):
     x = _signal(25000, seed=12, channels=2)
     i16 = np.round(x * 32767).astype(np.int16)
