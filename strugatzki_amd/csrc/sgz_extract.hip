@@ -612,6 +612,36 @@ __global__ __launch_bounds__(256) void pcm_decode_kernel(const unsigned char *__
     }
 }
 
+// 3 or 4 bytes per sample, four samples per thread: three or four 32-bit loads, one 16-byte store; the same values as
+// pcm_decode_kernel, which takes the last, partial group.
+template <int kBytes>
+__global__ __launch_bounds__(256) void pcm_decode4_kernel(const unsigned int *__restrict__ raw, long long groups,
+                                                          int bigEndian, int isFloat, float *__restrict__ out)
+{
+    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < groups; g += (long long)gridDim.x * 256) {
+        unsigned int w[kBytes];
+#pragma unroll
+        for (int k = 0; k < kBytes; k++) w[k] = raw[g * kBytes + k];
+        float f[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            unsigned int u;  // the sample, most significant byte first
+            if (kBytes == 4) {
+                u = bigEndian ? __builtin_bswap32(w[j]) : w[j];
+            } else {
+                unsigned int b[3];
+#pragma unroll
+                for (int k = 0; k < 3; k++) b[k] = (w[(3 * j + k) >> 2] >> (8 * ((3 * j + k) & 3))) & 0xffu;
+                u = bigEndian ? (b[0] << 16) | (b[1] << 8) | b[2] : (b[2] << 16) | (b[1] << 8) | b[0];
+            }
+            if (kBytes == 3) f[j] = (float)((int)(u << 8) >> 8) * (1.0f / 8388608.0f);
+            else if (isFloat) f[j] = __uint_as_float(u);
+            else f[j] = (float)((double)(int)u * (1.0 / 2147483648.0));
+        }
+        *reinterpret_cast<float4 *>(out + 4 * g) = make_float4(f[0], f[1], f[2], f[3]);
+    }
+}
+
 }  // namespace
 
 namespace sgz {
@@ -644,11 +674,22 @@ int pcm_decode_launch(sgz_context *ctx, const void *raw, long long count, int sa
     if (pcm_format(sample_format, &sampleBytes, &bigEndian, &isFloat)) return ctx->fail(SGZ_E_ARG, "unknown sample format");
     if (count <= 0) return SGZ_OK;
     const int grid = (int)std::min<long long>((count / (sampleBytes == 2 ? 8 : 1) + 255) / 256 + 1, 8192);
-    if (sampleBytes == 2)
+    if (sampleBytes == 2) {
         hipLaunchKernelGGL(pcm16_decode_kernel, dim3(grid), dim3(256), 0, stream, (const uint4 *)raw, count, bigEndian, out);
-    else
-        hipLaunchKernelGGL(pcm_decode_kernel, dim3(grid), dim3(256), 0, stream, (const unsigned char *)raw, count,
-                           sampleBytes, bigEndian, isFloat, out);
+    } else {
+        const long long groups = count >> 2, tail = count & 3;
+        const int grid4 = (int)std::min<long long>((groups + 255) / 256, 16384);
+        if (groups && sampleBytes == 3)
+            hipLaunchKernelGGL(pcm_decode4_kernel<3>, dim3(grid4), dim3(256), 0, stream, (const unsigned int *)raw, groups,
+                               bigEndian, isFloat, out);
+        else if (groups)
+            hipLaunchKernelGGL(pcm_decode4_kernel<4>, dim3(grid4), dim3(256), 0, stream, (const unsigned int *)raw, groups,
+                               bigEndian, isFloat, out);
+        if (tail)
+            hipLaunchKernelGGL(pcm_decode_kernel, dim3(1), dim3(256), 0, stream,
+                               (const unsigned char *)raw + 4 * groups * sampleBytes, tail, sampleBytes, bigEndian, isFloat,
+                               out + 4 * groups);
+    }
     SGZ_HIP(ctx, hipGetLastError());
     return SGZ_OK;
 }
