@@ -76,6 +76,7 @@ void sgz_destroy(sgz_context *ctx)
     (void)hipSetDevice(ctx->device);
     for (auto &f : ctx->files)
         if (f.owned && f.d_raw) (void)hipFree(f.d_raw);
+    for (void *slab : ctx->db_slabs) (void)hipFree(slab);
     void *bufs[] = {ctx->d_planar_f, ctx->d_planar_h, ctx->d_aprime, ctx->d_aprime_f, ctx->d_aimg_h, ctx->d_tnorm,
                     ctx->d_files,    ctx->d_tiles,    ctx->d_tiles_h, ctx->d_ptiles,  ctx->d_planar, ctx->d_prefix,
                     ctx->d_tbase,    ctx->d_sim,      ctx->d_boost,   ctx->d_cand,    ctx->d_hflags,

@@ -1703,6 +1703,31 @@ int sgz::noalloc_scratch_init(sgz_context *ctx)
     return SGZ_OK;
 }
 
+// Device memory for the frames of a database file: a piece of the current slab, or an allocation of its own for a
+// large file (f.owned).  256-byte aligned either way.
+static int db_file_alloc(sgz_context *ctx, size_t bytes, DbFile &f)
+{
+    constexpr size_t kSlab = (size_t)32 << 20, kLargest = (size_t)8 << 20;
+    const size_t need = (std::max<size_t>(bytes, 4) + 255) & ~(size_t)255;
+    if (need > kLargest) {
+        SGZ_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&f.d_raw), need));
+        f.owned = true;
+        return SGZ_OK;
+    }
+    if (need > ctx->db_slab_left) {
+        void *slab = nullptr;
+        SGZ_HIP(ctx, hipMalloc(&slab, kSlab));
+        ctx->db_slabs.push_back(slab);
+        ctx->db_slab_cur = static_cast<char *>(slab);
+        ctx->db_slab_left = kSlab;
+    }
+    f.d_raw = reinterpret_cast<float *>(ctx->db_slab_cur);
+    f.owned = false;
+    ctx->db_slab_cur += need;
+    ctx->db_slab_left -= need;
+    return SGZ_OK;
+}
+
 // ---------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------
@@ -1719,6 +1744,10 @@ int sgz_db_reset(sgz_context *ctx, int num_channels)
     for (auto &f : ctx->files)
         if (f.owned && f.d_raw) SGZ_HIP(ctx, hipFree(f.d_raw));
     ctx->files.clear();
+    for (void *slab : ctx->db_slabs) (void)hipFree(slab);
+    ctx->db_slabs.clear();
+    ctx->db_slab_cur = nullptr;
+    ctx->db_slab_left = 0;
     ctx->db_tag.clear();
     ctx->db_serial++;
     ctx->ring_images.clear();
@@ -1748,10 +1777,12 @@ int sgz_db_add_file(sgz_context *ctx, const float *frames, int64_t num_frames)
     SGZ_HIP(ctx, hipSetDevice(ctx->device));
     DbFile f;
     f.frames = num_frames;
-    f.owned = true;
     const size_t bytes = sizeof(float) * (size_t)num_frames * ctx->numCh;
-    SGZ_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&f.d_raw), bytes ? bytes : 4));
-    if (bytes) SGZ_HIP(ctx, hipMemcpy(f.d_raw, frames, bytes, hipMemcpyHostToDevice));
+    if (const int arc = db_file_alloc(ctx, bytes, f)) return arc;
+    if (bytes && hipMemcpy(f.d_raw, frames, bytes, hipMemcpyHostToDevice) != hipSuccess) {
+        if (f.owned) (void)hipFree(f.d_raw);
+        return ctx->fail(SGZ_E_HIP, "upload of the frames failed");
+    }
     ctx->files.push_back(f);
     ctx->db_tag.clear();
     ctx->db_serial++;
@@ -1770,9 +1801,8 @@ int sgz_db_add_file_pcm(sgz_context *ctx, const void *samples, int sample_format
     SGZ_HIP(ctx, hipSetDevice(ctx->device));
     DbFile f;
     f.frames = num_frames;
-    f.owned = true;
     const size_t count = (size_t)num_frames * ctx->numCh, bytes = sizeof(float) * count, rawBytes = (size_t)sampleBytes * count;
-    SGZ_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&f.d_raw), bytes ? bytes : 4));
+    if (const int arc = db_file_alloc(ctx, bytes, f)) return arc;
     if (count) {
         // the file's own bytes go up (into a buffer kept on the context) and are decoded there: no pass over the
         // samples on the host
@@ -1782,7 +1812,7 @@ int sgz_db_add_file_pcm(sgz_context *ctx, const void *samples, int sample_format
             ctx->pcm_stage_cap = 0;
             const size_t want = rawBytes + rawBytes / 4 + 16;
             if (hipMalloc(&ctx->d_pcm_stage, want) != hipSuccess) {
-                (void)hipFree(f.d_raw);
+                if (f.owned) (void)hipFree(f.d_raw);
                 return ctx->fail(SGZ_E_HIP, "hipMalloc of the sample staging buffer failed");
             }
             ctx->pcm_stage_cap = want;
@@ -1793,7 +1823,7 @@ int sgz_db_add_file_pcm(sgz_context *ctx, const void *samples, int sample_format
         // (the staging buffer is reused by the next file: its decode must have read it)
         if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = ctx->fail(SGZ_E_HIP, "sample decode failed");
         if (rc) {
-            (void)hipFree(f.d_raw);
+            if (f.owned) (void)hipFree(f.d_raw);
             return rc;
         }
     }

@@ -16,6 +16,7 @@
 #include <unordered_map>
 
 #include "strugatzki_amd.hpp"
+#include "sgz_readahead.hpp"
 
 namespace fs = std::filesystem;
 
@@ -227,15 +228,16 @@ std::vector<Match> runFeatureCorrelationMulti(const std::vector<sgz_context *> &
         const char *have = sgz_db_tag(ctxs[(size_t)c]);
         if (have && tag == have) continue;  // resident already
         check(ctxs[(size_t)c], sgz_db_reset(ctxs[(size_t)c], numCh));
-        for (size_t k = 0; k < ids[(size_t)c].size(); k++) {
+        std::vector<std::string> paths;
+        for (int32_t g : ids[(size_t)c]) paths.push_back(extrDBs[(size_t)g].featureOutput);
+        // (:169; the file's bytes as they are -- big-endian floats -- decoded on the device)
+        forEachFileReadAhead(paths, [&](size_t k, const PcmData &af) {
             const int g = ids[(size_t)c][k];
             checkAborted(obs, 0.5 * (double)g / (double)std::max(nf, 1));  // :164
-            // (:169; the file's bytes as they are -- big-endian floats -- decoded on the device)
-            const PcmData af = readAudioFilePcm(extrDBs[(size_t)g].featureOutput);
             if (af.numChannels != numCh)
-                throw Error(SGZ_E_IO, "feature file " + extrDBs[(size_t)g].featureOutput + " has the wrong number of channels");
+                throw Error(SGZ_E_IO, "feature file " + paths[k] + " has the wrong number of channels");
             check(ctxs[(size_t)c], sgz_db_add_file_pcm(ctxs[(size_t)c], af.samples(), af.sampleFormat, af.numFrames));
-        }
+        });
         check(ctxs[(size_t)c], sgz_db_set_tag(ctxs[(size_t)c], tag.c_str()));
     }
     for (sgz_context *c : ctxs) {
@@ -529,9 +531,8 @@ std::vector<std::pair<double, double>> runFeatureStats(sgz_context *ctx, const s
     if (!ctx) throw Error(SGZ_E_ARG, "null context");
     if (featureFiles.empty()) throw Error(SGZ_E_ARG, "no feature files");
     int numCh = 0;
-    for (size_t i = 0; i < featureFiles.size(); i++) {
+    forEachFileReadAhead(featureFiles, [&](size_t i, const PcmData &af) {  // (decoded on the device)
         checkAborted(obs, 0.8 * (double)i / (double)featureFiles.size());
-        const PcmData af = readAudioFilePcm(featureFiles[i]);  // (decoded on the device)
         if (i == 0) {
             numCh = af.numChannels;
             check(ctx, sgz_db_reset(ctx, numCh));
@@ -540,7 +541,7 @@ std::vector<std::pair<double, double>> runFeatureStats(sgz_context *ctx, const s
         }
         if (af.numFrames < 1) throw Error(SGZ_E_IO, "feature file " + featureFiles[i] + " is empty");
         check(ctx, sgz_db_add_file_pcm(ctx, af.samples(), af.sampleFormat, af.numFrames));
-    }
+    });
     std::vector<double> mm((size_t)numCh * 2);
     check(ctx, sgz_feature_stats(ctx, 0, (int)featureFiles.size(), mm.data(), nullptr));
     std::vector<std::pair<double, double>> out;

@@ -173,6 +173,11 @@ struct sgz_context {
     size_t half_stage_halfwords = 0;
     bool half_img_dirty = false;
     hipEvent_t tgt_event = nullptr;        // the target's upload on `stream`, for the other stream that reads it
+    // database files of up to 8 MB are carved from slabs of 32 MB (a hipMalloc per file costs 70 us: a third of
+    // what loading a five-minute feature file takes); released by sgz_db_reset and sgz_destroy
+    std::vector<void *> db_slabs;
+    char *db_slab_cur = nullptr;
+    size_t db_slab_left = 0;
     void *d_pcm_stage = nullptr;           // device: a file's samples as the file holds them, before sgz_db_add_file_pcm decodes them
     size_t pcm_stage_cap = 0;
     unsigned char *h_tgt_stage = nullptr;  // pinned: what sgz_corr_set_target uploads, written in place and copied

@@ -10,3 +10,9 @@ g++ -std=c++17 -O1 -g -fno-omit-frame-pointer -fsanitize=address,undefined -fno-
 D=$(mktemp -d)
 $ROOT/build/san/host_sanitize $D
 rm -rf $D
+# the read-ahead threads of the database loops under ThreadSanitizer
+g++ -std=c++17 -O1 -g -fno-omit-frame-pointer -fsanitize=thread -pthread -I$ROOT/include \
+    $ROOT/tools/readahead_sanitize.cpp $ROOT/strugatzki_amd/csrc/sgz_audiofile.cpp -o $ROOT/build/san/readahead_sanitize
+D=$(mktemp -d)
+$ROOT/build/san/readahead_sanitize $D
+rm -rf $D
