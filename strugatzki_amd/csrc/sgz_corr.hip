@@ -1867,9 +1867,8 @@ int sgz_db_add_synthetic(sgz_context *ctx, uint64_t seed, int64_t file_id, int64
         if (plants[k].file == file_id) mine.push_back(plants[k]);
     DbFile f;
     f.frames = num_frames;
-    f.owned = true;
     const size_t elems = (size_t)num_frames * ctx->numCh;
-    SGZ_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&f.d_raw), elems ? elems * sizeof(float) : 4));
+    if (const int arc = db_file_alloc(ctx, elems * sizeof(float), f)) return arc;
     sgz_plant *d_pl = nullptr;
     if (!mine.empty()) {
         SGZ_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&d_pl), sizeof(sgz_plant) * mine.size()));
