@@ -1803,7 +1803,18 @@ int sgz_db_add_file_pcm(sgz_context *ctx, const void *samples, int sample_format
     f.frames = num_frames;
     const size_t count = (size_t)num_frames * ctx->numCh, bytes = sizeof(float) * count, rawBytes = (size_t)sampleBytes * count;
     if (const int arc = db_file_alloc(ctx, bytes, f)) return arc;
-    if (count) {
+    if (count && sampleBytes == 4) {
+        // a layout as wide as the decoded frames (what feature files hold: big-endian floats): the file's bytes go
+        // straight to the file's place and are decoded there, on the stream every later reader is ordered after --
+        // no staging buffer, nothing to wait for
+        int rc = SGZ_OK;
+        if (hipMemcpy(f.d_raw, samples, rawBytes, hipMemcpyHostToDevice) != hipSuccess) rc = ctx->fail(SGZ_E_HIP, "upload of the samples failed");
+        if (!rc) rc = sgz::pcm_decode_launch(ctx, f.d_raw, (long long)count, sample_format, f.d_raw, ctx->stream);
+        if (rc) {
+            if (f.owned) (void)hipFree(f.d_raw);
+            return rc;
+        }
+    } else if (count) {
         // the file's own bytes go up (into a buffer kept on the context) and are decoded there: no pass over the
         // samples on the host
         if (rawBytes + 16 > ctx->pcm_stage_cap) {

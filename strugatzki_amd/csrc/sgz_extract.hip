@@ -592,8 +592,8 @@ __global__ __launch_bounds__(256) void pcm16_decode_kernel(const uint4 *__restri
 }
 
 // The other layouts byte by byte: bytes = 3 or 4 per sample, integer or (4 bytes only) IEEE float.
-__global__ __launch_bounds__(256) void pcm_decode_kernel(const unsigned char *__restrict__ raw, long long count, int bytes,
-                                                         int bigEndian, int isFloat, float *__restrict__ out)
+__global__ __launch_bounds__(256) void pcm_decode_kernel(const unsigned char *raw, long long count, int bytes,
+                                                         int bigEndian, int isFloat, float *out)
 {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long long)gridDim.x * 256) {
         const unsigned char *b = raw + i * bytes;
@@ -614,9 +614,10 @@ __global__ __launch_bounds__(256) void pcm_decode_kernel(const unsigned char *__
 
 // 3 or 4 bytes per sample, four samples per thread: three or four 32-bit loads, one 16-byte store; the same values as
 // pcm_decode_kernel, which takes the last, partial group.
+// For 4-byte layouts `out` may be `raw` itself (a thread reads its words before it writes them: no __restrict__).
 template <int kBytes>
-__global__ __launch_bounds__(256) void pcm_decode4_kernel(const unsigned int *__restrict__ raw, long long groups,
-                                                          int bigEndian, int isFloat, float *__restrict__ out)
+__global__ __launch_bounds__(256) void pcm_decode4_kernel(const unsigned int *raw, long long groups, int bigEndian,
+                                                          int isFloat, float *out)
 {
     for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < groups; g += (long long)gridDim.x * 256) {
         unsigned int w[kBytes];
@@ -667,7 +668,7 @@ int pcm_format(int sample_format, int *sample_bytes, int *big_endian, int *is_fl
 }
 
 // `count` samples of the layout `sample_format` in device memory (16-byte aligned, readable up to the next multiple
-// of 16 bytes) to fp32, on `stream`.
+// of 16 bytes) to fp32, on `stream`.  4-byte layouts may be decoded in place (out == raw).
 int pcm_decode_launch(sgz_context *ctx, const void *raw, long long count, int sample_format, float *out, hipStream_t stream)
 {
     int sampleBytes, bigEndian, isFloat;
